@@ -1,0 +1,168 @@
+/*
+ * tapstark.h -- C ABI of the MI355X-native tap-stark prover hot path (libtapstark_hip.so).
+ *
+ * Drop-in boundary for the reference's uni-stark/fri prover.  Every entry
+ * point names the reference interface it replaces (paths relative to the tap-stark repository).
+ * Conventions:
+ *   - field elements cross the boundary as CANONICAL u32 (reference basic/src/field/mod.rs:48-63
+ *     `as_u32_vec`); an EF4 element is its 4 coefficients [c0,c1,c2,c3];
+ *   - digests/commitments are 8 u32 words = the reference's [[u8;4];8] (little-endian words);
+ *   - host buffers are caller-owned and only read during the call; device objects are
+ *     library-owned handles, freed explicitly;
+ *   - every function returns a ts_status (0 = ok) and never throws or aborts; where the reference
+ *     panics (assert!/expect) the status is TS_ERR_INVARIANT and ts_last_error() holds the text;
+ *   - a context is driven by one host thread; different contexts are independent;
+ *   - there is NO CPU fallback: without a HIP device ts_ctx_create fails.
+ */
+#ifndef TAPSTARK_H
+#define TAPSTARK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int ts_status;
+enum {
+    TS_OK = 0,
+    TS_ERR_INVALID = 1,
+    TS_ERR_HIP = 2,
+    TS_ERR_OOM = 3,
+    TS_ERR_UNSUPPORTED = 4,
+    TS_ERR_INVARIANT = 5,
+    TS_ERR_BUFFER = 6
+};
+
+typedef struct ts_ctx ts_ctx;               /* one per GPU */
+typedef struct ts_matrix ts_matrix;         /* device-resident RowMajorMatrix<Val> */
+typedef struct ts_pcs_data ts_pcs_data;     /* Pcs::ProverData / BFMmcs::ProverData */
+typedef struct ts_air ts_air;               /* compiled constraint tape */
+typedef struct ts_challenger ts_challenger; /* BfChallenger (host side) */
+
+/* reference fri/src/config.rs:11-16 FriConfig (the `mmcs` field is the built-in Blake3 Merkle
+ * MMCS) */
+typedef struct {
+    uint32_t log_blowup;
+    uint32_t num_queries;
+    uint32_t proof_of_work_bits;
+} ts_fri_config;
+
+/* ------------------------------------------------------------------ context */
+ts_status ts_ctx_create(int device, ts_ctx** out);
+void ts_ctx_destroy(ts_ctx* ctx);
+const char* ts_last_error(const ts_ctx* ctx);
+ts_status ts_ctx_synchronize(ts_ctx* ctx);
+/* HIP stream every kernel of this context is launched on (as a void*), for event timing */
+void* ts_ctx_stream(ts_ctx* ctx);
+/* per-stage timers (HIP events on the context's stream); names follow the reference's tracing
+ * spans (uni-stark/src/prover.rs:53,82,121; fri/src/two_adic_pcs.rs:355-374; fri/src/prover.rs:18,45,92) */
+ts_status ts_ctx_set_timing(ts_ctx* ctx, int enabled);
+/* writes "name=ms;name=ms;..." of the stages recorded since the last call */
+ts_status ts_ctx_take_timings(ts_ctx* ctx, char* buf, size_t cap);
+
+/* per-kernel timers: HIP events recorded on the context's stream around EVERY kernel launch
+ * (resolved lazily, no sync per kernel); take writes "kernel=launches:total_ms;..." */
+ts_status ts_ctx_set_kernel_timing(ts_ctx* ctx, int enabled);
+ts_status ts_ctx_take_kernel_timings(ts_ctx* ctx, char* buf, size_t cap);
+
+/* ------------------------------------------------------------------ matrices */
+/* RowMajorMatrix<Val>::new(values, width): host row-major canonical values -> device */
+ts_status ts_matrix_upload(ts_ctx* ctx, const uint32_t* host_row_major, uint64_t height,
+                           uint32_t width, ts_matrix** out);
+/* same from a device pointer (e.g. a torch tensor's data_ptr); the data is copied */
+ts_status ts_matrix_from_device(ts_ctx* ctx, const uint32_t* dev_row_major, uint64_t height,
+                                uint32_t width, ts_matrix** out);
+ts_status ts_matrix_dims(const ts_matrix* m, uint64_t* height, uint32_t* width);
+/* row-major, natural row order */
+ts_status ts_matrix_download(ts_ctx* ctx, const ts_matrix* m, uint32_t* host_row_major);
+void ts_matrix_free(ts_ctx* ctx, ts_matrix* m);
+
+/* ------------------------------------------------------------------ AIR */
+/* Tape = serialised result of get_symbolic_constraints (uni-stark/src/symbolic_builder.rs:52-64):
+ *   [0]=0x54415354 [1]=1 [2]=width [3]=n_public [4]=n_nodes [5]=n_constraints,
+ *   n_nodes x {op,a,b}, n_constraints node ids in assert_zero order.
+ * ops (symbolic_expression.rs:12-37): 0 CONST(a=value) 1 MAIN(a=offset 0|1,b=column)
+ *   2 PUBLIC(a=index) 3 IS_FIRST_ROW 4 IS_LAST_ROW 5 IS_TRANSITION 6 ADD(a,b) 7 SUB(a,b) 8 NEG(a)
+ *   9 MUL(a,b) */
+ts_status ts_air_compile(ts_ctx* ctx, const uint32_t* tape, size_t n_words, ts_air** out);
+/* get_log_quotient_degree, uni-stark/src/symbolic_builder.rs:15-32 */
+ts_status ts_air_info(const ts_air* air, uint32_t* width, uint32_t* n_public,
+                      uint32_t* max_constraint_degree, uint32_t* log_quotient_degree);
+void ts_air_free(ts_ctx* ctx, ts_air* air);
+
+/* ------------------------------------------------------------------ PCS */
+/* Pcs::commit, fri/src/two_adic_pcs.rs:227-245: for each (domain, evals): coset LDE with shift
+ * 31/domain.shift, bit-reversed rows, then mmcs.commit.  All matrices must have equal height
+ * (mixed heights: SURVEY.md section 8(f) rank 4).  The matrices are consumed (like the moved
+ * `RowMajorMatrix` arguments).  root_out = commitment. */
+ts_status ts_pcs_commit(ts_ctx* ctx, const ts_fri_config* cfg, uint32_t n_mats,
+                        ts_matrix* const* evals, const uint32_t* domain_shifts,
+                        uint32_t root_out[8], ts_pcs_data** out);
+/* BFMmcs::get_matrices (basic/src/mmcs/bf_mmcs.rs:52): committed LDE `idx`, row-major,
+ * bit-reversed row order, N x width */
+ts_status ts_pcs_data_lde(ts_ctx* ctx, const ts_pcs_data* d, uint32_t idx, uint32_t* host_row_major);
+ts_status ts_pcs_data_info(const ts_pcs_data* d, uint32_t* n_mats, uint32_t* log_height);
+/* Merkle digest layer `level` (0 = leaves), (N >> level) x 8 words */
+ts_status ts_pcs_data_digests(ts_ctx* ctx, const ts_pcs_data* d, uint32_t level, uint32_t* host_out);
+/* BFMmcs::open_batch (bf_mmcs.rs:37-42; taptree_mmcs.rs:46-63): rows of every matrix at `index`
+ * (concatenated) and the sibling path (log_height x 8 words, leaf level first) */
+ts_status ts_pcs_open_batch(ts_ctx* ctx, const ts_pcs_data* d, uint64_t index, uint32_t* rows_out,
+                            uint32_t* path_out);
+void ts_pcs_data_free(ts_ctx* ctx, ts_pcs_data* d);
+
+/* get_evaluations_on_domain + quotient_values + flatten_to_base + split_evals
+ * (two_adic_pcs.rs:247-258; uni-stark/src/prover.rs:68-80,122-194): quotient_degree matrices of
+ * n x 4, ready for ts_pcs_commit with domain shifts 31 * w_{n*qd}^c.
+ * chunks_out must have room for 2^log_quotient_degree handles. */
+ts_status ts_quotient_chunks(ts_ctx* ctx, const ts_pcs_data* trace_data, uint32_t log_blowup,
+                             const ts_air* air, const uint32_t* public_values, uint32_t n_public,
+                             const uint32_t alpha[4], ts_matrix** chunks_out);
+
+/* Pcs::open up to the FRI input (two_adic_pcs.rs:312-389) for the prove() shape: round 0 = trace
+ * data opened at {zeta, zeta*w_n}, round 1 = quotient data (qd matrices) opened at {zeta}.
+ * opened_out: (2*w + 4*qd) EF4 in proof order (trace_local, trace_next, chunks);
+ * reduced_out: N EF4 (the single FRI input vector), or NULL. */
+ts_status ts_pcs_open_reduce(ts_ctx* ctx, const ts_fri_config* cfg, const ts_pcs_data* trace_data,
+                             const ts_pcs_data* quotient_data, const uint32_t zeta[4],
+                             const uint32_t batch_alpha[4], uint32_t* opened_out,
+                             uint32_t* reduced_out);
+
+/* FriGenericConfig::fold_matrix, two_adic_pcs.rs:116-147 (host in, host out; 2h EF4 -> h EF4) */
+ts_status ts_fri_fold(ts_ctx* ctx, const uint32_t* in, uint64_t h, const uint32_t beta[4],
+                      uint32_t* out);
+
+/* ------------------------------------------------------------------ challenger */
+/* BfChallenger::new, basic/src/challenger/mod.rs:122-137.  permutation: 0 = Blake3Permutation
+ * (mod.rs:23-49), 1 = reverse-the-state test permutation (fri/tests/fri.rs:35-48).
+ * sample_ext: 1 = F is EF4 (as in uni-stark/tests/fib_air.rs:108), 0 = BabyBear. */
+ts_status ts_chal_new(int permutation, int sample_ext, ts_challenger** out);
+ts_status ts_chal_clone(const ts_challenger* c, ts_challenger** out);
+void ts_chal_free(ts_challenger* c);
+void ts_chal_observe(ts_challenger* c, uint32_t word);                   /* mod.rs:183-194 */
+void ts_chal_observe_commitment(ts_challenger* c, const uint32_t d[8]);  /* mod.rs:197-223 */
+void ts_chal_sample(ts_challenger* c, uint32_t out[4]);                  /* mod.rs:261-313 */
+uint64_t ts_chal_sample_bits(ts_challenger* c, uint32_t bits);           /* mod.rs:341-348 */
+int ts_chal_check_witness(ts_challenger* c, uint32_t bits, uint32_t witness); /* mod.rs:108-114 */
+/* mod.rs:95-105; TS_ERR_INVARIANT when no witness in [0, 4096) ("failed to find witness") */
+ts_status ts_chal_grind(ts_challenger* c, uint32_t bits, uint32_t* witness);
+/* state export for tests: state[16], n_in, in[8], n_out, out[8] (34 words) */
+void ts_chal_state(const ts_challenger* c, uint32_t out[34]);
+
+/* ------------------------------------------------------------------ prove */
+/* uni_stark::prove(config, air, challenger, trace, public_values) -> Proof
+ * (uni-stark/src/prover.rs:25-119).  `trace` is consumed.  The proof is written in the TSPF v1
+ * wire format: header, commitments, opened_values, opening_proof.  Like a release
+ * build of the reference, it does not run check_constraints (prover.rs:40-41 is debug-only). */
+ts_status ts_prove(ts_ctx* ctx, const ts_fri_config* cfg, const ts_air* air, ts_challenger* chal,
+                   ts_matrix* trace, const uint32_t* public_values, uint32_t n_public,
+                   uint32_t* proof_out, size_t cap_words, size_t* n_words_out);
+
+/* library/ABI version (bumped on any incompatible change) */
+uint32_t ts_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -3,3 +3,5 @@ prover interface over the C-ABI HIP library (include/tapstark.h)."""
 from . import air, airs  # noqa: F401
 from .air import (BaseAir, SymbolicAirBuilder, air_tape, get_log_quotient_degree,  # noqa: F401
                   get_max_constraint_degree, get_symbolic_constraints)
+from .stark import (BfChallenger, CompiledAir, Context, DeviceMatrix, FriConfig, PcsData,  # noqa: F401
+                    Proof, StarkConfig, TwoAdicFriPcs, default_context, prove)

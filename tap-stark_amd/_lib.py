@@ -1,0 +1,106 @@
+"""ctypes loader of the C-ABI HIP library (include/tapstark.h).
+
+There is no CPU fallback: if the library is missing or no HIP device is present, every product
+entry point raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "lib", "libtapstark_hip.so")
+
+u32p = C.POINTER(C.c_uint32)
+voidpp = C.POINTER(C.c_void_p)
+
+# every symbol include/tapstark.h declares (tests check the built library exports all of them)
+ABI_SYMBOLS = [
+    "ts_abi_version", "ts_ctx_create", "ts_ctx_destroy", "ts_last_error", "ts_ctx_synchronize",
+    "ts_ctx_stream", "ts_ctx_set_timing", "ts_ctx_take_timings", "ts_ctx_set_kernel_timing",
+    "ts_ctx_take_kernel_timings", "ts_matrix_upload",
+    "ts_matrix_from_device", "ts_matrix_dims", "ts_matrix_download", "ts_matrix_free",
+    "ts_air_compile", "ts_air_info", "ts_air_free", "ts_pcs_commit", "ts_pcs_data_lde",
+    "ts_pcs_data_info", "ts_pcs_data_digests", "ts_pcs_open_batch", "ts_pcs_data_free",
+    "ts_quotient_chunks", "ts_pcs_open_reduce", "ts_fri_fold", "ts_chal_new", "ts_chal_clone",
+    "ts_chal_free", "ts_chal_observe", "ts_chal_observe_commitment", "ts_chal_sample",
+    "ts_chal_sample_bits", "ts_chal_check_witness", "ts_chal_grind", "ts_chal_state", "ts_prove",
+]
+
+STATUS = {0: "TS_OK", 1: "TS_ERR_INVALID", 2: "TS_ERR_HIP", 3: "TS_ERR_OOM",
+          4: "TS_ERR_UNSUPPORTED", 5: "TS_ERR_INVARIANT", 6: "TS_ERR_BUFFER"}
+
+
+class TsError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"{STATUS.get(code, code)}: {msg}")
+        self.code = code
+
+
+class FriConfigC(C.Structure):
+    _fields_ = [("log_blowup", C.c_uint32), ("num_queries", C.c_uint32),
+                ("proof_of_work_bits", C.c_uint32)]
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Loads the library; raises if it has not been built (no fallback path exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise TsError(2, f"{LIB_PATH} is missing: run __graft_entry__.build() "
+                             "(python -m tapstark_amd.build); there is no CPU fallback")
+        l = C.CDLL(LIB_PATH)
+        l.ts_last_error.restype = C.c_char_p
+        l.ts_last_error.argtypes = [C.c_void_p]
+        l.ts_ctx_stream.restype = C.c_void_p
+        l.ts_ctx_stream.argtypes = [C.c_void_p]
+        l.ts_chal_sample_bits.restype = C.c_uint64
+        l.ts_abi_version.restype = C.c_uint32
+        for name in ("ts_ctx_destroy", "ts_matrix_free", "ts_air_free", "ts_pcs_data_free",
+                     "ts_chal_free", "ts_chal_observe", "ts_chal_observe_commitment",
+                     "ts_chal_sample", "ts_chal_state"):
+            getattr(l, name).restype = None
+        l.ts_ctx_destroy.argtypes = [C.c_void_p]
+        l.ts_matrix_free.argtypes = [C.c_void_p, C.c_void_p]
+        l.ts_air_free.argtypes = [C.c_void_p, C.c_void_p]
+        l.ts_pcs_data_free.argtypes = [C.c_void_p, C.c_void_p]
+        l.ts_chal_free.argtypes = [C.c_void_p]
+        l.ts_chal_observe.argtypes = [C.c_void_p, C.c_uint32]
+        l.ts_chal_observe_commitment.argtypes = [C.c_void_p, u32p]
+        l.ts_chal_sample.argtypes = [C.c_void_p, u32p]
+        l.ts_chal_state.argtypes = [C.c_void_p, u32p]
+        l.ts_chal_sample_bits.argtypes = [C.c_void_p, C.c_uint32]
+        l.ts_chal_check_witness.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+        l.ts_chal_grind.argtypes = [C.c_void_p, C.c_uint32, u32p]
+        l.ts_chal_new.argtypes = [C.c_int, C.c_int, voidpp]
+        l.ts_chal_clone.argtypes = [C.c_void_p, voidpp]
+        l.ts_ctx_create.argtypes = [C.c_int, voidpp]
+        l.ts_ctx_synchronize.argtypes = [C.c_void_p]
+        l.ts_ctx_set_timing.argtypes = [C.c_void_p, C.c_int]
+        l.ts_ctx_take_timings.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+        l.ts_ctx_set_kernel_timing.argtypes = [C.c_void_p, C.c_int]
+        l.ts_ctx_take_kernel_timings.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+        l.ts_matrix_upload.argtypes = [C.c_void_p, u32p, C.c_uint64, C.c_uint32, voidpp]
+        l.ts_matrix_from_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, voidpp]
+        l.ts_matrix_dims.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), u32p]
+        l.ts_matrix_download.argtypes = [C.c_void_p, C.c_void_p, u32p]
+        l.ts_air_compile.argtypes = [C.c_void_p, u32p, C.c_size_t, voidpp]
+        l.ts_air_info.argtypes = [C.c_void_p, u32p, u32p, u32p, u32p]
+        l.ts_pcs_commit.argtypes = [C.c_void_p, C.POINTER(FriConfigC), C.c_uint32, voidpp, u32p,
+                                    u32p, voidpp]
+        l.ts_pcs_data_lde.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, u32p]
+        l.ts_pcs_data_info.argtypes = [C.c_void_p, u32p, u32p]
+        l.ts_pcs_data_digests.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, u32p]
+        l.ts_pcs_open_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, u32p, u32p]
+        l.ts_quotient_chunks.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, u32p,
+                                         C.c_uint32, u32p, voidpp]
+        l.ts_pcs_open_reduce.argtypes = [C.c_void_p, C.POINTER(FriConfigC), C.c_void_p, C.c_void_p,
+                                         u32p, u32p, u32p, u32p]
+        l.ts_fri_fold.argtypes = [C.c_void_p, u32p, C.c_uint64, u32p, u32p]
+        l.ts_prove.argtypes = [C.c_void_p, C.POINTER(FriConfigC), C.c_void_p, C.c_void_p, C.c_void_p,
+                               u32p, C.c_uint32, u32p, C.c_size_t, C.POINTER(C.c_size_t)]
+        _lib = l
+    return _lib

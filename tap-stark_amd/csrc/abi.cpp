@@ -1,0 +1,404 @@
+// extern "C" boundary (include/tapstark.h): plain pointers and sizes, status codes, no exceptions
+// across the ABI.
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/tapstark.h"
+#include "host.hpp"
+
+struct ts_ctx {
+    ts::Context ctx;
+    explicit ts_ctx(int dev) : ctx(dev) {}
+};
+struct ts_matrix {
+    ts::DeviceMatrix m;
+};
+struct ts_pcs_data {
+    std::unique_ptr<ts::PcsData> d;
+};
+struct ts_air {
+    ts::AirProgram prog;
+    ts::DevBuf<uint32_t> code;
+};
+struct ts_challenger {
+    ts::BfChallenger c;
+    ts_challenger(int perm, bool ext) : c(perm, ext) {}
+};
+
+namespace {
+
+thread_local std::string g_create_error;
+
+template <class F>
+ts_status guard(ts_ctx* ctx, F&& f) {
+    try {
+        if (ctx) TS_HIP(hipSetDevice(ctx->ctx.device));
+        f();
+        return TS_OK;
+    } catch (const ts::Error& e) {
+        if (ctx) ctx->ctx.last_error = e.what();
+        else g_create_error = e.what();
+        return e.code;
+    } catch (const std::bad_alloc&) {
+        if (ctx) ctx->ctx.last_error = "host allocation failed";
+        return TS_ERR_OOM;
+    } catch (const std::exception& e) {
+        if (ctx) ctx->ctx.last_error = e.what();
+        return TS_ERR_INVALID;
+    }
+}
+
+ts::Ef load_ef(const uint32_t w[4]) {
+    for (int i = 0; i < 4; i++)
+        TS_REQUIRE(w[i] < ts::P, ts::TS_ERR_INVALID, "non-canonical extension-field element");
+    return ts::Ef{{w[0], w[1], w[2], w[3]}};
+}
+
+ts::FriConfig load_cfg(const ts_fri_config* cfg) {
+    TS_REQUIRE(cfg != nullptr, ts::TS_ERR_INVALID, "null FriConfig");
+    TS_REQUIRE(cfg->log_blowup >= 1 && cfg->log_blowup <= 8, ts::TS_ERR_INVALID,
+               "FriConfig.log_blowup must be in [1, 8]");
+    TS_REQUIRE(cfg->num_queries >= 1 && cfg->num_queries <= 4096, ts::TS_ERR_INVALID,
+               "FriConfig.num_queries must be in [1, 4096]");
+    TS_REQUIRE(cfg->proof_of_work_bits <= 31, ts::TS_ERR_INVALID, "FriConfig.proof_of_work_bits > 31");
+    ts::FriConfig f;
+    f.log_blowup = cfg->log_blowup;
+    f.num_queries = cfg->num_queries;
+    f.proof_of_work_bits = cfg->proof_of_work_bits;
+    return f;
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t ts_abi_version(void) { return 1; }
+
+ts_status ts_ctx_create(int device, ts_ctx** out) {
+    if (!out) return TS_ERR_INVALID;
+    *out = nullptr;
+    return guard(nullptr, [&] { *out = new ts_ctx(device); });
+}
+void ts_ctx_destroy(ts_ctx* ctx) { delete ctx; }
+const char* ts_last_error(const ts_ctx* ctx) {
+    return ctx ? ctx->ctx.last_error.c_str() : g_create_error.c_str();
+}
+ts_status ts_ctx_synchronize(ts_ctx* ctx) {
+    if (!ctx) return TS_ERR_INVALID;
+    return guard(ctx, [&] { ctx->ctx.sync(); });
+}
+void* ts_ctx_stream(ts_ctx* ctx) { return ctx ? (void*)ctx->ctx.stream : nullptr; }
+ts_status ts_ctx_set_timing(ts_ctx* ctx, int enabled) {
+    if (!ctx) return TS_ERR_INVALID;
+    ctx->ctx.timing = enabled != 0;
+    ctx->ctx.stage_ms.clear();
+    return TS_OK;
+}
+ts_status ts_ctx_take_timings(ts_ctx* ctx, char* buf, size_t cap) {
+    if (!ctx || !buf || cap == 0) return TS_ERR_INVALID;
+    std::string s;
+    for (auto& kv : ctx->ctx.stage_ms) {
+        char tmp[160];
+        snprintf(tmp, sizeof tmp, "%s=%.6f;", kv.first.c_str(), kv.second);
+        s += tmp;
+    }
+    ctx->ctx.stage_ms.clear();
+    if (s.size() + 1 > cap) return TS_ERR_BUFFER;
+    memcpy(buf, s.c_str(), s.size() + 1);
+    return TS_OK;
+}
+
+ts_status ts_ctx_set_kernel_timing(ts_ctx* ctx, int enabled) {
+    if (!ctx) return TS_ERR_INVALID;
+    return guard(ctx, [&] {
+        ctx->ctx.take_kernel_timings();  // drop anything pending
+        ctx->ctx.kernel_timing = enabled != 0;
+    });
+}
+ts_status ts_ctx_take_kernel_timings(ts_ctx* ctx, char* buf, size_t cap) {
+    if (!ctx || !buf || cap == 0) return TS_ERR_INVALID;
+    return guard(ctx, [&] {
+        std::string s;
+        for (auto& kv : ctx->ctx.take_kernel_timings()) {
+            char tmp[200];
+            snprintf(tmp, sizeof tmp, "%s=%llu:%.6f;", kv.first.c_str(),
+                     (unsigned long long)kv.second.first, kv.second.second);
+            s += tmp;
+        }
+        TS_REQUIRE(s.size() + 1 <= cap, ts::TS_ERR_BUFFER, "timing buffer too small");
+        memcpy(buf, s.c_str(), s.size() + 1);
+    });
+}
+
+// ------------------------------------------------------------------ matrices
+static ts_status matrix_from(ts_ctx* ctx, const uint32_t* src, uint64_t height, uint32_t width,
+                             hipMemcpyKind kind, ts_matrix** out) {
+    if (!ctx || !out) return TS_ERR_INVALID;
+    *out = nullptr;
+    return guard(ctx, [&] {
+        TS_REQUIRE(src && height >= 1 && width >= 1, ts::TS_ERR_INVALID, "matrix: empty");
+        TS_REQUIRE((height & (height - 1)) == 0, ts::TS_ERR_INVALID, "matrix: height must be a power of two");
+        TS_REQUIRE(height <= (1ull << 27), ts::TS_ERR_INVALID, "matrix: height > 2^27");
+        auto m = std::make_unique<ts_matrix>();
+        m->m.buf = ts::DevBuf<uint32_t>(&ctx->ctx, (size_t)height * width);
+        m->m.height = height;
+        m->m.width = width;
+        m->m.layout = ts::DeviceMatrix::ROW_MAJOR;
+        TS_HIP(hipMemcpyAsync(m->m.buf.p, src, (size_t)height * width * 4, kind, ctx->ctx.stream));
+        ctx->ctx.sync();
+        *out = m.release();
+    });
+}
+ts_status ts_matrix_upload(ts_ctx* ctx, const uint32_t* host, uint64_t height, uint32_t width,
+                           ts_matrix** out) {
+    return matrix_from(ctx, host, height, width, hipMemcpyHostToDevice, out);
+}
+ts_status ts_matrix_from_device(ts_ctx* ctx, const uint32_t* dev, uint64_t height, uint32_t width,
+                                ts_matrix** out) {
+    return matrix_from(ctx, dev, height, width, hipMemcpyDeviceToDevice, out);
+}
+ts_status ts_matrix_dims(const ts_matrix* m, uint64_t* height, uint32_t* width) {
+    if (!m) return TS_ERR_INVALID;
+    if (height) *height = m->m.height;
+    if (width) *width = m->m.width;
+    return TS_OK;
+}
+ts_status ts_matrix_download(ts_ctx* ctx, const ts_matrix* m, uint32_t* host) {
+    if (!ctx || !m || !host) return TS_ERR_INVALID;
+    return guard(ctx, [&] {
+        TS_REQUIRE(m->m.buf.p, ts::TS_ERR_INVALID, "matrix was consumed");
+        const size_t words = (size_t)m->m.height * m->m.width;
+        if (m->m.layout == ts::DeviceMatrix::ROW_MAJOR) {
+            TS_HIP(hipMemcpyAsync(host, m->m.buf.p, words * 4, hipMemcpyDeviceToHost, ctx->ctx.stream));
+            ctx->ctx.sync();
+        } else {
+            // column-major with bit-reversed rows -> row-major natural
+            ts::DevBuf<uint32_t> rm(&ctx->ctx, words);
+            ts::launch_transpose_to_row_major(ctx->ctx, m->m.buf.p, m->m.height, rm.p, m->m.height,
+                                              m->m.width);
+            std::vector<uint32_t> tmp(words);
+            TS_HIP(hipMemcpyAsync(tmp.data(), rm.p, words * 4, hipMemcpyDeviceToHost, ctx->ctx.stream));
+            ctx->ctx.sync();
+            unsigned bits = 0;
+            while ((1ull << bits) < m->m.height) bits++;
+            for (uint64_t r = 0; r < m->m.height; r++) {
+                uint64_t nat = ts::bitrev32((uint32_t)r, bits);
+                memcpy(host + nat * m->m.width, tmp.data() + r * m->m.width, (size_t)m->m.width * 4);
+            }
+        }
+    });
+}
+void ts_matrix_free(ts_ctx* ctx, ts_matrix* m) {
+    (void)ctx;
+    delete m;
+}
+
+// ------------------------------------------------------------------ AIR
+ts_status ts_air_compile(ts_ctx* ctx, const uint32_t* tape, size_t n_words, ts_air** out) {
+    if (!ctx || !out) return TS_ERR_INVALID;
+    *out = nullptr;
+    return guard(ctx, [&] {
+        auto a = std::make_unique<ts_air>();
+        a->prog = ts::compile_air(tape, n_words);
+        a->code = ts::DevBuf<uint32_t>(&ctx->ctx, std::max<size_t>(a->prog.code.size(), 4));
+        if (!a->prog.code.empty())
+            TS_HIP(hipMemcpyAsync(a->code.p, a->prog.code.data(), a->prog.code.size() * 4,
+                                  hipMemcpyHostToDevice, ctx->ctx.stream));
+        ctx->ctx.sync();
+        a->prog.d_code = a->code.p;
+        *out = a.release();
+    });
+}
+ts_status ts_air_info(const ts_air* air, uint32_t* width, uint32_t* n_public,
+                      uint32_t* max_constraint_degree, uint32_t* log_quotient_degree) {
+    if (!air) return TS_ERR_INVALID;
+    if (width) *width = air->prog.width;
+    if (n_public) *n_public = air->prog.n_public;
+    if (max_constraint_degree) *max_constraint_degree = air->prog.max_degree;
+    if (log_quotient_degree) *log_quotient_degree = air->prog.log_quotient_degree;
+    return TS_OK;
+}
+void ts_air_free(ts_ctx* ctx, ts_air* air) {
+    (void)ctx;
+    delete air;
+}
+
+// ------------------------------------------------------------------ PCS
+ts_status ts_pcs_commit(ts_ctx* ctx, const ts_fri_config* cfg, uint32_t n_mats, ts_matrix* const* evals,
+                        const uint32_t* domain_shifts, uint32_t root_out[8], ts_pcs_data** out) {
+    if (!ctx || !out || !evals || !domain_shifts) return TS_ERR_INVALID;
+    *out = nullptr;
+    return guard(ctx, [&] {
+        ts::TwoAdicFriPcs pcs(ctx->ctx, load_cfg(cfg));
+        TS_REQUIRE(n_mats >= 1 && n_mats <= (uint32_t)ts::MAX_BATCH_MATS, ts::TS_ERR_INVALID,
+                   "commit: between 1 and 16 matrices");
+        std::vector<ts::DeviceMatrix> ms;
+        for (uint32_t i = 0; i < n_mats; i++) {
+            TS_REQUIRE(evals[i] && evals[i]->m.buf.p, ts::TS_ERR_INVALID, "commit: null or consumed matrix");
+            ms.push_back(std::move(evals[i]->m));
+        }
+        std::vector<uint32_t> shifts(domain_shifts, domain_shifts + n_mats);
+        auto d = std::make_unique<ts_pcs_data>();
+        d->d = pcs.commit(ms, shifts);
+        if (root_out) memcpy(root_out, d->d->root, 32);
+        *out = d.release();
+    });
+}
+ts_status ts_pcs_data_info(const ts_pcs_data* d, uint32_t* n_mats, uint32_t* log_height) {
+    if (!d || !d->d) return TS_ERR_INVALID;
+    if (n_mats) *n_mats = (uint32_t)d->d->ldes.size();
+    if (log_height) *log_height = d->d->log_height;
+    return TS_OK;
+}
+ts_status ts_pcs_data_lde(ts_ctx* ctx, const ts_pcs_data* d, uint32_t idx, uint32_t* host) {
+    if (!ctx || !d || !d->d || !host) return TS_ERR_INVALID;
+    return guard(ctx, [&] {
+        TS_REQUIRE(idx < d->d->ldes.size(), ts::TS_ERR_INVALID, "lde index out of range");
+        const ts::ColMat& cm = d->d->ldes[idx];
+        const size_t words = (size_t)cm.height * cm.width;
+        ts::DevBuf<uint32_t> rm(&ctx->ctx, words);
+        ts::launch_transpose_to_row_major(ctx->ctx, cm.d, cm.col_stride, rm.p, cm.height, cm.width);
+        TS_HIP(hipMemcpyAsync(host, rm.p, words * 4, hipMemcpyDeviceToHost, ctx->ctx.stream));
+        ctx->ctx.sync();
+    });
+}
+ts_status ts_pcs_data_digests(ts_ctx* ctx, const ts_pcs_data* d, uint32_t level, uint32_t* host) {
+    if (!ctx || !d || !d->d || !host) return TS_ERR_INVALID;
+    return guard(ctx, [&] {
+        TS_REQUIRE(level <= d->d->log_height, ts::TS_ERR_INVALID, "digest level out of range");
+        const uint64_t off = ts::merkle_level_offset(d->d->log_height, level);
+        const uint64_t cnt = 1ull << (d->d->log_height - level);
+        TS_HIP(hipMemcpyAsync(host, d->d->tree.p + 8 * off, cnt * 32, hipMemcpyDeviceToHost, ctx->ctx.stream));
+        ctx->ctx.sync();
+    });
+}
+ts_status ts_pcs_open_batch(ts_ctx* ctx, const ts_pcs_data* d, uint64_t index, uint32_t* rows_out,
+                            uint32_t* path_out) {
+    if (!ctx || !d || !d->d || !rows_out || !path_out) return TS_ERR_INVALID;
+    return guard(ctx, [&] {
+        ts::TwoAdicFriPcs pcs(ctx->ctx, ts::FriConfig{});
+        std::vector<uint32_t> rows, path;
+        pcs.open_batch(*d->d, index, rows, path);
+        memcpy(rows_out, rows.data(), rows.size() * 4);
+        memcpy(path_out, path.data(), path.size() * 4);
+    });
+}
+void ts_pcs_data_free(ts_ctx* ctx, ts_pcs_data* d) {
+    (void)ctx;
+    delete d;
+}
+
+ts_status ts_quotient_chunks(ts_ctx* ctx, const ts_pcs_data* trace_data, uint32_t log_blowup,
+                             const ts_air* air, const uint32_t* public_values, uint32_t n_public,
+                             const uint32_t alpha[4], ts_matrix** chunks_out) {
+    if (!ctx || !trace_data || !trace_data->d || !air || !alpha || !chunks_out) return TS_ERR_INVALID;
+    return guard(ctx, [&] {
+        ts::FriConfig f;
+        f.log_blowup = log_blowup;
+        ts::TwoAdicFriPcs pcs(ctx->ctx, f);
+        std::vector<uint32_t> pis;
+        if (n_public) {
+            TS_REQUIRE(public_values, ts::TS_ERR_INVALID, "null public values");
+            pis.assign(public_values, public_values + n_public);
+        }
+        auto chunks = pcs.quotient_chunks(*trace_data->d, air->prog, pis, load_ef(alpha));
+        for (size_t c = 0; c < chunks.size(); c++) {
+            auto m = std::make_unique<ts_matrix>();
+            m->m = std::move(chunks[c]);
+            chunks_out[c] = m.release();
+        }
+    });
+}
+
+ts_status ts_pcs_open_reduce(ts_ctx* ctx, const ts_fri_config* cfg, const ts_pcs_data* trace_data,
+                             const ts_pcs_data* quotient_data, const uint32_t zeta[4],
+                             const uint32_t batch_alpha[4], uint32_t* opened_out, uint32_t* reduced_out) {
+    if (!ctx || !trace_data || !trace_data->d || !quotient_data || !quotient_data->d || !zeta ||
+        !batch_alpha || !opened_out)
+        return TS_ERR_INVALID;
+    return guard(ctx, [&] {
+        ts::TwoAdicFriPcs pcs(ctx->ctx, load_cfg(cfg));
+        std::vector<ts::Ef> opened;
+        ts::DevBuf<ts::Ef> ro =
+            pcs.open_reduce(*trace_data->d, *quotient_data->d, load_ef(zeta), load_ef(batch_alpha), opened);
+        memcpy(opened_out, opened.data(), opened.size() * sizeof(ts::Ef));
+        if (reduced_out) {
+            TS_HIP(hipMemcpyAsync(reduced_out, ro.p, ro.n * sizeof(ts::Ef), hipMemcpyDeviceToHost,
+                                  ctx->ctx.stream));
+            ctx->ctx.sync();
+        }
+    });
+}
+
+ts_status ts_fri_fold(ts_ctx* ctx, const uint32_t* in, uint64_t h, const uint32_t beta[4], uint32_t* out) {
+    if (!ctx || !in || !beta || !out || h == 0) return TS_ERR_INVALID;
+    return guard(ctx, [&] {
+        ts::DevBuf<ts::Ef> d_in(&ctx->ctx, 2 * h), d_out(&ctx->ctx, h);
+        TS_HIP(hipMemcpyAsync(d_in.p, in, 2 * h * 16, hipMemcpyHostToDevice, ctx->ctx.stream));
+        ts::launch_fri_fold(ctx->ctx, d_in.p, h, load_ef(beta), d_out.p, nullptr);
+        TS_HIP(hipMemcpyAsync(out, d_out.p, h * 16, hipMemcpyDeviceToHost, ctx->ctx.stream));
+        ctx->ctx.sync();
+    });
+}
+
+// ------------------------------------------------------------------ challenger
+ts_status ts_chal_new(int permutation, int sample_ext, ts_challenger** out) {
+    if (!out || (permutation != 0 && permutation != 1)) return TS_ERR_INVALID;
+    *out = new (std::nothrow) ts_challenger(permutation, sample_ext != 0);
+    return *out ? TS_OK : TS_ERR_OOM;
+}
+ts_status ts_chal_clone(const ts_challenger* c, ts_challenger** out) {
+    if (!c || !out) return TS_ERR_INVALID;
+    *out = new (std::nothrow) ts_challenger(*c);
+    return *out ? TS_OK : TS_ERR_OOM;
+}
+void ts_chal_free(ts_challenger* c) { delete c; }
+void ts_chal_observe(ts_challenger* c, uint32_t word) { c->c.observe(word); }
+void ts_chal_observe_commitment(ts_challenger* c, const uint32_t d[8]) { c->c.observe_commitment(d); }
+void ts_chal_sample(ts_challenger* c, uint32_t out[4]) {
+    ts::Ef e = c->c.sample();
+    memcpy(out, e.c, 16);
+}
+uint64_t ts_chal_sample_bits(ts_challenger* c, uint32_t bits) { return c->c.sample_bits(bits); }
+int ts_chal_check_witness(ts_challenger* c, uint32_t bits, uint32_t witness) {
+    return c->c.check_witness(bits, witness) ? 1 : 0;
+}
+ts_status ts_chal_grind(ts_challenger* c, uint32_t bits, uint32_t* witness) {
+    if (!c || !witness) return TS_ERR_INVALID;
+    try {
+        *witness = c->c.grind(bits);
+        return TS_OK;
+    } catch (const ts::Error& e) {
+        return e.code;
+    }
+}
+void ts_chal_state(const ts_challenger* c, uint32_t out[34]) { c->c.export_state(out); }
+
+// ------------------------------------------------------------------ prove
+ts_status ts_prove(ts_ctx* ctx, const ts_fri_config* cfg, const ts_air* air, ts_challenger* chal,
+                   ts_matrix* trace, const uint32_t* public_values, uint32_t n_public,
+                   uint32_t* proof_out, size_t cap_words, size_t* n_words_out) {
+    if (!ctx || !air || !chal || !trace || !proof_out || !n_words_out) return TS_ERR_INVALID;
+    *n_words_out = 0;
+    return guard(ctx, [&] {
+        ts::TwoAdicFriPcs pcs(ctx->ctx, load_cfg(cfg));
+        TS_REQUIRE(trace->m.buf.p, ts::TS_ERR_INVALID, "prove: trace matrix was already consumed");
+        std::vector<uint32_t> pis;
+        if (n_public) {
+            TS_REQUIRE(public_values, ts::TS_ERR_INVALID, "null public values");
+            pis.assign(public_values, public_values + n_public);
+        }
+        ts::StageTimer t(&ctx->ctx, "prove");
+        std::vector<uint32_t> proof = ts::prove(pcs, air->prog, chal->c, std::move(trace->m), pis);
+        *n_words_out = proof.size();
+        TS_REQUIRE(proof.size() <= cap_words, ts::TS_ERR_BUFFER, "proof buffer too small");
+        memcpy(proof_out, proof.data(), proof.size() * 4);
+    });
+}
+
+}  // extern "C"

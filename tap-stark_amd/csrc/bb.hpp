@@ -1,0 +1,192 @@
+// BabyBear / EF4 arithmetic shared by host code and HIP kernels.
+//
+// Field constants follow reference basic/src/field/mod.rs:45 (MOD = 0x78000001) and SURVEY.md
+// App. A.1/A.2 (generator 31, two-adic generator 0x1a427a41, EF4 = F[x]/(x^4 - 11)).
+//
+// Representation policy (DESIGN.md "Data layout"): everything that lives in HBM or crosses the
+// C ABI is CANONICAL u32 (reference as_u32_vec, basic/src/field/mod.rs:48-63).  Montgomery form
+// (R = 2^32) is used only for constants (twiddles, challenge powers) and inside kernels:
+// mont_mul(canonical, montgomery) == canonical product, so streaming data never needs converting.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define TS_HD __host__ __device__ __forceinline__
+#else
+#define TS_HD inline
+#endif
+
+namespace ts {
+
+constexpr uint32_t P = 0x78000001u;
+constexpr uint32_t P_INV = 0x88000001u;      // p^-1 mod 2^32
+constexpr uint32_t R_MOD_P = 0x0ffffffeu;    // 2^32 mod p  (Montgomery form of 1)
+constexpr uint32_t R2_MOD_P = 0x45dddde3u;   // 2^64 mod p  (checked by tests/test_host_field)
+constexpr uint32_t GENERATOR = 31u;
+constexpr uint32_t TWO_ADIC_GEN_27 = 0x1a427a41u;
+constexpr uint32_t EF_W = 11u;
+
+TS_HD uint32_t add(uint32_t a, uint32_t b) {
+    uint32_t s = a + b;
+    uint32_t t = s - P;
+    return s >= P ? t : s;
+}
+TS_HD uint32_t sub(uint32_t a, uint32_t b) {
+    uint32_t d = a - b;
+    return a >= b ? d : d + P;
+}
+TS_HD uint32_t neg(uint32_t a) { return a ? P - a : 0u; }
+
+TS_HD uint32_t mulhi32(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umulhi(a, b);
+#else
+    return (uint32_t)(((uint64_t)a * b) >> 32);
+#endif
+}
+
+// Montgomery reduction of t < p * 2^32: returns t * 2^-32 mod p in [0, p)
+TS_HD uint32_t mont_reduce(uint64_t t) {
+    uint32_t m = (uint32_t)t * P_INV;
+    uint32_t u = mulhi32(m, P);
+    uint32_t hi = (uint32_t)(t >> 32);
+    uint32_t r = hi - u;
+    return hi < u ? r + P : r;
+}
+// a * b * 2^-32 mod p.  Needs a*b < p*2^32 (true if either operand is < p).
+TS_HD uint32_t mont_mul(uint32_t a, uint32_t b) { return mont_reduce((uint64_t)a * b); }
+TS_HD uint32_t to_mont(uint32_t a) { return mont_mul(a, R2_MOD_P); }
+TS_HD uint32_t from_mont(uint32_t a) { return mont_reduce((uint64_t)a); }
+
+// plain (canonical x canonical -> canonical) product; host-side convenience, slow path on device
+TS_HD uint32_t mul(uint32_t a, uint32_t b) { return mont_mul(to_mont(a), b); }
+
+TS_HD uint32_t pow_canon(uint32_t a, uint64_t e) {
+    uint32_t r = R_MOD_P, am = to_mont(a);
+    while (e) {
+        if (e & 1) r = mont_mul(r, am);
+        am = mont_mul(am, am);
+        e >>= 1;
+    }
+    return from_mont(r);
+}
+// Montgomery-domain exponentiation / inverse (input and output in Montgomery form)
+TS_HD uint32_t mont_pow(uint32_t am, uint64_t e) {
+    uint32_t r = R_MOD_P;
+    while (e) {
+        if (e & 1) r = mont_mul(r, am);
+        am = mont_mul(am, am);
+        e >>= 1;
+    }
+    return r;
+}
+// a^(p-2), p-2 = 0x77ffffff: 4-bit windows 7,7,f,f,f,f,f,f  (31 squarings + 10 products)
+TS_HD uint32_t mont_inv(uint32_t a) {
+    uint32_t a2 = mont_mul(a, a), a3 = mont_mul(a2, a), a6 = mont_mul(a3, a3);
+    uint32_t a7 = mont_mul(a6, a), a14 = mont_mul(a7, a7), a15 = mont_mul(a14, a);
+    uint32_t r = a7;
+    for (int k = 0; k < 4; k++) r = mont_mul(r, r);
+    r = mont_mul(r, a7);
+    for (int w = 0; w < 6; w++) {
+        for (int k = 0; k < 4; k++) r = mont_mul(r, r);
+        r = mont_mul(r, a15);
+    }
+    return r;
+}
+TS_HD uint32_t inv_canon(uint32_t a) { return pow_canon(a, P - 2); }
+TS_HD uint32_t two_adic_generator(unsigned bits) {
+    return pow_canon(TWO_ADIC_GEN_27, 1ull << (27 - bits));
+}
+
+// ---------------------------------------------------------------------------------- EF4
+// Coefficient order [c0,c1,c2,c3] (reference basic/src/field/mod.rs:58-63).  The struct does not
+// record whether the coefficients are canonical or Montgomery: each call site says which.
+struct alignas(16) Ef {
+    uint32_t c[4];
+};
+
+TS_HD Ef ef_zero() { return Ef{{0, 0, 0, 0}}; }
+TS_HD Ef ef_add(Ef a, Ef b) {
+    return Ef{{add(a.c[0], b.c[0]), add(a.c[1], b.c[1]), add(a.c[2], b.c[2]), add(a.c[3], b.c[3])}};
+}
+TS_HD Ef ef_sub(Ef a, Ef b) {
+    return Ef{{sub(a.c[0], b.c[0]), sub(a.c[1], b.c[1]), sub(a.c[2], b.c[2]), sub(a.c[3], b.c[3])}};
+}
+TS_HD Ef ef_neg(Ef a) { return Ef{{neg(a.c[0]), neg(a.c[1]), neg(a.c[2]), neg(a.c[3])}}; }
+TS_HD bool ef_eq(Ef a, Ef b) {
+    return a.c[0] == b.c[0] && a.c[1] == b.c[1] && a.c[2] == b.c[2] && a.c[3] == b.c[3];
+}
+// (a in form X) * (b Montgomery base) -> form X
+TS_HD Ef ef_mul_base(Ef a, uint32_t bm) {
+    return Ef{{mont_mul(a.c[0], bm), mont_mul(a.c[1], bm), mont_mul(a.c[2], bm), mont_mul(a.c[3], bm)}};
+}
+// Montgomery product of two EF4 elements: if both are Montgomery the result is Montgomery; if one
+// is canonical and the other Montgomery the result is canonical.
+// Sums of two 64-bit products stay below p*2^32, so each output coefficient needs few reductions.
+TS_HD Ef ef_mul(Ef a, Ef b) {
+    constexpr uint32_t W_M = (uint32_t)(((uint64_t)EF_W << 32) % P);  // 11 in Montgomery form
+    uint64_t a0 = a.c[0], a1 = a.c[1], a2 = a.c[2], a3 = a.c[3];
+    // high part t4..t6 (needs the x^4 = 11 fold)
+    uint32_t t4 = add(mont_reduce(a1 * b.c[3] + a2 * b.c[2]), mont_reduce(a3 * b.c[1]));
+    uint32_t t5 = mont_reduce(a2 * b.c[3] + a3 * b.c[2]);
+    uint32_t t6 = mont_reduce(a3 * b.c[3]);
+    uint32_t r0 = add(mont_reduce(a0 * b.c[0]), mont_mul(t4, W_M));
+    uint32_t r1 = add(mont_reduce(a0 * b.c[1] + a1 * b.c[0]), mont_mul(t5, W_M));
+    uint32_t r2 = add(add(mont_reduce(a0 * b.c[2] + a1 * b.c[1]), mont_reduce(a2 * b.c[0])),
+                      mont_mul(t6, W_M));
+    uint32_t r3 = add(mont_reduce(a0 * b.c[3] + a1 * b.c[2]), mont_reduce(a2 * b.c[1] + a3 * b.c[0]));
+    return Ef{{r0, r1, r2, r3}};
+}
+TS_HD Ef ef_to_mont(Ef a) { return Ef{{to_mont(a.c[0]), to_mont(a.c[1]), to_mont(a.c[2]), to_mont(a.c[3])}}; }
+TS_HD Ef ef_from_mont(Ef a) {
+    return Ef{{from_mont(a.c[0]), from_mont(a.c[1]), from_mont(a.c[2]), from_mont(a.c[3])}};
+}
+TS_HD Ef ef_one_mont() { return Ef{{R_MOD_P, 0, 0, 0}}; }
+TS_HD Ef ef_from_base(uint32_t a) { return Ef{{a, 0, 0, 0}}; }
+
+// Inverse split in two halves so that callers can batch the base-field inversion:
+//   a^-1 = num * nrm^-1,   nrm in F (Montgomery in -> Montgomery out)
+// Tower F < F[y]/(y^2-11) < F[x]/(x^2-y): a = A + xB;  a(A - xB) = A^2 - yB^2 = c0 + c1 y;
+// (c0 + c1 y)(c0 - c1 y) = c0^2 - 11 c1^2.
+TS_HD void ef_inv_parts(Ef a, Ef& num, uint32_t& nrm) {
+    constexpr uint32_t W_M = (uint32_t)(((uint64_t)EF_W << 32) % P);
+    uint32_t a0 = a.c[0], a1 = a.c[1], a2 = a.c[2], a3 = a.c[3];
+    uint32_t A2_0 = add(mont_mul(a0, a0), mont_mul(W_M, mont_mul(a2, a2)));
+    uint32_t A2_1 = mont_mul(add(a0, a0), a2);
+    uint32_t B2_0 = add(mont_mul(a1, a1), mont_mul(W_M, mont_mul(a3, a3)));
+    uint32_t B2_1 = mont_mul(add(a1, a1), a3);
+    uint32_t c0 = sub(A2_0, mont_mul(W_M, B2_1));
+    uint32_t c1 = sub(A2_1, B2_0);
+    nrm = sub(mont_mul(c0, c0), mont_mul(W_M, mont_mul(c1, c1)));
+    Ef conj = Ef{{a0, neg(a1), a2, neg(a3)}};
+    Ef cc = Ef{{c0, 0, neg(c1), 0}};
+    num = ef_mul(conj, cc);
+}
+TS_HD Ef ef_inv(Ef a) {  // Montgomery in, Montgomery out
+    Ef num;
+    uint32_t nrm;
+    ef_inv_parts(a, num, nrm);
+    return ef_mul_base(num, mont_inv(nrm));
+}
+TS_HD Ef ef_pow(Ef am, uint64_t e) {  // Montgomery
+    Ef r = ef_one_mont();
+    while (e) {
+        if (e & 1) r = ef_mul(r, am);
+        am = ef_mul(am, am);
+        e >>= 1;
+    }
+    return r;
+}
+
+TS_HD uint32_t bitrev32(uint32_t x, unsigned bits) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return bits ? (__brev(x) >> (32 - bits)) : 0u;
+#else
+    uint32_t r = 0;
+    for (unsigned i = 0; i < bits; i++) r |= ((x >> i) & 1u) << (bits - 1 - i);
+    return r;
+#endif
+}
+
+}  // namespace ts

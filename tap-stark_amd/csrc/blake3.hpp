@@ -1,0 +1,93 @@
+// BLAKE3 compression for host code and HIP kernels (written from the published BLAKE3 spec).
+//
+// Uses: (1) the Fiat-Shamir permutation, reference basic/src/challenger/mod.rs:34-48
+//           (one 64-byte block, CHUNK_START|CHUNK_END|ROOT);
+//       (2) the build-defined Merkle MMCS: leaf = Blake3(row bytes),
+//           node = Blake3(left || right).
+// Inputs up to one chunk (1024 bytes = 256 field elements per row) are supported on the device;
+// wider rows are refused by the host before any launch.
+#pragma once
+#include <stdint.h>
+#include "bb.hpp"
+
+namespace ts {
+namespace b3 {
+
+constexpr uint32_t CHUNK_START = 1, CHUNK_END = 2, PARENT = 4, ROOT = 8;
+
+#define TS_B3_IV0 0x6A09E667u
+#define TS_B3_IV1 0xBB67AE85u
+#define TS_B3_IV2 0x3C6EF372u
+#define TS_B3_IV3 0xA54FF53Au
+#define TS_B3_IV4 0x510E527Fu
+#define TS_B3_IV5 0x9B05688Cu
+#define TS_B3_IV6 0x1F83D9ABu
+#define TS_B3_IV7 0x5BE0CD19u
+
+TS_HD uint32_t rotr(uint32_t x, int n) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(x, x, n);
+#else
+    return (x >> n) | (x << (32 - n));
+#endif
+}
+
+#define TS_B3_G(a, b, c, d, mx, my) \
+    a = a + b + (mx);               \
+    d = rotr(d ^ a, 16);            \
+    c = c + d;                      \
+    b = rotr(b ^ c, 12);            \
+    a = a + b + (my);               \
+    d = rotr(d ^ a, 8);             \
+    c = c + d;                      \
+    b = rotr(b ^ c, 7);
+
+// One round with the message words addressed through a compile-time schedule.
+#define TS_B3_ROUND(m0, m1, m2, m3, m4, m5, m6, m7, m8, m9, m10, m11, m12, m13, m14, m15) \
+    TS_B3_G(s0, s4, s8, s12, m0, m1)                                                      \
+    TS_B3_G(s1, s5, s9, s13, m2, m3)                                                      \
+    TS_B3_G(s2, s6, s10, s14, m4, m5)                                                     \
+    TS_B3_G(s3, s7, s11, s15, m6, m7)                                                     \
+    TS_B3_G(s0, s5, s10, s15, m8, m9)                                                     \
+    TS_B3_G(s1, s6, s11, s12, m10, m11)                                                   \
+    TS_B3_G(s2, s7, s8, s13, m12, m13)                                                    \
+    TS_B3_G(s3, s4, s9, s14, m14, m15)
+
+// cv (8 words, updated in place) <- compress(cv, m[16], counter = 0, block_len, flags).
+// The 7 rounds use the spec's message permutation unrolled into fixed schedules, so `m` stays in
+// registers and is never moved.
+TS_HD void compress(uint32_t cv[8], const uint32_t m[16], uint32_t block_len, uint32_t flags) {
+    uint32_t s0 = cv[0], s1 = cv[1], s2 = cv[2], s3 = cv[3], s4 = cv[4], s5 = cv[5], s6 = cv[6],
+             s7 = cv[7];
+    uint32_t s8 = TS_B3_IV0, s9 = TS_B3_IV1, s10 = TS_B3_IV2, s11 = TS_B3_IV3;
+    uint32_t s12 = 0, s13 = 0, s14 = block_len, s15 = flags;
+    TS_B3_ROUND(m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7], m[8], m[9], m[10], m[11], m[12], m[13], m[14], m[15])
+    TS_B3_ROUND(m[2], m[6], m[3], m[10], m[7], m[0], m[4], m[13], m[1], m[11], m[12], m[5], m[9], m[14], m[15], m[8])
+    TS_B3_ROUND(m[3], m[4], m[10], m[12], m[13], m[2], m[7], m[14], m[6], m[5], m[9], m[0], m[11], m[15], m[8], m[1])
+    TS_B3_ROUND(m[10], m[7], m[12], m[9], m[14], m[3], m[13], m[15], m[4], m[0], m[11], m[2], m[5], m[8], m[1], m[6])
+    TS_B3_ROUND(m[12], m[13], m[9], m[11], m[15], m[10], m[14], m[8], m[7], m[2], m[5], m[3], m[0], m[1], m[6], m[4])
+    TS_B3_ROUND(m[9], m[14], m[11], m[5], m[8], m[12], m[15], m[1], m[13], m[3], m[0], m[10], m[2], m[6], m[4], m[7])
+    TS_B3_ROUND(m[11], m[15], m[5], m[0], m[1], m[9], m[8], m[6], m[14], m[10], m[2], m[12], m[3], m[4], m[7], m[13])
+    cv[0] = s0 ^ s8;
+    cv[1] = s1 ^ s9;
+    cv[2] = s2 ^ s10;
+    cv[3] = s3 ^ s11;
+    cv[4] = s4 ^ s12;
+    cv[5] = s5 ^ s13;
+    cv[6] = s6 ^ s14;
+    cv[7] = s7 ^ s15;
+}
+
+TS_HD void iv(uint32_t cv[8]) {
+    cv[0] = TS_B3_IV0; cv[1] = TS_B3_IV1; cv[2] = TS_B3_IV2; cv[3] = TS_B3_IV3;
+    cv[4] = TS_B3_IV4; cv[5] = TS_B3_IV5; cv[6] = TS_B3_IV6; cv[7] = TS_B3_IV7;
+}
+
+// Blake3 of exactly 64 bytes (16 words): Merkle node = hash(left || right); sponge permutation.
+TS_HD void hash64(const uint32_t m[16], uint32_t out[8]) {
+    iv(out);
+    compress(out, m, 64, CHUNK_START | CHUNK_END | ROOT);
+}
+
+}  // namespace b3
+}  // namespace ts

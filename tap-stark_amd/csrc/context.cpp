@@ -1,0 +1,127 @@
+#include "context.hpp"
+
+#include "kernels.hpp"
+
+namespace ts {
+
+Context::Context(int dev) : device(dev) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0)
+        throw Error(TS_ERR_HIP, "no HIP device available: the tap-stark HIP path has no CPU fallback");
+    TS_REQUIRE(dev >= 0 && dev < count, TS_ERR_INVALID, "device index out of range");
+    TS_HIP(hipSetDevice(dev));
+    hipDeviceProp_t prop;
+    TS_HIP(hipGetDeviceProperties(&prop, dev));
+    num_cus = prop.multiProcessorCount;
+    TS_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+}
+
+Context::~Context() {
+    hipSetDevice(device);
+    if (stream) hipStreamSynchronize(stream);
+    if (d_twiddle_fwd) hipFree(d_twiddle_fwd);
+    if (d_twiddle_inv) hipFree(d_twiddle_inv);
+    for (auto& kv : free_blocks) hipFree(kv.second);
+    for (auto& kv : live_blocks) hipFree(kv.first);
+    if (h_pinned) hipHostFree(h_pinned);
+    if (stream) hipStreamDestroy(stream);
+}
+
+static size_t round_block(size_t bytes) {
+    if (bytes < 512) return 512;
+    if (bytes < (1u << 20)) {  // next power of two
+        size_t r = 512;
+        while (r < bytes) r <<= 1;
+        return r;
+    }
+    const size_t g = 1u << 20;  // 1 MiB granules
+    return (bytes + g - 1) / g * g;
+}
+
+void* Context::alloc(size_t bytes) {
+    const size_t sz = round_block(bytes);
+    auto it = free_blocks.find(sz);
+    void* p = nullptr;
+    if (it != free_blocks.end()) {
+        p = it->second;
+        free_blocks.erase(it);
+    } else {
+        TS_HIP(hipSetDevice(device));
+        hipError_t e = hipMalloc(&p, sz);
+        if (e != hipSuccess) {
+            // drop the cache and retry once
+            release_cache();
+            e = hipMalloc(&p, sz);
+        }
+        if (e != hipSuccess) throw Error(TS_ERR_OOM, "device allocation failed");
+        bytes_reserved += sz;
+    }
+    live_blocks[p] = sz;
+    return p;
+}
+
+void Context::free(void* p) {
+    if (!p) return;
+    auto it = live_blocks.find(p);
+    if (it == live_blocks.end()) return;
+    // All work is enqueued on the single stream, so a recycled block is only touched by kernels
+    // that run after every earlier user of it.
+    free_blocks.emplace(it->second, p);
+    live_blocks.erase(it);
+}
+
+void Context::release_cache() {
+    if (stream) hipStreamSynchronize(stream);
+    for (auto& kv : free_blocks) {
+        hipFree(kv.second);
+        bytes_reserved -= kv.first;
+    }
+    free_blocks.clear();
+}
+
+void* Context::pinned(size_t bytes) {
+    if (bytes > h_pinned_bytes) {
+        if (h_pinned) {
+            sync();
+            hipHostFree(h_pinned);
+        }
+        size_t sz = 1 << 16;
+        while (sz < bytes) sz <<= 1;
+        TS_HIP(hipHostMalloc(&h_pinned, sz, hipHostMallocDefault));
+        h_pinned_bytes = sz;
+    }
+    return h_pinned;
+}
+
+std::map<std::string, std::pair<uint64_t, double>> Context::take_kernel_timings() {
+    std::map<std::string, std::pair<uint64_t, double>> out;
+    sync();
+    for (auto& ev : kernel_events) {
+        float ms = 0;
+        hipEventElapsedTime(&ms, ev.e0, ev.e1);
+        auto& slot = out[ev.name];
+        slot.first += 1;
+        slot.second += ms;
+        hipEventDestroy(ev.e0);
+        hipEventDestroy(ev.e1);
+    }
+    kernel_events.clear();
+    return out;
+}
+
+void Context::ensure_twiddles(unsigned log_size) {
+    if (log_size <= twiddle_log && d_twiddle_fwd) return;
+    TS_REQUIRE(log_size <= 27, TS_ERR_INVALID, "two-adicity of BabyBear is 27");
+    sync();
+    if (d_twiddle_fwd) hipFree(d_twiddle_fwd);
+    if (d_twiddle_inv) hipFree(d_twiddle_inv);
+    d_twiddle_fwd = d_twiddle_inv = nullptr;
+    const size_t n = (size_t)1 << log_size;
+    TS_HIP(hipMalloc((void**)&d_twiddle_fwd, n * 4));
+    TS_HIP(hipMalloc((void**)&d_twiddle_inv, n * 4));
+    twiddle_log = log_size;
+    launch_build_twiddles(*this, d_twiddle_fwd, d_twiddle_inv, log_size);
+}
+
+}  // namespace ts

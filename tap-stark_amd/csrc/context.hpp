@@ -1,0 +1,172 @@
+// Per-GPU context of the tap-stark HIP library: stream, caching device allocator, twiddle tables,
+// error reporting.  One context is driven by one host thread (SURVEY.md section 8(b) Threading).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "bb.hpp"
+
+namespace ts {
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+// status codes of the C ABI (include/tapstark.h)
+enum : int {
+    TS_OK = 0,
+    TS_ERR_INVALID = 1,    // bad argument / shape
+    TS_ERR_HIP = 2,        // HIP runtime failure
+    TS_ERR_OOM = 3,        // device allocation failed
+    TS_ERR_UNSUPPORTED = 4,
+    TS_ERR_INVARIANT = 5,  // the reference would have panicked (assert/expect)
+    TS_ERR_BUFFER = 6,     // output buffer too small
+};
+
+#define TS_HIP(expr)                                                                        \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess)                                                               \
+            throw ts::Error(ts::TS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+#define TS_REQUIRE(cond, code, msg)                   \
+    do {                                              \
+        if (!(cond)) throw ts::Error((code), (msg));  \
+    } while (0)
+
+struct Context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string last_error;
+    int num_cus = 256;
+
+    // caching allocator: blocks are rounded up and recycled by exact rounded size
+    std::multimap<size_t, void*> free_blocks;
+    std::map<void*, size_t> live_blocks;
+    size_t bytes_reserved = 0;
+
+    // twiddle tables in bit-reversed block order (kernels_ntt.hip): W[m + i] = w_{2m}^bitrev(i),
+    // Montgomery form; index 0 unused.  Grown on demand, never shrunk.
+    uint32_t* d_twiddle_fwd = nullptr;
+    uint32_t* d_twiddle_inv = nullptr;
+    unsigned twiddle_log = 0;
+
+    // pinned host staging
+    void* h_pinned = nullptr;
+    size_t h_pinned_bytes = 0;
+
+    // optional per-stage timing (bench.py): name -> accumulated ms, measured with HIP events on
+    // `stream`
+    bool timing = false;
+    std::vector<std::pair<std::string, float>> stage_ms;
+
+    // optional per-kernel timing: HIP events recorded on `stream` around every launch, resolved
+    // lazily (no sync per kernel) by take_kernel_timings()
+    struct KernelEvent {
+        const char* name;
+        hipEvent_t e0, e1;
+    };
+    bool kernel_timing = false;
+    std::vector<KernelEvent> kernel_events;
+    // name -> (launch count, total ms)
+    std::map<std::string, std::pair<uint64_t, double>> take_kernel_timings();
+
+    explicit Context(int dev);
+    ~Context();
+    Context(const Context&) = delete;
+
+    void* alloc(size_t bytes);
+    void free(void* p);
+    template <class T>
+    T* alloc_n(size_t n) { return static_cast<T*>(alloc(n * sizeof(T))); }
+    void release_cache();
+
+    void* pinned(size_t bytes);
+    void ensure_twiddles(unsigned log_size);
+    void sync() { TS_HIP(hipStreamSynchronize(stream)); }
+};
+
+// RAII device buffer from the context's pool
+template <class T>
+struct DevBuf {
+    Context* ctx = nullptr;
+    T* p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    DevBuf(Context* c, size_t count) : ctx(c), p(c->alloc_n<T>(count)), n(count) {}
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : ctx(o.ctx), p(o.p), n(o.n) { o.p = nullptr; }
+    DevBuf& operator=(DevBuf&& o) noexcept {
+        if (this != &o) {
+            reset();
+            ctx = o.ctx; p = o.p; n = o.n; o.p = nullptr;
+        }
+        return *this;
+    }
+    ~DevBuf() { reset(); }
+    void reset() {
+        if (p) ctx->free(p);
+        p = nullptr;
+    }
+};
+
+// Brackets one kernel launch with events when per-kernel timing is on (bench.py's roofline leg).
+struct KernelTimer {
+    Context* ctx;
+    Context::KernelEvent ev;
+    bool on;
+    KernelTimer(Context* c, const char* name) : ctx(c), on(c->kernel_timing) {
+        if (on) {
+            ev.name = name;
+            hipEventCreate(&ev.e0);
+            hipEventCreate(&ev.e1);
+            hipEventRecord(ev.e0, ctx->stream);
+        }
+    }
+    ~KernelTimer() {
+        if (on) {
+            hipEventRecord(ev.e1, ctx->stream);
+            ctx->kernel_events.push_back(ev);
+        }
+    }
+};
+
+#define TS_LAUNCH(ctx, kernel, grid, block, lds, ...)                               \
+    do {                                                                            \
+        ts::KernelTimer _kt(&(ctx), #kernel);                                       \
+        hipLaunchKernelGGL(kernel, grid, block, lds, (ctx).stream, __VA_ARGS__);    \
+    } while (0)
+
+struct StageTimer {
+    Context* ctx;
+    const char* name;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    StageTimer(Context* c, const char* n) : ctx(c), name(n) {
+        if (ctx->timing) {
+            hipEventCreate(&e0);
+            hipEventCreate(&e1);
+            hipEventRecord(e0, ctx->stream);
+        }
+    }
+    ~StageTimer() {
+        if (ctx->timing && e0) {
+            hipEventRecord(e1, ctx->stream);
+            hipEventSynchronize(e1);
+            float ms = 0;
+            hipEventElapsedTime(&ms, e0, e1);
+            ctx->stage_ms.emplace_back(name, ms);
+            hipEventDestroy(e0);
+            hipEventDestroy(e1);
+        }
+    }
+};
+
+}  // namespace ts

@@ -1,0 +1,112 @@
+// Host-side C++ mirror of the reference interface for the prover hot path: StarkConfig /
+// TwoAdicFriPcs / FriConfig / BfChallenger / prove(), sitting on the HIP kernels.  The names and
+// argument meaning follow the reference (uni-stark/src/prover.rs, fri/src/two_adic_pcs.rs,
+// fri/src/prover.rs, basic/src/challenger/mod.rs); device objects replace host matrices.
+#pragma once
+#include <stdint.h>
+
+#include <memory>
+#include <vector>
+
+#include "air.hpp"
+#include "bb.hpp"
+#include "context.hpp"
+#include "kernels.hpp"
+
+namespace ts {
+
+// ------------------------------------------------------------------ challenger
+// reference basic/src/challenger/mod.rs:67-84 BfChallenger<F, U32, P, 16>
+class BfChallenger {
+public:
+    enum Permutation { Blake3Permutation = 0, TestReversePermutation = 1 };
+    BfChallenger(int permutation, bool sample_ext)
+        : permutation_(permutation), sample_ext_(sample_ext) {}
+
+    void observe(uint32_t word);                   // mod.rs:183-194
+    void observe_commitment(const uint32_t d[8]);  // mod.rs:197-223
+    uint32_t sample_base();                        // mod.rs:269-279
+    Ef sample_ext();                               // mod.rs:282-304 (canonical EF4)
+    Ef sample();                                   // F = EF4 or BabyBear (embedded)
+    uint64_t sample_bits(unsigned bits);           // mod.rs:341-348
+    bool check_witness(unsigned bits, uint32_t witness);  // mod.rs:108-114
+    uint32_t grind(unsigned bits);                 // mod.rs:95-105 (throws TS_ERR_INVARIANT)
+    void export_state(uint32_t out[34]) const;
+
+private:
+    void duplexing();  // mod.rs:151-174
+    uint32_t pop();
+    uint32_t state_[16] = {0};
+    uint32_t in_[8] = {0};
+    int n_in_ = 0;
+    uint32_t out_[8] = {0};
+    int n_out_ = 0;
+    int permutation_;
+    bool sample_ext_;
+};
+
+// ------------------------------------------------------------------ config
+// reference fri/src/config.rs:11-16
+struct FriConfig {
+    uint32_t log_blowup = 1;
+    uint32_t num_queries = 1;
+    uint32_t proof_of_work_bits = 0;
+    uint32_t blowup() const { return 1u << log_blowup; }
+};
+
+// ------------------------------------------------------------------ device matrices
+// RowMajorMatrix<Val> handed to the library.  ROW_MAJOR: natural rows, as uploaded.
+// COL_MAJOR_BITREV: produced on the device (quotient chunks), column-major, bit-reversed rows.
+struct DeviceMatrix {
+    enum Layout { ROW_MAJOR, COL_MAJOR_BITREV };
+    DevBuf<uint32_t> buf;
+    uint64_t height = 0;
+    uint32_t width = 0;
+    Layout layout = ROW_MAJOR;
+};
+
+// Pcs::ProverData / BFMmcs::ProverData: the committed LDEs (column-major, bit-reversed rows) and
+// the whole Merkle tree, all resident in HBM.
+struct PcsData {
+    std::vector<DevBuf<uint32_t>> lde_storage;
+    std::vector<ColMat> ldes;
+    unsigned log_height = 0;
+    DevBuf<uint32_t> tree;  // merkle_total_digests(log_height) x 8 words
+    uint32_t root[8] = {0};
+    LeafMats leaf_mats() const;
+};
+
+// ------------------------------------------------------------------ PCS (TwoAdicFriPcs)
+class TwoAdicFriPcs {
+public:
+    TwoAdicFriPcs(Context& ctx, FriConfig fri) : ctx_(ctx), fri_(fri) {}
+    const FriConfig& fri() const { return fri_; }
+    Context& ctx() const { return ctx_; }
+
+    // two_adic_pcs.rs:227-245.  Consumes the matrices.
+    std::unique_ptr<PcsData> commit(std::vector<DeviceMatrix>& evals,
+                                    const std::vector<uint32_t>& domain_shifts);
+
+    // two_adic_pcs.rs:247-258 + uni-stark prover.rs:122-194,78-80
+    std::vector<DeviceMatrix> quotient_chunks(const PcsData& trace_data, const AirProgram& air,
+                                              const std::vector<uint32_t>& public_values, Ef alpha);
+
+    // two_adic_pcs.rs:312-389 for the prove() shape; returns the FRI input (N EF4, device)
+    DevBuf<Ef> open_reduce(const PcsData& trace_data, const PcsData& quotient_data, Ef zeta,
+                           Ef batch_alpha, std::vector<Ef>& opened_values);
+
+    // BFMmcs::open_batch
+    void open_batch(const PcsData& d, uint64_t index, std::vector<uint32_t>& rows,
+                    std::vector<uint32_t>& path);
+
+private:
+    Context& ctx_;
+    FriConfig fri_;
+};
+
+// ------------------------------------------------------------------ prove
+// uni-stark/src/prover.rs:25-119.  Returns the proof in TSPF v1 words.
+std::vector<uint32_t> prove(TwoAdicFriPcs& pcs, const AirProgram& air, BfChallenger& challenger,
+                            DeviceMatrix trace, const std::vector<uint32_t>& public_values);
+
+}  // namespace ts

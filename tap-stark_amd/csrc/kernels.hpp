@@ -1,0 +1,103 @@
+// Host-callable launchers of the HIP kernels (one translation unit per kernel family).
+#pragma once
+#include <stdint.h>
+
+#include "bb.hpp"
+#include "context.hpp"
+
+namespace ts {
+
+// Column-major device matrix: element (row r, column c) at d[c * col_stride + r].
+struct ColMat {
+    uint32_t* d = nullptr;
+    uint64_t height = 0;
+    uint32_t width = 0;
+    uint64_t col_stride = 0;
+};
+
+// ---- ntt.hip ---------------------------------------------------------------------------------
+void launch_build_twiddles(Context& ctx, uint32_t* W, uint32_t* Winv, unsigned log_size);
+// src: row-major n x w (natural rows)  ->  dst: column-major, rows in bit-reversed order
+void launch_transpose_bitrev(Context& ctx, const uint32_t* src, uint32_t* dst, unsigned log_n,
+                             uint32_t w, uint64_t dst_col_stride);
+// dst row-major (h x w)  <-  src column-major; used by debug downloads and row gathers
+void launch_transpose_to_row_major(Context& ctx, const uint32_t* src, uint64_t col_stride,
+                                   uint32_t* dst, uint64_t h, uint32_t w);
+// Coset low-degree extension of `ncols` columns (reference fri/src/two_adic_pcs.rs:233-241):
+//   in : evals[c][p] = column value at subgroup index bitrev(p)   (n per column, DESTROYED)
+//   out: out[c][beta*n + t] = p_c(shift * w_N^bitrev(beta*n+t)),  N = n << log_blowup
+void coset_lde(Context& ctx, uint32_t* evals, uint64_t in_col_stride, uint32_t ncols, unsigned log_n,
+               unsigned log_blowup, uint32_t shift, uint32_t* out, uint64_t out_col_stride);
+
+// ---- merkle.hip ------------------------------------------------------------------------------
+constexpr int MAX_BATCH_MATS = 16;
+struct LeafMats {
+    const uint32_t* d[MAX_BATCH_MATS];
+    uint64_t col_stride[MAX_BATCH_MATS];
+    uint32_t width[MAX_BATCH_MATS];
+    uint32_t n_mats;
+    uint32_t total_width;
+};
+// leaf digests (8 words each) of `height` rows: Blake3(row of mat 0 || row of mat 1 || ...)
+void launch_leaf_hash(Context& ctx, const LeafMats& mats, uint64_t height, uint32_t* digests);
+// leaf digests of an array-of-EF4 vector taken as rows of two elements (FRI commit-phase matrix)
+void launch_leaf_hash_ef_pairs(Context& ctx, const uint32_t* vec, uint64_t n_rows, uint32_t* digests);
+// builds every upper level of the tree; `tree` holds level l at offset level_off(l) (in digests)
+void launch_merkle_levels(Context& ctx, uint32_t* tree, unsigned log_leaves);
+inline uint64_t merkle_level_offset(unsigned log_leaves, unsigned level) {
+    // levels are stored back to back: leaves first
+    uint64_t off = 0;
+    for (unsigned l = 0; l < level; l++) off += (uint64_t)1 << (log_leaves - l);
+    return off;
+}
+inline uint64_t merkle_total_digests(unsigned log_leaves) { return ((uint64_t)2 << log_leaves) - 1; }
+
+// ---- quotient.hip ----------------------------------------------------------------------------
+struct AirProgram;  // air.hpp
+void launch_selectors(Context& ctx, unsigned log_n, unsigned log_qd, uint32_t* is_first,
+                      uint32_t* is_last, uint32_t* is_transition);
+// quotient chunks, each written column-major (4 columns x n) with bit-reversed rows:
+// coefficient k of chunk c at chunk[c][k * n + pos]
+struct QuotOut {
+    uint32_t* chunk[16];
+};
+void launch_quotient(Context& ctx, const AirProgram& air, const ColMat& trace_lde, unsigned log_n,
+                     unsigned log_qd, const uint32_t* d_consts_mont, const uint32_t* d_alpha_pows_mont,
+                     const uint32_t* is_first, const uint32_t* is_last, const uint32_t* is_transition,
+                     const QuotOut& out);
+
+// ---- open.hip --------------------------------------------------------------------------------
+// d[p][i] = x_i / (z_p - x_i) (Montgomery EF4) for the low coset 31*H_n in bit-reversed order,
+// for up to 2 points; out layout [point][n] of Ef
+void launch_bary_weights(Context& ctx, unsigned log_n, const Ef* points_mont, uint32_t n_points,
+                         Ef* out);
+// partial[c][p] = sum_i m[c][i] * d[p][i]   (canonical EF4), i over the first n rows
+void launch_bary_sums(Context& ctx, const ColMat& m, unsigned log_n, const Ef* weights,
+                      uint32_t n_points, Ef* out /* width * n_points */);
+// ro[X] (+)= sum_p off_p * (S(X) - rys_p) / (x_X - z_p),  S(X) = sum_i alpha^i m[i][X]
+struct ReduceArgs {
+    Ef z_mont[2];
+    Ef off_mont[2];  // alpha^num_reduced (Montgomery)
+    Ef rys[2];       // reduced opened values (canonical)
+    uint32_t n_points;
+    uint32_t accumulate;  // 0: ro = ..., 1: ro += ...
+};
+void launch_reduce(Context& ctx, const ColMat& m, unsigned log_h, const uint32_t* d_alpha_pows_mont,
+                   const ReduceArgs& args, Ef* ro);
+
+// ---- fri.hip ---------------------------------------------------------------------------------
+// out[i] = fold(in[2i], in[2i+1]; beta) (reference two_adic_pcs.rs:116-147); h = output length.
+// If next_digests != nullptr (h >= 2) also writes the h/2 leaf digests of the next round.
+void launch_fri_fold(Context& ctx, const Ef* in, uint64_t h, Ef beta_canonical, Ef* out,
+                     uint32_t* next_digests);
+void launch_vec_add(Context& ctx, Ef* acc, const Ef* other, uint64_t n);
+// gathers: rows of column-major matrices and Merkle paths at given indices
+void launch_gather_rows(Context& ctx, const LeafMats& mats, const uint32_t* d_indices,
+                        uint32_t n_idx, unsigned index_shift, uint32_t* out);
+void launch_gather_paths(Context& ctx, const uint32_t* tree, unsigned log_leaves,
+                         const uint32_t* d_indices, uint32_t n_idx, unsigned index_shift,
+                         uint32_t* out);
+void launch_gather_ef_pairs(Context& ctx, const Ef* vec, const uint32_t* d_indices, uint32_t n_idx,
+                            unsigned index_shift, uint32_t* out);
+
+}  // namespace ts

@@ -1,0 +1,133 @@
+// Blake3 Merkle MMCS kernels (build-defined spec; there is no Merkle tree
+// in the reference, whose BFMmcs is a Bitcoin taptree: basic/src/mmcs/taptree_mmcs.rs:101-114).
+//   leaf  = Blake3(row of matrix 0 || row of matrix 1 || ...), elements as canonical u32 LE
+//   node  = Blake3(left || right)
+// Leaves: one thread per row; column-major matrices make every column read a coalesced 256 B
+// per wavefront.  Digests are stored as 8 consecutive words per node, levels back to back.
+#include "blake3.hpp"
+#include "kernels.hpp"
+
+namespace ts {
+
+__global__ void __launch_bounds__(256)
+k_leaf_hash(LeafMats mats, uint64_t height, uint32_t* __restrict__ digests) {
+    uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= height) return;
+    uint32_t cv[8];
+    b3::iv(cv);
+    const uint32_t total = mats.total_width;
+    const uint32_t n_blocks = total == 0 ? 1 : (total + 15) / 16;
+    // walk the concatenated row 16 words (one Blake3 block) at a time
+    uint32_t mi = 0;   // current matrix
+    uint32_t ci = 0;   // current column inside it
+    for (uint32_t blk = 0; blk < n_blocks; blk++) {
+        uint32_t m[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            uint32_t v = 0;
+            if (blk * 16 + j < total) {
+                while (ci >= mats.width[mi]) {
+                    ci = 0;
+                    mi++;
+                }
+                v = mats.d[mi][(uint64_t)ci * mats.col_stride[mi] + r];
+                ci++;
+            }
+            m[j] = v;
+        }
+        uint32_t words = total - blk * 16 < 16 ? total - blk * 16 : 16;
+        uint32_t flags = (blk == 0 ? b3::CHUNK_START : 0u) |
+                         (blk + 1 == n_blocks ? (b3::CHUNK_END | b3::ROOT) : 0u);
+        b3::compress(cv, m, words * 4, flags);
+    }
+    uint4* o = reinterpret_cast<uint4*>(digests + 8 * r);
+    o[0] = make_uint4(cv[0], cv[1], cv[2], cv[3]);
+    o[1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
+}
+
+void launch_leaf_hash(Context& ctx, const LeafMats& mats, uint64_t height, uint32_t* digests) {
+    TS_REQUIRE(mats.total_width <= 256, TS_ERR_UNSUPPORTED,
+               "leaf rows wider than 256 field elements (one Blake3 chunk) are not supported");
+    TS_LAUNCH(ctx, k_leaf_hash, dim3((unsigned)((height + 255) / 256)), dim3(256), 0, mats, height, digests);
+    TS_HIP(hipGetLastError());
+}
+
+// rows of two EF4 (32 bytes) -> one short block each
+__global__ void __launch_bounds__(256)
+k_leaf_hash_ef_pairs(const uint4* __restrict__ vec, uint64_t n_rows, uint32_t* __restrict__ digests) {
+    uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    uint4 a = vec[2 * r], b = vec[2 * r + 1];
+    uint32_t m[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t cv[8];
+    b3::iv(cv);
+    b3::compress(cv, m, 32, b3::CHUNK_START | b3::CHUNK_END | b3::ROOT);
+    uint4* o = reinterpret_cast<uint4*>(digests + 8 * r);
+    o[0] = make_uint4(cv[0], cv[1], cv[2], cv[3]);
+    o[1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
+}
+
+void launch_leaf_hash_ef_pairs(Context& ctx, const uint32_t* vec, uint64_t n_rows, uint32_t* digests) {
+    TS_LAUNCH(ctx, k_leaf_hash_ef_pairs, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0,
+                       reinterpret_cast<const uint4*>(vec), n_rows, digests);
+    TS_HIP(hipGetLastError());
+}
+
+// one level: parents[i] = Blake3(children[2i] || children[2i+1])
+__global__ void __launch_bounds__(256)
+k_merkle_level(const uint4* __restrict__ children, uint4* __restrict__ parents, uint64_t n_parents) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_parents) return;
+    uint4 a = children[4 * i], b = children[4 * i + 1], c = children[4 * i + 2], d = children[4 * i + 3];
+    uint32_t m[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+    uint32_t cv[8];
+    b3::hash64(m, cv);
+    parents[2 * i] = make_uint4(cv[0], cv[1], cv[2], cv[3]);
+    parents[2 * i + 1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
+}
+
+// the top of the tree (<= 512 children) in one workgroup: avoids ~9 tiny launches per tree
+__global__ void __launch_bounds__(256)
+k_merkle_top(uint32_t* __restrict__ tree, unsigned log_leaves, unsigned first_level) {
+    // level `first_level` (already computed) has 2^(log_leaves - first_level) <= 512 nodes
+    uint64_t off = 0;
+    for (unsigned l = 0; l < first_level; l++) off += (uint64_t)1 << (log_leaves - l);
+    for (unsigned l = first_level; l < log_leaves; l++) {
+        const uint64_t n_children = (uint64_t)1 << (log_leaves - l);
+        const uint4* children = reinterpret_cast<const uint4*>(tree + 8 * off);
+        uint4* parents = reinterpret_cast<uint4*>(tree + 8 * (off + n_children));
+        uint32_t i = threadIdx.x;
+        if (i < n_children / 2) {
+            uint4 a = children[4 * i], b = children[4 * i + 1], c = children[4 * i + 2],
+                  d = children[4 * i + 3];
+            uint32_t m[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w,
+                              c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+            uint32_t cv[8];
+            b3::hash64(m, cv);
+            parents[2 * i] = make_uint4(cv[0], cv[1], cv[2], cv[3]);
+            parents[2 * i + 1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
+        }
+        off += n_children;
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+void launch_merkle_levels(Context& ctx, uint32_t* tree, unsigned log_leaves) {
+    uint64_t off = 0;
+    unsigned l = 0;
+    for (; l < log_leaves; l++) {
+        uint64_t n_children = (uint64_t)1 << (log_leaves - l);
+        if (n_children <= 512) break;
+        uint64_t n_parents = n_children / 2;
+        TS_LAUNCH(ctx, k_merkle_level, dim3((unsigned)((n_parents + 255) / 256)), dim3(256), 0,
+                           reinterpret_cast<const uint4*>(tree + 8 * off),
+                           reinterpret_cast<uint4*>(tree + 8 * (off + n_children)), n_parents);
+        off += n_children;
+    }
+    if (l < log_leaves)
+        TS_LAUNCH(ctx, k_merkle_top, dim3(1), dim3(256), 0, tree, log_leaves, l);
+    TS_HIP(hipGetLastError());
+}
+
+}  // namespace ts

@@ -1,0 +1,472 @@
+// prove() and TwoAdicFriPcs on the device.  Transcript order, proof structure and every index
+// convention follow the reference:
+//   uni-stark/src/prover.rs:25-119      prove
+//   fri/src/two_adic_pcs.rs:227-245     commit
+//   fri/src/two_adic_pcs.rs:247-258     get_evaluations_on_domain (fused into the quotient kernel)
+//   fri/src/two_adic_pcs.rs:260-419     open
+//   fri/src/prover.rs:19-141            bf_prove / bf_commit_phase / bf_answer_query
+// The GPU owns the data from the uploaded trace to the opened rows; the host owns the transcript
+// (one 32-byte root down, one challenge up per commitment).
+#include <string.h>
+
+#include <algorithm>
+
+#include "host.hpp"
+
+namespace ts {
+
+namespace {
+
+void h2d(Context& ctx, void* dst, const void* src, size_t bytes) {
+    if (bytes) TS_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx.stream));
+}
+void d2h_sync(Context& ctx, void* dst, const void* src, size_t bytes) {
+    if (bytes) TS_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx.stream));
+    ctx.sync();
+}
+
+unsigned log2_strict(uint64_t n) {
+    unsigned k = 0;
+    while ((1ull << k) < n) k++;
+    TS_REQUIRE((1ull << k) == n, TS_ERR_INVALID, "height must be a power of two");
+    return k;
+}
+
+// canonical-domain EF helpers for the handful of host-side scalars
+Ef efc_mul(Ef a, Ef b) { return ef_mul(a, ef_to_mont(b)); }
+Ef efc_mul_base(Ef a, uint32_t b) { return ef_mul_base(a, to_mont(b)); }
+Ef efc_pow(Ef a, uint64_t e) { return ef_from_mont(ef_pow(ef_to_mont(a), e)); }
+Ef efc_one() { return Ef{{1, 0, 0, 0}}; }
+
+constexpr uint32_t TSPF_MAGIC = 0x46505354u;
+
+}  // namespace
+
+LeafMats PcsData::leaf_mats() const {
+    LeafMats lm;
+    memset(&lm, 0, sizeof lm);
+    lm.n_mats = (uint32_t)ldes.size();
+    for (size_t i = 0; i < ldes.size(); i++) {
+        lm.d[i] = ldes[i].d;
+        lm.col_stride[i] = ldes[i].col_stride;
+        lm.width[i] = ldes[i].width;
+        lm.total_width += ldes[i].width;
+    }
+    return lm;
+}
+
+// ------------------------------------------------------------------ commit
+std::unique_ptr<PcsData> TwoAdicFriPcs::commit(std::vector<DeviceMatrix>& evals,
+                                               const std::vector<uint32_t>& domain_shifts) {
+    TS_REQUIRE(!evals.empty() && evals.size() <= (size_t)MAX_BATCH_MATS, TS_ERR_INVALID,
+               "commit: between 1 and 16 matrices per batch");
+    TS_REQUIRE(evals.size() == domain_shifts.size(), TS_ERR_INVALID, "commit: one domain per matrix");
+    const uint64_t n = evals[0].height;
+    for (auto& m : evals) {
+        TS_REQUIRE(m.height == n, TS_ERR_UNSUPPORTED,
+                   "commit: matrices of different heights in one batch are not supported yet");
+        TS_REQUIRE(m.width >= 1 && m.buf.p, TS_ERR_INVALID, "commit: empty matrix");
+    }
+    const unsigned log_n = log2_strict(n);
+    const unsigned log_N = log_n + fri_.log_blowup;
+    TS_REQUIRE(log_N <= 27, TS_ERR_INVALID, "commit: LDE larger than the two-adic subgroup");
+    const uint64_t N = 1ull << log_N;
+    ctx_.ensure_twiddles(std::max(1u, log_N));
+
+    auto data = std::make_unique<PcsData>();
+    data->log_height = log_N;
+    {
+        StageTimer t(&ctx_, "coset_lde");
+        for (size_t i = 0; i < evals.size(); i++) {
+            DeviceMatrix& m = evals[i];
+            TS_REQUIRE(domain_shifts[i] != 0 && domain_shifts[i] < P, TS_ERR_INVALID, "bad domain shift");
+            DevBuf<uint32_t> colmajor;
+            uint32_t* ev = m.buf.p;
+            if (m.layout == DeviceMatrix::ROW_MAJOR) {
+                colmajor = DevBuf<uint32_t>(&ctx_, (size_t)m.width * n);
+                launch_transpose_bitrev(ctx_, m.buf.p, colmajor.p, log_n, m.width, n);
+                ev = colmajor.p;
+            }
+            DevBuf<uint32_t> lde(&ctx_, (size_t)m.width * N);
+            // two_adic_pcs.rs:235: shift = Val::generator() / domain.shift
+            const uint32_t shift = mul(GENERATOR, inv_canon(domain_shifts[i]));
+            coset_lde(ctx_, ev, n, m.width, log_n, fri_.log_blowup, shift, lde.p, N);
+            ColMat cm;
+            cm.d = lde.p;
+            cm.height = N;
+            cm.width = m.width;
+            cm.col_stride = N;
+            data->ldes.push_back(cm);
+            data->lde_storage.push_back(std::move(lde));
+            m.buf.reset();  // consumed
+        }
+    }
+    {
+        StageTimer t(&ctx_, "merkle_commit");
+        data->tree = DevBuf<uint32_t>(&ctx_, merkle_total_digests(log_N) * 8);
+        launch_leaf_hash(ctx_, data->leaf_mats(), N, data->tree.p);
+        launch_merkle_levels(ctx_, data->tree.p, log_N);
+        d2h_sync(ctx_, data->root, data->tree.p + 8 * (merkle_total_digests(log_N) - 1), 32);
+    }
+    return data;
+}
+
+// ------------------------------------------------------------------ quotient
+std::vector<DeviceMatrix> TwoAdicFriPcs::quotient_chunks(const PcsData& trace_data,
+                                                         const AirProgram& air,
+                                                         const std::vector<uint32_t>& pis, Ef alpha) {
+    StageTimer t(&ctx_, "compute quotient polynomial");
+    TS_REQUIRE(trace_data.ldes.size() >= 1, TS_ERR_INVALID, "quotient: no trace matrix");
+    const ColMat& lde = trace_data.ldes[0];
+    TS_REQUIRE(lde.width == air.width, TS_ERR_INVALID, "quotient: trace width != AIR width");
+    TS_REQUIRE(pis.size() == air.n_public, TS_ERR_INVALID, "quotient: wrong number of public values");
+    const unsigned lqd = air.log_quotient_degree;
+    // two_adic_pcs.rs:256: assert!(lde.height() >= domain.size())
+    TS_REQUIRE(lqd <= fri_.log_blowup, TS_ERR_INVARIANT,
+               "quotient domain larger than the committed LDE (log_quotient_degree > log_blowup)");
+    TS_REQUIRE(trace_data.log_height >= fri_.log_blowup, TS_ERR_INVALID, "quotient: bad trace data");
+    const unsigned log_n = trace_data.log_height - fri_.log_blowup;
+    const uint64_t n = 1ull << log_n, qn = n << lqd;
+    const uint32_t qd = 1u << lqd;
+
+    DevBuf<uint32_t> sel(&ctx_, 3 * qn);
+    launch_selectors(ctx_, log_n, lqd, sel.p, sel.p + qn, sel.p + 2 * qn);
+
+    // constants / public values in Montgomery form
+    std::vector<uint32_t> consts(std::max<size_t>(air.const_canonical.size(), 1), 0);
+    for (size_t k = 0; k < air.const_canonical.size(); k++) {
+        uint32_t v = air.const_public_idx[k] != ~0u ? pis[air.const_public_idx[k]] : air.const_canonical[k];
+        TS_REQUIRE(v < P, TS_ERR_INVALID, "non-canonical public value");
+        consts[k] = to_mont(v);
+    }
+    // alpha^(K-1-i): folder.rs:60-64 unrolled (acc = acc*alpha + c_i)
+    const uint32_t K = air.n_constraints;
+    std::vector<uint32_t> apow(std::max<size_t>(4 * (size_t)K, 4), 0);
+    {
+        Ef am = ef_to_mont(alpha), cur = ef_one_mont();
+        for (uint32_t i = 0; i < K; i++) {
+            memcpy(&apow[4 * (size_t)(K - 1 - i)], cur.c, 16);
+            cur = ef_mul(cur, am);
+        }
+    }
+    DevBuf<uint32_t> d_consts(&ctx_, consts.size()), d_apow(&ctx_, apow.size());
+    h2d(ctx_, d_consts.p, consts.data(), consts.size() * 4);
+    h2d(ctx_, d_apow.p, apow.data(), apow.size() * 4);
+
+    std::vector<DeviceMatrix> chunks(qd);
+    QuotOut qo;
+    memset(&qo, 0, sizeof qo);
+    for (uint32_t c = 0; c < qd; c++) {
+        chunks[c].buf = DevBuf<uint32_t>(&ctx_, 4 * n);
+        chunks[c].height = n;
+        chunks[c].width = 4;
+        chunks[c].layout = DeviceMatrix::COL_MAJOR_BITREV;
+        qo.chunk[c] = chunks[c].buf.p;
+    }
+    launch_quotient(ctx_, air, lde, log_n, lqd, d_consts.p, d_apow.p, sel.p, sel.p + qn, sel.p + 2 * qn, qo);
+    // the pageable staging vectors must outlive the async copies
+    ctx_.sync();
+    return chunks;
+}
+
+// ------------------------------------------------------------------ open
+DevBuf<Ef> TwoAdicFriPcs::open_reduce(const PcsData& trace_data, const PcsData& quotient_data, Ef zeta,
+                                      Ef alpha, std::vector<Ef>& opened_values) {
+    TS_REQUIRE(trace_data.ldes.size() == 1, TS_ERR_UNSUPPORTED, "open: one trace matrix expected");
+    TS_REQUIRE(trace_data.log_height == quotient_data.log_height, TS_ERR_INVALID,
+               "open: trace and quotient LDE heights differ");
+    const unsigned log_N = trace_data.log_height;
+    const unsigned log_n = log_N - fri_.log_blowup;
+    const uint64_t n = 1ull << log_n, N = 1ull << log_N;
+    const ColMat& tr = trace_data.ldes[0];
+    const uint32_t w = tr.width;
+    const uint32_t qd = (uint32_t)quotient_data.ldes.size();
+    for (auto& m : quotient_data.ldes)
+        TS_REQUIRE(m.width == 4, TS_ERR_INVALID, "open: quotient chunks must have width 4");
+    ctx_.ensure_twiddles(std::max(1u, log_N));
+
+    // prover.rs:92 zeta_next = trace_domain.next_point(zeta) = zeta * omega_n
+    const Ef zeta_next = efc_mul_base(zeta, two_adic_generator(log_n));
+    const Ef pts_mont[2] = {ef_to_mont(zeta), ef_to_mont(zeta_next)};
+
+    // ---- opened values: barycentric interpolation on the low coset (two_adic_pcs.rs:358-369)
+    std::vector<Ef> raw(2 * (size_t)w + 4 * (size_t)qd);
+    {
+        StageTimer t(&ctx_, "compute opened values with Lagrange interpolation");
+        DevBuf<Ef> weights(&ctx_, 2 * n);
+        launch_bary_weights(ctx_, log_n, pts_mont, 2, weights.p);
+        DevBuf<Ef> sums(&ctx_, raw.size());
+        launch_bary_sums(ctx_, tr, log_n, weights.p, 2, sums.p);  // [col][point]
+        for (uint32_t c = 0; c < qd; c++)
+            launch_bary_sums(ctx_, quotient_data.ldes[c], log_n, weights.p, 1, sums.p + 2 * w + 4 * c);
+        d2h_sync(ctx_, raw.data(), sums.p, raw.size() * sizeof(Ef));
+    }
+    // p(z) = ((z/31)^n - 1)/n * sum_i p_i x_i/(z - x_i)
+    const uint32_t gen_inv = inv_canon(GENERATOR);
+    const uint32_t n_inv = inv_canon((uint32_t)(n % P));
+    Ef scale[2];
+    for (int p = 0; p < 2; p++) {
+        Ef u = efc_mul_base(p == 0 ? zeta : zeta_next, gen_inv);
+        Ef un = efc_pow(u, n);
+        un.c[0] = sub(un.c[0], 1);
+        scale[p] = efc_mul_base(un, n_inv);
+    }
+    opened_values.assign(2 * (size_t)w + 4 * (size_t)qd, ef_zero());
+    for (uint32_t c = 0; c < w; c++) {
+        opened_values[c] = efc_mul(raw[2 * c], scale[0]);          // trace_local
+        opened_values[w + c] = efc_mul(raw[2 * c + 1], scale[1]);  // trace_next
+    }
+    for (uint32_t k = 0; k < 4 * qd; k++) opened_values[2 * w + k] = efc_mul(raw[2 * w + k], scale[0]);
+
+    // ---- reduce (two_adic_pcs.rs:371-383)
+    StageTimer t(&ctx_, "reduce rows");
+    const uint32_t max_w = std::max(w, 4u);
+    std::vector<uint32_t> apow(4 * (size_t)max_w);
+    const Ef am = ef_to_mont(alpha);
+    {
+        Ef cur = ef_one_mont();
+        for (uint32_t i = 0; i < max_w; i++) {
+            memcpy(&apow[4 * (size_t)i], cur.c, 16);
+            cur = ef_mul(cur, am);
+        }
+    }
+    DevBuf<uint32_t> d_apow(&ctx_, apow.size());
+    h2d(ctx_, d_apow.p, apow.data(), apow.size() * 4);
+    auto reduced_ys = [&](const Ef* ys, uint32_t width) {  // dot_product(alpha.powers(), ys), :372
+        Ef acc = ef_zero();
+        for (uint32_t i = 0; i < width; i++) {
+            Ef ap;
+            memcpy(ap.c, &apow[4 * (size_t)i], 16);
+            acc = ef_add(acc, ef_mul(ys[i], ap));  // canonical x Montgomery -> canonical
+        }
+        return acc;
+    };
+    DevBuf<Ef> ro(&ctx_, N);
+    uint64_t num_reduced = 0;  // :329, all matrices share log_height here
+    {
+        ReduceArgs a;
+        memset(&a, 0, sizeof a);
+        a.n_points = 2;
+        a.accumulate = 0;
+        a.z_mont[0] = pts_mont[0];
+        a.z_mont[1] = pts_mont[1];
+        a.off_mont[0] = ef_pow(am, num_reduced);  // :371 alpha^num_reduced
+        a.rys[0] = reduced_ys(&opened_values[0], w);
+        num_reduced += w;
+        a.off_mont[1] = ef_pow(am, num_reduced);
+        a.rys[1] = reduced_ys(&opened_values[w], w);
+        num_reduced += w;
+        launch_reduce(ctx_, tr, log_N, d_apow.p, a, ro.p);
+    }
+    for (uint32_t c = 0; c < qd; c++) {
+        ReduceArgs a;
+        memset(&a, 0, sizeof a);
+        a.n_points = 1;
+        a.accumulate = 1;
+        a.z_mont[0] = pts_mont[0];
+        a.off_mont[0] = ef_pow(am, num_reduced);
+        a.rys[0] = reduced_ys(&opened_values[2 * w + 4 * c], 4);
+        num_reduced += 4;
+        launch_reduce(ctx_, quotient_data.ldes[c], log_N, d_apow.p, a, ro.p);
+    }
+    ctx_.sync();  // pageable apow must outlive its async copy
+    return ro;
+}
+
+// ------------------------------------------------------------------ open_batch
+void TwoAdicFriPcs::open_batch(const PcsData& d, uint64_t index, std::vector<uint32_t>& rows,
+                               std::vector<uint32_t>& path) {
+    TS_REQUIRE(index < (1ull << d.log_height), TS_ERR_INVALID, "open_batch: index out of range");
+    LeafMats lm = d.leaf_mats();
+    DevBuf<uint32_t> d_idx(&ctx_, 1), d_rows(&ctx_, std::max(lm.total_width, 1u)),
+        d_path(&ctx_, std::max(8u * d.log_height, 8u));
+    uint32_t idx32 = (uint32_t)index;
+    h2d(ctx_, d_idx.p, &idx32, 4);
+    launch_gather_rows(ctx_, lm, d_idx.p, 1, 0, d_rows.p);
+    launch_gather_paths(ctx_, d.tree.p, d.log_height, d_idx.p, 1, 0, d_path.p);
+    rows.resize(lm.total_width);
+    path.resize(8 * (size_t)d.log_height);
+    if (!rows.empty()) TS_HIP(hipMemcpyAsync(rows.data(), d_rows.p, rows.size() * 4, hipMemcpyDeviceToHost, ctx_.stream));
+    if (!path.empty()) TS_HIP(hipMemcpyAsync(path.data(), d_path.p, path.size() * 4, hipMemcpyDeviceToHost, ctx_.stream));
+    ctx_.sync();
+}
+
+// ------------------------------------------------------------------ prove
+namespace {
+
+struct FriRound {
+    DevBuf<Ef> vec;          // committed vector (rows of two): length 2 * 2^log_leaves
+    DevBuf<uint32_t> tree;
+    unsigned log_leaves = 0;
+    uint32_t root[8];
+};
+
+}  // namespace
+
+std::vector<uint32_t> prove(TwoAdicFriPcs& pcs, const AirProgram& air, BfChallenger& challenger,
+                            DeviceMatrix trace, const std::vector<uint32_t>& public_values) {
+    Context& ctx = pcs.ctx();
+    const FriConfig& fri = pcs.fri();
+    TS_REQUIRE(trace.width == air.width, TS_ERR_INVALID, "prove: trace width != AIR width");
+    TS_REQUIRE(public_values.size() == air.n_public, TS_ERR_INVALID,
+               "prove: wrong number of public values");
+    const uint64_t degree = trace.height;  // prover.rs:43-44
+    const unsigned log_degree = log2_strict(degree);
+    const unsigned lqd = air.log_quotient_degree;  // :46
+    const uint32_t qd = 1u << lqd;
+    const unsigned log_N = log_degree + fri.log_blowup;
+    const uint32_t w = air.width;
+    TS_REQUIRE(lqd <= fri.log_blowup, TS_ERR_INVARIANT,
+               "quotient domain larger than the committed LDE (log_quotient_degree > log_blowup)");
+    ctx.ensure_twiddles(std::max(1u, log_N));
+
+    // :50-53 commit to trace data (natural domain: shift 1)
+    std::vector<DeviceMatrix> tv;
+    tv.push_back(std::move(trace));
+    std::unique_ptr<PcsData> trace_data = pcs.commit(tv, {1u});
+    challenger.observe_commitment(trace_data->root);  // :60
+    const Ef alpha = challenger.sample();              // :63
+
+    // :65-80 quotient on the disjoint domain, flattened and split into qd chunks
+    std::vector<DeviceMatrix> chunks = pcs.quotient_chunks(*trace_data, air, public_values, alpha);
+    // split_domains (:80): chunk c lives on {log_n, shift = 31 * omega_{n*qd}^c}
+    std::vector<uint32_t> qshifts(qd);
+    const uint32_t gq = two_adic_generator(log_degree + lqd);
+    for (uint32_t c = 0; c < qd; c++) qshifts[c] = mul(GENERATOR, pow_canon(gq, c));
+    std::unique_ptr<PcsData> quotient_data = pcs.commit(chunks, qshifts);  // :82-83
+    challenger.observe_commitment(quotient_data->root);                    // :84
+    const Ef zeta = challenger.sample();                                   // :91
+
+    // :94-104 open; two_adic_pcs.rs:312 batch-combination challenge first
+    const Ef batch_alpha = challenger.sample();
+    std::vector<Ef> opened;
+    DevBuf<Ef> folded = pcs.open_reduce(*trace_data, *quotient_data, zeta, batch_alpha, opened);
+
+    // ---- bf_commit_phase, fri/src/prover.rs:93-141
+    std::vector<FriRound> rounds;
+    Ef final_poly;
+    {
+        StageTimer t(&ctx, "FRI commit phase");
+        uint64_t len = 1ull << log_N;
+        DevBuf<uint32_t> next_tree;
+        while (len > fri.blowup()) {  // :111
+            FriRound r;
+            const uint64_t h = len / 2;
+            r.log_leaves = log2_strict(h);
+            if (rounds.empty()) {
+                r.tree = DevBuf<uint32_t>(&ctx, merkle_total_digests(r.log_leaves) * 8);
+                launch_leaf_hash_ef_pairs(ctx, reinterpret_cast<const uint32_t*>(folded.p), h, r.tree.p);
+            } else {
+                r.tree = std::move(next_tree);  // leaves were hashed by the previous fold
+            }
+            launch_merkle_levels(ctx, r.tree.p, r.log_leaves);  // :113 commit_matrix
+            d2h_sync(ctx, r.root, r.tree.p + 8 * (merkle_total_digests(r.log_leaves) - 1), 32);
+            challenger.observe_commitment(r.root);  // :114
+            const Ef beta = challenger.sample();    // :116
+            DevBuf<Ef> out(&ctx, h);
+            uint32_t* nd = nullptr;
+            if (h > fri.blowup()) {  // another round follows: its leaves are pairs of `out`
+                next_tree = DevBuf<uint32_t>(&ctx, merkle_total_digests(r.log_leaves - 1) * 8);
+                nd = next_tree.p;
+            }
+            launch_fri_fold(ctx, folded.p, h, beta, out.p, nd);  // :119 fold_matrix
+            r.vec = std::move(folded);
+            folded = std::move(out);
+            rounds.push_back(std::move(r));
+            len = h;
+        }
+        // :129-134 `blowup` evaluations of a constant polynomial
+        TS_REQUIRE(len == fri.blowup(), TS_ERR_INVARIANT, "FRI: folded length != blowup");
+        std::vector<Ef> fin(len);
+        d2h_sync(ctx, fin.data(), folded.p, len * sizeof(Ef));
+        final_poly = fin[0];
+        for (auto& x : fin)
+            TS_REQUIRE(ef_eq(x, final_poly), TS_ERR_INVARIANT,
+                       "FRI: final polynomial is not constant (assert_eq!(x, final_poly))");
+    }
+    const uint32_t R = (uint32_t)rounds.size();
+
+    // :43 proof of work
+    uint32_t pow_witness;
+    {
+        StageTimer t(&ctx, "grind for proof-of-work witness");
+        pow_witness = challenger.grind(fri.proof_of_work_bits);
+    }
+
+    // ---- query phase :45-59
+    StageTimer tq(&ctx, "query phase");
+    const uint32_t Q = fri.num_queries;
+    std::vector<uint32_t> indices(std::max(Q, 1u));
+    for (uint32_t q = 0; q < Q; q++) indices[q] = (uint32_t)challenger.sample_bits(log_N);
+    DevBuf<uint32_t> d_idx(&ctx, indices.size());
+    h2d(ctx, d_idx.p, indices.data(), indices.size() * 4);
+
+    // gather everything into one buffer, one D2H
+    const size_t path_words = 8 * (size_t)log_N;
+    size_t off = 0;
+    const size_t o_trows = off; off += (size_t)Q * w;
+    const size_t o_tpath = off; off += (size_t)Q * path_words;
+    const size_t o_qrows = off; off += (size_t)Q * 4 * qd;
+    const size_t o_qpath = off; off += (size_t)Q * path_words;
+    std::vector<size_t> o_fvals(R), o_fpath(R);
+    for (uint32_t r = 0; r < R; r++) {
+        o_fvals[r] = off; off += (size_t)Q * 8;
+        o_fpath[r] = off; off += (size_t)Q * 8 * rounds[r].log_leaves;
+    }
+    DevBuf<uint32_t> d_out(&ctx, std::max<size_t>(off, 1));
+    const LeafMats tlm = trace_data->leaf_mats(), qlm = quotient_data->leaf_mats();
+    // two_adic_pcs.rs:399-414: both input batches have the global max height => bits_reduced = 0
+    launch_gather_rows(ctx, tlm, d_idx.p, Q, 0, d_out.p + o_trows);
+    launch_gather_paths(ctx, trace_data->tree.p, log_N, d_idx.p, Q, 0, d_out.p + o_tpath);
+    launch_gather_rows(ctx, qlm, d_idx.p, Q, 0, d_out.p + o_qrows);
+    launch_gather_paths(ctx, quotient_data->tree.p, log_N, d_idx.p, Q, 0, d_out.p + o_qpath);
+    for (uint32_t r = 0; r < R; r++) {  // bf_answer_query :69-90: index_i = index >> i >> 1
+        launch_gather_ef_pairs(ctx, rounds[r].vec.p, d_idx.p, Q, r + 1, d_out.p + o_fvals[r]);
+        launch_gather_paths(ctx, rounds[r].tree.p, rounds[r].log_leaves, d_idx.p, Q, r + 1,
+                            d_out.p + o_fpath[r]);
+    }
+    std::vector<uint32_t> g(std::max<size_t>(off, 1));
+    d2h_sync(ctx, g.data(), d_out.p, off * 4);
+
+    // ---- assemble Proof (prover.rs:105-118) in TSPF v1 order
+    std::vector<uint32_t> pf;
+    pf.reserve(64 + opened.size() * 4 + off + (size_t)Q * (8 + 2 * R));
+    auto push = [&](uint32_t v) { pf.push_back(v); };
+    auto push_n = [&](const uint32_t* p, size_t k) { pf.insert(pf.end(), p, p + k); };
+    push(TSPF_MAGIC);
+    push(1);
+    push(log_degree);
+    push(w);
+    push(qd);
+    push_n(trace_data->root, 8);
+    push_n(quotient_data->root, 8);
+    for (auto& e : opened) push_n(e.c, 4);
+    push(R);
+    for (uint32_t r = 0; r < R; r++) push_n(rounds[r].root, 8);
+    push(Q);
+    for (uint32_t q = 0; q < Q; q++) {
+        push(2);  // input_proof: one BatchOpening per commit round
+        push(1);
+        push(w);
+        push_n(&g[o_trows + (size_t)q * w], w);
+        push(log_N);
+        push_n(&g[o_tpath + (size_t)q * path_words], path_words);
+        push(qd);
+        for (uint32_t c = 0; c < qd; c++) {
+            push(4);
+            push_n(&g[o_qrows + (size_t)q * 4 * qd + 4 * c], 4);
+        }
+        push(log_N);
+        push_n(&g[o_qpath + (size_t)q * path_words], path_words);
+        for (uint32_t r = 0; r < R; r++) {  // commit_phase_openings
+            push_n(&g[o_fvals[r] + (size_t)q * 8], 8);
+            push(rounds[r].log_leaves);
+            push_n(&g[o_fpath[r] + (size_t)q * 8 * rounds[r].log_leaves], 8 * (size_t)rounds[r].log_leaves);
+        }
+    }
+    push_n(final_poly.c, 4);
+    push(pow_witness);
+    return pf;
+}
+
+}  // namespace ts

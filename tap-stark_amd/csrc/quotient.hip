@@ -1,0 +1,191 @@
+// Quotient evaluation (reference uni-stark/src/prover.rs:122-194 `quotient_values` with
+// ProverConstraintFolder, folder.rs:11-19,60-64; selectors: p3-commit selectors_on_coset,
+// SURVEY.md App. A.4; chunking: prover.rs:78-80 flatten_to_base/split_evals).
+//
+// One thread per row of the quotient domain 31*H_{n*qd}, addressed in the LDE's own storage order
+// (bit-reversed), so that `local` is a coalesced read and `next` (natural index + qd) is a second
+// coalesced read for all but one wavefront in 2^(L-6).  The constraint program is interpreted with
+// wave-uniform control flow; its register file lives in LDS ([reg][thread], conflict-free).
+// folder.rs:60-64 accumulates acc = acc*alpha + c_i; here the same value is formed as
+// sum_i c_i * alpha^(K-1-i) with precomputed powers (4 base multiplications per constraint instead
+// of an EF4 x EF4 product) -- exact field arithmetic, identical result.
+#include "air.hpp"
+#include "kernels.hpp"
+
+namespace ts {
+
+// ------------------------------------------------------------------ selectors
+// Storage index r <-> natural index i = bitrev_L(r); x_r = 31 * omega_{2^L}^i.
+// W is the block-twiddle table: omega_{2^L}^bitrev_L(r) = (r odd ? -1 : 1) * W[2^(L-1) + (r >> 1)].
+constexpr int SEL_BATCH = 8;
+
+struct SelConsts {
+    uint32_t zh_mont[16];  // Z_H on the qd cosets: 31^n * omega_qd^c - 1  (Montgomery)
+};
+
+__global__ void __launch_bounds__(256)
+k_selectors(unsigned L, unsigned log_qd, const uint32_t* __restrict__ W, uint32_t gen_mont,
+            uint32_t gn_inv_mont, SelConsts sc, uint32_t* __restrict__ is_first,
+            uint32_t* __restrict__ is_last, uint32_t* __restrict__ is_transition) {
+    const uint64_t total = 1ull << L;
+    const uint64_t r0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * SEL_BATCH;
+    if (r0 >= total) return;
+    const unsigned log_n = L - log_qd;
+    uint32_t d[2 * SEL_BATCH];
+    uint32_t pre[2 * SEL_BATCH];
+    uint32_t run = R_MOD_P;
+    const int cnt = (total - r0) < (uint64_t)SEL_BATCH ? (int)(total - r0) : SEL_BATCH;
+#pragma unroll
+    for (int k = 0; k < SEL_BATCH; k++) {
+        if (k < cnt) {
+            uint64_t r = r0 + k;
+            uint32_t w = L == 0 ? R_MOD_P : W[(total >> 1) + (r >> 1)];
+            if (r & 1) w = neg(w);
+            uint32_t x = mont_mul(gen_mont, w);
+            d[2 * k] = sub(x, R_MOD_P);         // x - 1
+            d[2 * k + 1] = sub(x, gn_inv_mont);  // x - omega_n^-1
+        } else {
+            d[2 * k] = d[2 * k + 1] = R_MOD_P;
+        }
+        pre[2 * k] = run;
+        run = mont_mul(run, d[2 * k]);
+        pre[2 * k + 1] = run;
+        run = mont_mul(run, d[2 * k + 1]);
+    }
+    uint32_t inv = mont_inv(run);
+#pragma unroll
+    for (int k = SEL_BATCH - 1; k >= 0; k--) {
+        uint32_t inv_last = mont_mul(inv, pre[2 * k + 1]);
+        inv = mont_mul(inv, d[2 * k + 1]);
+        uint32_t inv_first = mont_mul(inv, pre[2 * k]);
+        inv = mont_mul(inv, d[2 * k]);
+        if (k < cnt) {
+            uint64_t r = r0 + k;
+            // coset index c = natural i mod qd = bitrev_lqd(r >> log_n)
+            uint32_t c = bitrev32((uint32_t)(r >> log_n), log_qd);
+            uint32_t zh = sc.zh_mont[c];
+            is_first[r] = mont_mul(zh, inv_first);
+            is_last[r] = mont_mul(zh, inv_last);
+            is_transition[r] = d[2 * k + 1];
+        }
+    }
+}
+
+void launch_selectors(Context& ctx, unsigned log_n, unsigned log_qd, uint32_t* is_first,
+                      uint32_t* is_last, uint32_t* is_transition) {
+    const unsigned L = log_n + log_qd;
+    TS_REQUIRE(log_qd <= 4, TS_ERR_UNSUPPORTED, "quotient degree > 16 not supported");
+    ctx.ensure_twiddles(L == 0 ? 1 : L);
+    SelConsts sc;
+    const uint32_t s_pow_n = pow_canon(GENERATOR, 1ull << log_n);
+    const uint32_t gqd = two_adic_generator(log_qd);
+    for (uint32_t c = 0; c < (1u << log_qd); c++)
+        sc.zh_mont[c] = to_mont(sub(mul(s_pow_n, pow_canon(gqd, c)), 1));
+    const uint32_t gn_inv = inv_canon(two_adic_generator(log_n));
+    const uint64_t threads = (((uint64_t)1 << L) + SEL_BATCH - 1) / SEL_BATCH;
+    TS_LAUNCH(ctx, k_selectors, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, L, log_qd, ctx.d_twiddle_fwd, to_mont(GENERATOR), to_mont(gn_inv), sc, is_first,
+                       is_last, is_transition);
+    TS_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------ interpreter
+struct QuotConsts {
+    uint32_t inv_zh_canonical[16];  // 1/Z_H per coset, CANONICAL: acc(Mont) * it -> canonical
+};
+
+template <int NTHREADS>
+__global__ void __launch_bounds__(NTHREADS)
+k_quotient(const uint32_t* __restrict__ code, uint32_t n_instr, uint32_t n_regs,
+           const uint32_t* __restrict__ lde, uint64_t col_stride, unsigned log_n, unsigned log_qd,
+           const uint32_t* __restrict__ consts_mont, const uint32_t* __restrict__ alpha_pows,
+           const uint32_t* __restrict__ is_first, const uint32_t* __restrict__ is_last,
+           const uint32_t* __restrict__ is_transition, QuotConsts qc, QuotOut out) {
+    extern __shared__ uint32_t regs[];  // [n_regs][NTHREADS]
+    const unsigned L = log_n + log_qd;
+    const uint32_t r = blockIdx.x * NTHREADS + threadIdx.x;  // grid covers exactly 2^L rows
+    const uint32_t total = 1u << L;
+    const bool active = r < total;
+    const uint32_t rr = active ? r : 0;
+    const uint32_t i = bitrev32(rr, L);
+    const uint32_t i_next = (i + (1u << log_qd)) & (total - 1);  // prover.rs:139-140,165
+    const uint32_t r_next = bitrev32(i_next, L);
+    const uint32_t sel0 = is_first[rr], sel1 = is_last[rr], sel2 = is_transition[rr];
+    const uint32_t* row_local = lde + rr;
+    const uint32_t* row_next = lde + r_next;
+    uint32_t* my = regs + threadIdx.x;
+    uint32_t acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
+
+    for (uint32_t pc = 0; pc < n_instr; pc++) {
+        // wave-uniform instruction fetch (scalar loads)
+        const uint32_t op = code[4 * pc], dst = code[4 * pc + 1], a = code[4 * pc + 2],
+                       b = code[4 * pc + 3];
+        uint32_t v;
+        switch (op) {
+            case D_LOAD: {
+                const uint32_t* base = a ? row_next : row_local;
+                v = to_mont(base[(uint64_t)b * col_stride]);
+                break;
+            }
+            case D_CONST: v = consts_mont[a]; break;
+            case D_SEL: v = a == 0 ? sel0 : (a == 1 ? sel1 : sel2); break;
+            case D_ADD: v = add(my[a * NTHREADS], my[b * NTHREADS]); break;
+            case D_SUB: v = sub(my[a * NTHREADS], my[b * NTHREADS]); break;
+            case D_NEG: v = neg(my[a * NTHREADS]); break;
+            case D_MUL: v = mont_mul(my[a * NTHREADS], my[b * NTHREADS]); break;
+            default: {  // D_ASSERT
+                const uint32_t c = my[a * NTHREADS];
+                const uint32_t* ap = alpha_pows + 4 * b;
+                acc0 = add(acc0, mont_mul(c, ap[0]));
+                acc1 = add(acc1, mont_mul(c, ap[1]));
+                acc2 = add(acc2, mont_mul(c, ap[2]));
+                acc3 = add(acc3, mont_mul(c, ap[3]));
+                continue;
+            }
+        }
+        my[dst * NTHREADS] = v;
+    }
+    if (!active) return;
+    // quotient(x) = constraints(x) / Z_H(x)  (prover.rs:183); flatten + split (prover.rs:78-80):
+    // natural row i -> chunk i % qd, position i / qd; stored bit-reversed = r & (n-1)
+    const uint32_t c = bitrev32(r >> log_n, log_qd);
+    const uint32_t iz = qc.inv_zh_canonical[c];
+    const uint64_t n = 1ull << log_n;
+    uint32_t* o = out.chunk[c] + (r & (n - 1));
+    o[0] = mont_mul(acc0, iz);
+    o[n] = mont_mul(acc1, iz);
+    o[2 * n] = mont_mul(acc2, iz);
+    o[3 * n] = mont_mul(acc3, iz);
+}
+
+void launch_quotient(Context& ctx, const AirProgram& air, const ColMat& trace_lde, unsigned log_n,
+                     unsigned log_qd, const uint32_t* d_consts_mont, const uint32_t* d_alpha_pows_mont,
+                     const uint32_t* is_first, const uint32_t* is_last, const uint32_t* is_transition,
+                     const QuotOut& out) {
+    TS_REQUIRE(air.d_code != nullptr, TS_ERR_INVALID, "air program not uploaded");
+    TS_REQUIRE(log_n + log_qd <= 31, TS_ERR_INVALID, "quotient domain too large");
+    QuotConsts qc;
+    const uint32_t s_pow_n = pow_canon(GENERATOR, 1ull << log_n);
+    const uint32_t gqd = two_adic_generator(log_qd);
+    for (uint32_t c = 0; c < (1u << log_qd); c++)
+        qc.inv_zh_canonical[c] = inv_canon(sub(mul(s_pow_n, pow_canon(gqd, c)), 1));
+    const uint32_t n_instr = (uint32_t)(air.code.size() / 4);
+    const uint64_t total = 1ull << (log_n + log_qd);
+    // LDS register file: <= 48 KiB per workgroup
+    int nthreads = 256;
+    while (nthreads > 64 && (size_t)air.n_regs * nthreads * 4 > 48 * 1024) nthreads >>= 1;
+    TS_REQUIRE((size_t)air.n_regs * nthreads * 4 <= 64 * 1024, TS_ERR_UNSUPPORTED,
+               "constraint program needs too many live registers for the interpreter");
+    const size_t lds = (size_t)air.n_regs * nthreads * 4;
+    const unsigned grid = (unsigned)((total + nthreads - 1) / nthreads);
+#define TS_LAUNCH_Q(NTH)                                                                          \
+    TS_LAUNCH(ctx, k_quotient<NTH>, dim3(grid), dim3(NTH), lds, air.d_code, n_instr, \
+                       air.n_regs, trace_lde.d, trace_lde.col_stride, log_n, log_qd, d_consts_mont, \
+                       d_alpha_pows_mont, is_first, is_last, is_transition, qc, out)
+    if (nthreads == 256) TS_LAUNCH_Q(256);
+    else if (nthreads == 128) TS_LAUNCH_Q(128);
+    else TS_LAUNCH_Q(64);
+#undef TS_LAUNCH_Q
+    TS_HIP(hipGetLastError());
+}
+
+}  // namespace ts

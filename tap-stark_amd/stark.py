@@ -1,0 +1,439 @@
+"""Python binding of the host-side mirror of the reference's prover interface.
+
+The prover itself (orchestration, transcript, kernels) is C++/HIP behind the C ABI
+(include/tapstark.h); this module only gives it the reference's names so that tests and benches
+read like the reference's own:
+
+* ``FriConfig``            -- reference fri/src/config.rs:11-16
+* ``TwoAdicFriPcs``        -- reference fri/src/two_adic_pcs.rs:38-61 (commit/open on the device)
+* ``StarkConfig``          -- reference uni-stark/src/config.rs:64-101
+* ``BfChallenger``         -- reference basic/src/challenger/mod.rs:67-137
+* ``prove``                -- reference uni-stark/src/prover.rs:25-35
+* ``Proof``                -- reference uni-stark/src/proof.rs:17-37 + fri/src/proof.rs:13-33
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _lib
+from .air import BaseAir, air_tape
+
+P = 0x78000001
+TSPF_MAGIC = 0x46505354
+
+
+def _u32(a) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(a, dtype=np.uint32))
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(_lib.u32p)
+
+
+class Context:
+    """One per GPU (``ts_ctx``)."""
+
+    def __init__(self, device: int = 0):
+        self._l = _lib.lib()
+        h = C.c_void_p()
+        rc = self._l.ts_ctx_create(device, C.byref(h))
+        if rc:
+            raise _lib.TsError(rc, (self._l.ts_last_error(None) or b"").decode())
+        self.h = h
+        self.device = device
+
+    def check(self, rc: int):
+        if rc:
+            raise _lib.TsError(rc, (self._l.ts_last_error(self.h) or b"").decode())
+
+    def synchronize(self):
+        self.check(self._l.ts_ctx_synchronize(self.h))
+
+    @property
+    def stream(self) -> int:
+        return int(self._l.ts_ctx_stream(self.h) or 0)
+
+    def set_timing(self, enabled: bool):
+        self.check(self._l.ts_ctx_set_timing(self.h, int(enabled)))
+
+    def take_timings(self) -> list[tuple[str, float]]:
+        buf = C.create_string_buffer(1 << 16)
+        self.check(self._l.ts_ctx_take_timings(self.h, buf, len(buf)))
+        out = []
+        for item in buf.value.decode().split(";"):
+            if item:
+                k, v = item.rsplit("=", 1)
+                out.append((k, float(v)))
+        return out
+
+    def set_kernel_timing(self, enabled: bool):
+        self.check(self._l.ts_ctx_set_kernel_timing(self.h, int(enabled)))
+
+    def take_kernel_timings(self) -> dict[str, tuple[int, float]]:
+        """kernel name -> (launches, total ms), from HIP events on the context's stream."""
+        buf = C.create_string_buffer(1 << 16)
+        self.check(self._l.ts_ctx_take_kernel_timings(self.h, buf, len(buf)))
+        out = {}
+        for item in buf.value.decode().split(";"):
+            if item:
+                k, v = item.rsplit("=", 1)
+                cnt, ms = v.split(":")
+                out[k] = (int(cnt), float(ms))
+        return out
+
+    def close(self):
+        if self.h:
+            self._l.ts_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx: Context | None = None
+
+
+def default_context() -> Context:
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0)
+    return _default_ctx
+
+
+class DeviceMatrix:
+    """``RowMajorMatrix<Val>`` resident in HBM (``ts_matrix``)."""
+
+    def __init__(self, ctx: Context, handle):
+        self.ctx = ctx
+        self.h = handle
+
+    @classmethod
+    def upload(cls, ctx: Context, values) -> "DeviceMatrix":
+        values = _u32(values)
+        assert values.ndim == 2
+        h = C.c_void_p()
+        ctx.check(ctx._l.ts_matrix_upload(ctx.h, _p(values), values.shape[0], values.shape[1],
+                                          C.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def from_device_ptr(cls, ctx: Context, ptr: int, height: int, width: int) -> "DeviceMatrix":
+        h = C.c_void_p()
+        ctx.check(ctx._l.ts_matrix_from_device(ctx.h, C.c_void_p(ptr), height, width, C.byref(h)))
+        return cls(ctx, h)
+
+    def dims(self):
+        hh, ww = C.c_uint64(), C.c_uint32()
+        self.ctx.check(self.ctx._l.ts_matrix_dims(self.h, C.byref(hh), C.byref(ww)))
+        return int(hh.value), int(ww.value)
+
+    def download(self) -> np.ndarray:
+        hh, ww = self.dims()
+        out = np.zeros((hh, ww), dtype=np.uint32)
+        self.ctx.check(self.ctx._l.ts_matrix_download(self.ctx.h, self.h, _p(out)))
+        return out
+
+    def __del__(self):
+        try:
+            if self.h and self.ctx.h:
+                self.ctx._l.ts_matrix_free(self.ctx.h, self.h)
+        except Exception:
+            pass
+
+
+class CompiledAir:
+    def __init__(self, ctx: Context, tape):
+        self.ctx = ctx
+        self.tape = _u32(tape)
+        h = C.c_void_p()
+        ctx.check(ctx._l.ts_air_compile(ctx.h, _p(self.tape), len(self.tape), C.byref(h)))
+        self.h = h
+        w, npub, deg, lqd = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+        ctx.check(ctx._l.ts_air_info(h, C.byref(w), C.byref(npub), C.byref(deg), C.byref(lqd)))
+        self.width, self.n_public = int(w.value), int(npub.value)
+        self.max_constraint_degree, self.log_quotient_degree = int(deg.value), int(lqd.value)
+
+    def __del__(self):
+        try:
+            if self.h and self.ctx.h:
+                self.ctx._l.ts_air_free(self.ctx.h, self.h)
+        except Exception:
+            pass
+
+
+@dataclass
+class FriConfig:
+    """reference fri/src/config.rs:11-16; ``mmcs`` is the built-in Blake3 Merkle MMCS."""
+    log_blowup: int
+    num_queries: int
+    proof_of_work_bits: int
+
+    def blowup(self) -> int:
+        return 1 << self.log_blowup
+
+    def _c(self):
+        return _lib.FriConfigC(self.log_blowup, self.num_queries, self.proof_of_work_bits)
+
+
+class PcsData:
+    """``Pcs::ProverData``: committed LDEs + Merkle tree in HBM (``ts_pcs_data``)."""
+
+    def __init__(self, ctx: Context, handle, root: np.ndarray):
+        self.ctx, self.h, self.root = ctx, handle, root
+        n, lh = C.c_uint32(), C.c_uint32()
+        ctx.check(ctx._l.ts_pcs_data_info(handle, C.byref(n), C.byref(lh)))
+        self.n_mats, self.log_height = int(n.value), int(lh.value)
+
+    def lde(self, idx: int, width: int) -> np.ndarray:
+        out = np.zeros((1 << self.log_height, width), dtype=np.uint32)
+        self.ctx.check(self.ctx._l.ts_pcs_data_lde(self.ctx.h, self.h, idx, _p(out)))
+        return out
+
+    def digests(self, level: int) -> np.ndarray:
+        out = np.zeros(((1 << self.log_height) >> level, 8), dtype=np.uint32)
+        self.ctx.check(self.ctx._l.ts_pcs_data_digests(self.ctx.h, self.h, level, _p(out)))
+        return out
+
+    def open_batch(self, index: int, total_width: int):
+        rows = np.zeros(max(total_width, 1), dtype=np.uint32)
+        path = np.zeros((max(self.log_height, 1), 8), dtype=np.uint32)
+        self.ctx.check(self.ctx._l.ts_pcs_open_batch(self.ctx.h, self.h, index, _p(rows), _p(path)))
+        return rows[:total_width], path[: self.log_height]
+
+    def __del__(self):
+        try:
+            if self.h and self.ctx.h:
+                self.ctx._l.ts_pcs_data_free(self.ctx.h, self.h)
+        except Exception:
+            pass
+
+
+class TwoAdicFriPcs:
+    """reference fri/src/two_adic_pcs.rs:38-61,203-419 on the device."""
+
+    def __init__(self, fri: FriConfig, ctx: Context | None = None):
+        self.fri = fri
+        self.ctx = ctx or default_context()
+
+    def natural_domain_for_degree(self, degree: int):
+        return (degree.bit_length() - 1, 1)  # (log_n, shift), two_adic_pcs.rs:220-226
+
+    def commit(self, evaluations) -> tuple[np.ndarray, PcsData]:
+        """``evaluations``: list of ((log_n, shift), DeviceMatrix | ndarray). Matrices are consumed."""
+        ctx = self.ctx
+        mats, shifts = [], []
+        for (log_n, shift), m in evaluations:
+            if not isinstance(m, DeviceMatrix):
+                m = DeviceMatrix.upload(ctx, m)
+            assert m.dims()[0] == 1 << log_n
+            mats.append(m)
+            shifts.append(shift)
+        arr = (C.c_void_p * len(mats))(*[m.h for m in mats])
+        sh = _u32(shifts)
+        root = np.zeros(8, dtype=np.uint32)
+        h = C.c_void_p()
+        cfg = self.fri._c()
+        ctx.check(ctx._l.ts_pcs_commit(ctx.h, C.byref(cfg), len(mats), arr, _p(sh), _p(root),
+                                       C.byref(h)))
+        return root, PcsData(ctx, h, root)
+
+    def quotient_chunks(self, trace_data: PcsData, air: CompiledAir, public_values, alpha):
+        qd = 1 << air.log_quotient_degree
+        out = (C.c_void_p * qd)()
+        pis = _u32(public_values)
+        pis_p = _p(pis) if len(pis) else None
+        self.ctx.check(self.ctx._l.ts_quotient_chunks(self.ctx.h, trace_data.h, self.fri.log_blowup,
+                                                      air.h, pis_p, len(pis), _p(_u32(alpha)), out))
+        return [DeviceMatrix(self.ctx, C.c_void_p(out[c])) for c in range(qd)]
+
+    def open_reduce(self, trace_data: PcsData, quotient_data: PcsData, width: int, zeta, batch_alpha):
+        qd = quotient_data.n_mats
+        opened = np.zeros((2 * width + 4 * qd, 4), dtype=np.uint32)
+        ro = np.zeros((1 << trace_data.log_height, 4), dtype=np.uint32)
+        cfg = self.fri._c()
+        self.ctx.check(self.ctx._l.ts_pcs_open_reduce(self.ctx.h, C.byref(cfg), trace_data.h,
+                                                      quotient_data.h, _p(_u32(zeta)),
+                                                      _p(_u32(batch_alpha)), _p(opened), _p(ro)))
+        return opened, ro
+
+    def fold_matrix(self, vec, beta) -> np.ndarray:
+        vec = _u32(vec)
+        h = vec.shape[0] // 2
+        out = np.zeros((h, 4), dtype=np.uint32)
+        self.ctx.check(self.ctx._l.ts_fri_fold(self.ctx.h, _p(vec), h, _p(_u32(beta)), _p(out)))
+        return out
+
+
+@dataclass
+class StarkConfig:
+    """reference uni-stark/src/config.rs:64-101 (Challenge = EF4, Challenger = BfChallenger)."""
+    pcs: TwoAdicFriPcs
+
+
+class BfChallenger:
+    """reference basic/src/challenger/mod.rs:67-137 (host side, ``ts_challenger``)."""
+
+    def __init__(self, permutation: int = 0, sample_ext: bool = True, _handle=None):
+        self._l = _lib.lib()
+        if _handle is None:
+            h = C.c_void_p()
+            rc = self._l.ts_chal_new(permutation, int(sample_ext), C.byref(h))
+            if rc:
+                raise _lib.TsError(rc, "ts_chal_new")
+            _handle = h
+        self.h = _handle
+
+    def clone(self) -> "BfChallenger":
+        h = C.c_void_p()
+        rc = self._l.ts_chal_clone(self.h, C.byref(h))
+        if rc:
+            raise _lib.TsError(rc, "ts_chal_clone")
+        return BfChallenger(_handle=h)
+
+    def observe(self, word: int):
+        self._l.ts_chal_observe(self.h, word)
+
+    def observe_commitment(self, d):
+        self._l.ts_chal_observe_commitment(self.h, _p(_u32(d)))
+
+    def sample(self) -> np.ndarray:
+        out = np.zeros(4, dtype=np.uint32)
+        self._l.ts_chal_sample(self.h, _p(out))
+        return out
+
+    def sample_bits(self, bits: int) -> int:
+        return int(self._l.ts_chal_sample_bits(self.h, bits))
+
+    def check_witness(self, bits: int, witness: int) -> bool:
+        return bool(self._l.ts_chal_check_witness(self.h, bits, witness))
+
+    def grind(self, bits: int) -> int:
+        w = C.c_uint32()
+        rc = self._l.ts_chal_grind(self.h, bits, C.byref(w))
+        if rc:
+            raise _lib.TsError(rc, "failed to find witness")
+        return int(w.value)
+
+    def state(self) -> np.ndarray:
+        out = np.zeros(34, dtype=np.uint32)
+        self._l.ts_chal_state(self.h, _p(out))
+        return out
+
+    def __del__(self):
+        try:
+            if self.h:
+                self._l.ts_chal_free(self.h)
+        except Exception:
+            pass
+
+
+# ------------------------------------------------------------------------ Proof
+@dataclass
+class BatchOpening:
+    """reference fri/src/two_adic_pcs.rs:63-68"""
+    opened_values: list
+    opening_proof: np.ndarray
+
+
+@dataclass
+class QueryProof:
+    """reference fri/src/proof.rs:28-33"""
+    input_proof: list
+    commit_phase_openings: list
+
+
+@dataclass
+class Proof:
+    """reference uni-stark/src/proof.rs:17-37 (+ FriProof fri/src/proof.rs:13-21), parsed from
+    the TSPF v1 words the library writes; ``words`` keeps the wire form."""
+    words: np.ndarray
+    degree_bits: int = 0
+    trace_commit: np.ndarray = None
+    quotient_commit: np.ndarray = None
+    trace_local: np.ndarray = None
+    trace_next: np.ndarray = None
+    quotient_chunks: np.ndarray = None
+    commit_phase_commits: np.ndarray = None
+    query_proofs: list = field(default_factory=list)
+    final_poly: np.ndarray = None
+    pow_witness: int = 0
+
+    @classmethod
+    def parse(cls, words: np.ndarray) -> "Proof":
+        w = np.asarray(words, dtype=np.uint32)
+        pos = 0
+
+        def take(n):
+            nonlocal pos
+            out = w[pos:pos + n]
+            if len(out) != n:
+                raise ValueError("truncated proof")
+            pos += n
+            return out
+
+        magic, version, degree_bits, width, qd = (int(x) for x in take(5))
+        if magic != TSPF_MAGIC or version != 1:
+            raise ValueError("not a TSPF v1 proof")
+        pf = cls(words=w, degree_bits=degree_bits)
+        pf.trace_commit, pf.quotient_commit = take(8), take(8)
+        pf.trace_local = take(4 * width).reshape(width, 4)
+        pf.trace_next = take(4 * width).reshape(width, 4)
+        pf.quotient_chunks = take(16 * qd).reshape(qd, 4, 4)
+        R = int(take(1)[0])
+        pf.commit_phase_commits = take(8 * R).reshape(R, 8)
+        Q = int(take(1)[0])
+        for _ in range(Q):
+            nb = int(take(1)[0])
+            batches = []
+            for _ in range(nb):
+                nm = int(take(1)[0])
+                vals = [take(int(take(1)[0])) for _ in range(nm)]
+                plen = int(take(1)[0])
+                batches.append(BatchOpening(vals, take(8 * plen).reshape(plen, 8)))
+            steps = []
+            for _ in range(R):
+                vals = take(8).reshape(2, 4)
+                plen = int(take(1)[0])
+                steps.append((vals, take(8 * plen).reshape(plen, 8)))
+            pf.query_proofs.append(QueryProof(batches, steps))
+        pf.final_poly = take(4)
+        pf.pow_witness = int(take(1)[0])
+        if pos != len(w):
+            raise ValueError("trailing words in proof")
+        return pf
+
+
+def prove(config: StarkConfig, air, challenger: BfChallenger, trace, public_values) -> Proof:
+    """``uni_stark::prove`` (reference uni-stark/src/prover.rs:25-35).
+
+    ``air`` is a ``BaseAir`` (captured symbolically like ``get_symbolic_constraints``) or an
+    already ``CompiledAir``; ``trace`` an (n, w) array or a ``DeviceMatrix`` (consumed).
+    """
+    pcs = config.pcs
+    ctx = pcs.ctx
+    pis = _u32(public_values)
+    if isinstance(air, BaseAir):
+        air = CompiledAir(ctx, air_tape(air, len(pis)))
+    if not isinstance(trace, DeviceMatrix):
+        trace = DeviceMatrix.upload(ctx, trace)
+    n, w = trace.dims()
+    log_n = n.bit_length() - 1
+    log_N = log_n + pcs.fri.log_blowup
+    qd = 1 << air.log_quotient_degree
+    R = log_N - pcs.fri.log_blowup
+    Q = pcs.fri.num_queries
+    cap = (64 + 8 * w + 16 * qd + 8 * R
+           + Q * (16 + w + 5 * qd + 2 * 8 * log_N + R * (9 + 8 * log_N)))
+    out = np.zeros(cap, dtype=np.uint32)
+    n_words = C.c_size_t()
+    cfg = pcs.fri._c()
+    pis_p = _p(pis) if len(pis) else None
+    ctx.check(ctx._l.ts_prove(ctx.h, C.byref(cfg), air.h, challenger.h, trace.h, pis_p, len(pis),
+                              _p(out), cap, C.byref(n_words)))
+    return Proof.parse(out[: n_words.value].copy())

@@ -1,0 +1,241 @@
+#!/usr/bin/env python3
+"""bench.py -- trace cells/sec (and proofs/sec) of the MI355X STARK prover hot path.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one complete prove() (commit trace -> quotient -> commit chunks -> open -> FRI ->
+queries -> proof on the host) of BASELINE.json configs[2]: the build-defined SynthMulAir-64 trace,
+2^20 rows x 64 columns, log_blowup 2, 28 queries, 8 PoW bits, with the trace already resident in
+HBM when the timed region starts.  N > 1 (launched by torch.distributed.run, one rank per GPU):
+every rank proves its own independent trace -- "replicas only" this round (DESIGN.md section
+"Multi-GPU"), so scaling is weak and `value` is the aggregate over ranks.
+
+Prints ONE JSON line on rank 0 with the driver's contract fields plus:
+  roofline     -- the dominant kernel's achieved algorithmic-bytes rate from HIP events recorded
+                  around every launch on the library's own stream (a separate, untimed pass);
+  cpu_baseline -- the CPU oracle (a port: the Rust reference cannot run here) on a bounded
+                  sample of the same workload, on this box's host cores.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK = 8.0e12  # B/s, /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
+
+
+def workload(name: str, log_n: int):
+    from tapstark_amd.airs import (FibonacciAir, SynthMulAir, fibonacci_public_values,
+                                   generate_fibonacci_trace, generate_synth_mul_trace)
+    n = 1 << log_n
+    if name == "config3":
+        air = SynthMulAir(64)
+        trace = generate_synth_mul_trace(n)
+        pis = np.zeros(0, dtype=np.uint32)
+        desc = f"SynthMulAir-64 (build-defined), trace 2^{log_n}x64, log_blowup=2, 28 queries, pow 8"
+    elif name == "config2":
+        air = FibonacciAir()
+        trace = generate_fibonacci_trace(0, 1, n)
+        pis = fibonacci_public_values(trace)
+        desc = f"Fibonacci AIR, trace 2^{log_n}x2, log_blowup=2, 28 queries, pow 8"
+    else:
+        raise SystemExit(f"unknown workload {name}")
+    return air, trace, pis, desc, (2, 28, 8)
+
+
+def algorithmic_bytes_per_proof(n: int, w: int, b: int, qd: int) -> dict:
+    """Algorithmic HBM bytes per proof, per kernel (DESIGN.md "Kernels and their rooflines"):
+    each array counted once per launch that must read or write it."""
+    N = n << b
+    wall = w + 4 * qd  # every committed column (trace + quotient chunks)
+    fri_elems = 2 * N  # sum over rounds of the folded vector lengths (N + N/2 + ...)
+    return {
+        "k_transpose_bitrev": 8 * n * w,
+        "k_intt_contig": 8 * n * wall,
+        "k_intt_strided": 8 * n * wall,
+        "k_lde_fwd_strided": 4 * n * wall + 4 * N * wall,
+        "k_lde_fwd_contig": 8 * N * wall,
+        "k_leaf_hash": 4 * N * wall + 2 * 32 * N,
+        "k_leaf_hash_ef_pairs": 16 * N + 16 * N,
+        "k_merkle_level": 96 * (N + N + N // 2),
+        "k_selectors": 12 * n * qd,
+        "k_quotient<256>": 4 * n * qd * w + 12 * n * qd + 16 * n * qd,
+        "k_bary_weights": 32 * n,
+        "k_bary_sums<2>": 4 * n * w + 32 * n,
+        "k_bary_sums<1>": qd * (16 * n + 16 * n),
+        "k_reduce<2>": 4 * N * w + 16 * N,
+        "k_reduce<1>": qd * (16 * N + 32 * N),
+        "k_fri_fold_pairs": 16 * fri_elems + 8 * fri_elems + 8 * fri_elems,
+    }
+
+
+def cpu_baseline(target_seconds: float = 15.0) -> dict:
+    """The oracle prover (oracle/, a C port of the reference's algorithm) on this box's host
+    cores, on a bounded sample of the same workload."""
+    import tapstark_amd as ts
+    from oracle import oracle_py as orc
+    from tapstark_amd.airs import SynthMulAir, generate_synth_mul_trace
+
+    # the GPU box gives one GPU's share of the host (16 cores); never oversubscribe
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = int(os.environ.get("OMP_NUM_THREADS", min(avail, 16)))
+    os.environ["OMP_NUM_THREADS"] = str(cores)  # read by libgomp when the oracle is first loaded
+    air = SynthMulAir(64)
+    tape = ts.air_tape(air, 0)
+    cfg = orc.FriConfig(2, 28, 8)
+    orc.prove(cfg, tape, generate_synth_mul_trace(1 << 8), [])  # thread-pool warm-up
+    probe = 14
+    t0 = time.perf_counter()
+    orc.prove(cfg, tape, generate_synth_mul_trace(1 << probe), [], cap_words=1 << 22)
+    rate = (64 << probe) / (time.perf_counter() - t0)
+    log_n = probe
+    while log_n < 20 and (64 << (log_n + 1)) / rate < target_seconds:
+        log_n += 1
+    trace = generate_synth_mul_trace(1 << log_n)
+    t0 = time.perf_counter()
+    orc.prove(cfg, tape, trace, [], cap_words=1 << 22)
+    dt = time.perf_counter() - t0
+    return {"value": (64 << log_n) / dt, "unit": "trace cells/sec", "cores": cores, "kind": "port",
+            "sample": f"one oracle prove() of SynthMulAir-64 2^{log_n}x64, log_blowup=2, 28 queries "
+                      f"({dt:.2f} s, OpenMP over {cores} host threads)",
+            "proofs_per_sec": 1.0 / dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="config3", choices=["config3", "config2"])
+    ap.add_argument("--log-n", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist_mod
+
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist = dist_mod
+
+    import tapstark_amd as ts
+    from tapstark_amd.build import build
+
+    if not os.path.exists(ts._lib.LIB_PATH):
+        build()
+    ctx = ts.Context(local_rank)  # raises without a GPU: there is no fallback path
+
+    air, trace, pis, desc, cfg = workload(args.workload, args.log_n)
+    n, w = trace.shape
+    config = ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(*cfg), ctx))
+    cair = ts.CompiledAir(ctx, ts.air_tape(air, len(pis)))
+    qd = 1 << cair.log_quotient_degree
+
+    # inputs resident in HBM before the timed region (prove() consumes its trace, like the
+    # reference's moved RowMajorMatrix, so one copy per step)
+    total = args.warmup + args.steps
+    mats = [ts.DeviceMatrix.upload(ctx, trace) for _ in range(total)]
+
+    def barrier():
+        ctx.synchronize()
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    proofs = []
+    for i in range(args.warmup):
+        proofs.append(ts.prove(config, cair, ts.BfChallenger(), mats[i], pis))
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, total):
+        p = ts.prove(config, cair, ts.BfChallenger(), mats[i], pis)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], device=f"cuda:{local_rank}", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+    proofs_per_sec = world * args.steps / elapsed
+    cells_per_sec = proofs_per_sec * n * w
+
+    out = None
+    if rank == 0:
+        # ---- roofline leg: per-kernel HIP-event timings over 3 extra (untimed) proofs
+        reps = 3
+        extra = [ts.DeviceMatrix.upload(ctx, trace) for _ in range(reps)]
+        ctx.set_kernel_timing(True)
+        for m in extra:
+            ts.prove(config, cair, ts.BfChallenger(), m, pis)
+        kt = ctx.take_kernel_timings()
+        ctx.set_kernel_timing(False)
+        ctx.set_timing(True)
+        ts.prove(config, cair, ts.BfChallenger(), ts.DeviceMatrix.upload(ctx, trace), pis)
+        stages = ctx.take_timings()
+        ctx.set_timing(False)
+        stage_sum = {}
+        for k, v in stages:  # a stage name can occur twice (trace commit, quotient commit)
+            stage_sum[k] = round(stage_sum.get(k, 0.0) + v, 3)
+        alg =algorithmic_bytes_per_proof(n, w, cfg[0], qd)
+        per_kernel = {}
+        for name, (cnt, ms) in kt.items():
+            ms_pp = ms / reps
+            b = alg.get(name)
+            per_kernel[name] = {
+                "launches_per_proof": cnt / reps, "ms_per_proof": round(ms_pp, 4),
+                "avg_launch_ms": round(ms / cnt, 5),
+                "alg_gbps": round(b / (ms_pp * 1e-3) / 1e9, 1) if b and ms_pp > 0 else None}
+        dom = max(kt.items(), key=lambda kv: kv[1][1])[0]
+        dom_ms_pp = kt[dom][1] / reps
+        achieved = alg.get(dom, 0) / (dom_ms_pp * 1e-3)
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved / 1e9, 2),
+                    "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 4),
+                    "traffic": None,
+                    "avg_launch_ms": round(kt[dom][1] / kt[dom][0], 5),
+                    "launches_per_proof": kt[dom][0] / reps,
+                    "alg_bytes_per_proof": alg.get(dom),
+                    "kernel_ms_total_per_proof": round(sum(v[1] for v in kt.values()) / reps, 3)}
+        cpu = None if args.no_cpu_baseline else cpu_baseline()
+        out = {
+            "metric": "trace cells/sec (proofs/sec alongside), 2^20x64 BabyBear trace",
+            "value": cells_per_sec, "unit": "trace cells/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": desc, "rows": n, "width": w, "log_blowup": cfg[0],
+                       "num_queries": cfg[1], "proof_of_work_bits": cfg[2], "quotient_degree": qd,
+                       "parallelism": "1 proof per GPU (replicas)" if world > 1 else "1 GPU",
+                       "proof_words": int(len(p.words))},
+            "proofs_per_sec": proofs_per_sec,
+            "roofline": roofline, "cpu_baseline": cpu,
+            "stages_ms": stage_sum,
+            "kernels": per_kernel,
+        }
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if out is not None:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -211,12 +211,27 @@ def test_error_behaviour(ctx):
     # log_quotient_degree (1) > log_blowup (... must be >= ): two_adic_pcs.rs:256 assert
     low = ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(1, 4, 8), ctx))
     ts.prove(low, SynthMulAir(7), ts.BfChallenger(), generate_synth_mul_trace(16, 7), [])  # qd=2 fits b=1
-    with pytest.raises(TsError):  # an invalid trace makes the FRI final-poly assertion fire
-        bad = generate_fibonacci_trace(0, 1, 64)
-        bad[7, 0] += 1
-        ts.prove(config, FibonacciAir(), ts.BfChallenger(), bad, fibonacci_public_values(bad))
     with pytest.raises(TsError):  # malformed tape
         ts.CompiledAir(ctx, np.array([1, 2, 3, 4, 5, 6], dtype=np.uint32))
+
+
+def test_invalid_trace_is_caught_by_the_verifier(ctx, orc):
+    """A release build of the reference proves an invalid trace without complaint (its
+    check_constraints is debug-only, prover.rs:40-41; with quotient_degree 1 the quotient always
+    interpolates); the verifier's out-of-domain check (verifier.rs:157) must then reject."""
+    bad = generate_fibonacci_trace(0, 1, 64)
+    bad[7, 0] += 1
+    pis = fibonacci_public_values(bad)
+    config = ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(2, 6, 8), ctx))
+    proof = ts.prove(config, FibonacciAir(), ts.BfChallenger(), bad, pis)
+    tape = ts.air_tape(FibonacciAir(), 3)
+    assert orc.verify(orc.FriConfig(2, 6, 8), tape, proof.words, pis) == 7  # OodEvaluationMismatch
+    # same with quotient_degree 2: every chunk is still an honest low-degree extension of its n
+    # evaluations, so FRI passes and only the out-of-domain identity fails
+    badm = generate_synth_mul_trace(64)
+    badm[9, 2] = (int(badm[9, 2]) + 1) % P
+    proof = ts.prove(config, SynthMulAir(64), ts.BfChallenger(), badm, [])
+    assert orc.verify(orc.FriConfig(2, 6, 8), ts.air_tape(SynthMulAir(64), 0), proof.words, []) == 7
 
 
 # ------------------------------------------------------------------ BASELINE sizes: properties

@@ -27,14 +27,16 @@ constexpr uint32_t GENERATOR = 31u;
 constexpr uint32_t TWO_ADIC_GEN_27 = 0x1a427a41u;
 constexpr uint32_t EF_W = 11u;
 
+TS_HD uint32_t umin32(uint32_t a, uint32_t b) { return a < b ? a : b; }
+// a, b in [0, p): if the true result is out of range, the wrapped value is the larger one, so an
+// unsigned min picks the canonical representative (3 full-rate VALU ops, no compare/select pair)
 TS_HD uint32_t add(uint32_t a, uint32_t b) {
     uint32_t s = a + b;
-    uint32_t t = s - P;
-    return s >= P ? t : s;
+    return umin32(s, s - P);
 }
 TS_HD uint32_t sub(uint32_t a, uint32_t b) {
     uint32_t d = a - b;
-    return a >= b ? d : d + P;
+    return umin32(d, d + P);
 }
 TS_HD uint32_t neg(uint32_t a) { return a ? P - a : 0u; }
 
@@ -46,13 +48,22 @@ TS_HD uint32_t mulhi32(uint32_t a, uint32_t b) {
 #endif
 }
 
-// Montgomery reduction of t < p * 2^32: returns t * 2^-32 mod p in [0, p)
+// Montgomery reduction of t < p * 2^32: returns t * 2^-32 mod p in [0, p).
+// m = lo * p^-1 mod 2^32 with p^-1 = 2^31 + 2^27 + 1 costs two shift-adds instead of a
+// quarter-rate 32-bit multiply.
 TS_HD uint32_t mont_reduce(uint64_t t) {
-    uint32_t m = (uint32_t)t * P_INV;
+    uint32_t lo = (uint32_t)t;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // (inline asm keeps LLVM from folding the two shift-adds back into a v_mul_lo_u32)
+    uint32_t t1, m;
+    asm("v_lshl_add_u32 %0, %1, 27, %1" : "=v"(t1) : "v"(lo));
+    asm("v_lshl_add_u32 %0, %1, 31, %2" : "=v"(m) : "v"(lo), "v"(t1));
+#else
+    uint32_t m = lo + (lo << 27) + (lo << 31);
+#endif
     uint32_t u = mulhi32(m, P);
-    uint32_t hi = (uint32_t)(t >> 32);
-    uint32_t r = hi - u;
-    return hi < u ? r + P : r;
+    uint32_t r = (uint32_t)(t >> 32) - u;
+    return umin32(r, r + P);
 }
 // a * b * 2^-32 mod p.  Needs a*b < p*2^32 (true if either operand is < p).
 TS_HD uint32_t mont_mul(uint32_t a, uint32_t b) { return mont_reduce((uint64_t)a * b); }

@@ -94,4 +94,23 @@ void BfChallenger::export_state(uint32_t out[34]) const {
     for (int i = 0; i < 8; i++) out[26 + i] = i < n_out_ ? out_[i] : 0;
 }
 
+void BfChallenger::export_dev(DevChallenger& d) const {
+    memset(&d, 0, sizeof d);
+    memcpy(d.state, state_, 64);
+    d.n_in = (uint32_t)n_in_;
+    memcpy(d.in_buf, in_, 32);
+    d.n_out = (uint32_t)n_out_;
+    memcpy(d.out_buf, out_, 32);
+    d.permutation = (uint32_t)permutation_;
+    d.sample_ext = sample_ext_ ? 1u : 0u;
+}
+
+void BfChallenger::import_dev(const DevChallenger& d) {
+    memcpy(state_, d.state, 64);
+    n_in_ = (int)d.n_in;
+    memcpy(in_, d.in_buf, 32);
+    n_out_ = (int)d.n_out;
+    memcpy(out_, d.out_buf, 32);
+}
+
 }  // namespace ts

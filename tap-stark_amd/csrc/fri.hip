@@ -7,6 +7,7 @@
 // The folded vector is an array of EF4 (16 B); a fold thread produces two adjacent outputs, i.e.
 // exactly one leaf of the NEXT round's commit-phase matrix, and hashes it in the same pass.
 #include "blake3.hpp"
+#include "chal_dev.hpp"
 #include "kernels.hpp"
 
 namespace ts {
@@ -19,6 +20,8 @@ __device__ __forceinline__ void store_ef(Ef* p, Ef e) {
     *reinterpret_cast<uint4*>(p) = make_uint4(e.c[0], e.c[1], e.c[2], e.c[3]);
 }
 
+constexpr uint32_t HALF_MONT = 0x07ffffffu;  // to_mont(2^-1)
+
 // out = (lo + hi)/2 + (lo - hi) * w * (beta/2);  w = g^-bitrev(i) (Montgomery base)
 __device__ __forceinline__ Ef fold_one(Ef lo, Ef hi, uint32_t w_mont, Ef half_beta_mont,
                                        uint32_t half_mont) {
@@ -29,10 +32,12 @@ __device__ __forceinline__ Ef fold_one(Ef lo, Ef hi, uint32_t w_mont, Ef half_be
 
 __global__ void __launch_bounds__(256)
 k_fri_fold_pairs(const Ef* __restrict__ in, uint64_t h, const uint32_t* __restrict__ Winv,
-                 Ef half_beta_mont, uint32_t half_mont, Ef* __restrict__ out,
+                 const Ef* __restrict__ beta_ptr, Ef* __restrict__ out,
                  uint32_t* __restrict__ next_digests) {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;  // output pair index
     if (2 * j >= h) return;
+    const uint32_t half_mont = HALF_MONT;
+    const Ef half_beta_mont = ef_mul_base(ef_to_mont(load_ef(beta_ptr)), half_mont);
     const uint64_t i0 = 2 * j, i1 = 2 * j + 1;
     Ef a = fold_one(load_ef(in + 2 * i0), load_ef(in + 2 * i0 + 1), Winv[h + i0], half_beta_mont,
                     half_mont);
@@ -53,33 +58,39 @@ k_fri_fold_pairs(const Ef* __restrict__ in, uint64_t h, const uint32_t* __restri
 }
 
 __global__ void k_fri_fold_single(const Ef* __restrict__ in, uint64_t h,
-                                  const uint32_t* __restrict__ Winv, Ef half_beta_mont,
-                                  uint32_t half_mont, Ef* __restrict__ out) {
+                                  const uint32_t* __restrict__ Winv,
+                                  const Ef* __restrict__ beta_ptr, Ef* __restrict__ out) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= h) return;
+    const uint32_t half_mont = HALF_MONT;
+    const Ef half_beta_mont = ef_mul_base(ef_to_mont(load_ef(beta_ptr)), half_mont);
     store_ef(out + i, fold_one(load_ef(in + 2 * i), load_ef(in + 2 * i + 1), Winv[h + i],
                                half_beta_mont, half_mont));
 }
 
-void launch_fri_fold(Context& ctx, const Ef* in, uint64_t h, Ef beta, Ef* out,
-                     uint32_t* next_digests) {
+void launch_fri_fold_dev(Context& ctx, const Ef* in, uint64_t h, const Ef* d_beta, Ef* out,
+                         uint32_t* next_digests) {
     unsigned log_h = 0;
     while ((1ull << log_h) < h) log_h++;
     TS_REQUIRE((1ull << log_h) == h, TS_ERR_INVALID, "fri_fold: length not a power of two");
     ctx.ensure_twiddles(log_h + 1);
-    const uint32_t half_mont = to_mont(inv_canon(2));
-    const Ef half_beta_mont = ef_mul_base(ef_to_mont(beta), half_mont);
     if (h >= 2) {
         const uint64_t pairs = h / 2;
-        TS_LAUNCH(ctx, k_fri_fold_pairs, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0,
-                           in, h, ctx.d_twiddle_inv, half_beta_mont, half_mont, out,
-                           next_digests);
+        TS_LAUNCH(ctx, k_fri_fold_pairs, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, in, h,
+                  ctx.d_twiddle_inv, d_beta, out, next_digests);
     } else {
         TS_REQUIRE(next_digests == nullptr, TS_ERR_INVALID, "fri_fold: no next round at h = 1");
-        TS_LAUNCH(ctx, k_fri_fold_single, dim3(1), dim3(64), 0, in, h,
-                           ctx.d_twiddle_inv, half_beta_mont, half_mont, out);
+        TS_LAUNCH(ctx, k_fri_fold_single, dim3(1), dim3(64), 0, in, h, ctx.d_twiddle_inv, d_beta, out);
     }
     TS_HIP(hipGetLastError());
+}
+
+void launch_fri_fold(Context& ctx, const Ef* in, uint64_t h, Ef beta, Ef* out,
+                     uint32_t* next_digests) {
+    DevBuf<Ef> d_beta(&ctx, 1);
+    TS_HIP(hipMemcpyAsync(d_beta.p, &beta, sizeof(Ef), hipMemcpyHostToDevice, ctx.stream));
+    ctx.sync();  // `beta` is a stack temporary
+    launch_fri_fold_dev(ctx, in, h, d_beta.p, out, next_digests);
 }
 
 // acc[i] += other[i]   (reference fri/src/prover.rs:124-126)
@@ -157,6 +168,138 @@ void launch_gather_ef_pairs(Context& ctx, const Ef* vec, const uint32_t* d_indic
                             unsigned index_shift, uint32_t* out) {
     if (!n_idx) return;
     TS_LAUNCH(ctx, k_gather_ef_pairs, dim3((n_idx * 8 + 255) / 256), dim3(256), 0, reinterpret_cast<const uint32_t*>(vec), d_indices, n_idx, index_shift, out);
+    TS_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------ device-side transcript
+// One round of fri/src/prover.rs:113-116 without a host round trip: observe the root that the
+// Merkle kernels just wrote, sample beta, leave both where the host will collect them later.
+__global__ void k_chal_round(DevChallenger* __restrict__ ch, const uint32_t* __restrict__ root,
+                             uint32_t* __restrict__ root_out, Ef* __restrict__ beta_out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    uint32_t r[8];
+    for (int i = 0; i < 8; i++) {
+        r[i] = root[i];
+        root_out[i] = r[i];
+    }
+    Ef beta = dc_observe_root_and_sample(ch, r);
+    store_ef(beta_out, beta);
+}
+void launch_chal_round(Context& ctx, DevChallenger* ch, const uint32_t* root, uint32_t* root_out,
+                       Ef* beta_out) {
+    TS_LAUNCH(ctx, k_chal_round, dim3(1), dim3(64), 0, ch, root, root_out, beta_out);
+    TS_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------ FRI tail
+// Every remaining round of bf_commit_phase (fri/src/prover.rs:111-127) once the folded vector has
+// at most 2^FRI_TAIL_LOG elements, in ONE workgroup: commit (leaf hashes + tree in LDS, also
+// written to the tail arenas for the query phase), observe/sample on the device challenger, fold.
+// Arena layout for tail round t (vector length L_t = L0 >> t): vector at sum_{j<t} L_j (in Ef),
+// tree (L_t - 1 digests, leaves first) at sum_{j<t} (L_j - 1) (in digests).
+constexpr int TAIL_NT = 512;
+constexpr int TAIL_MAX = 1 << FRI_TAIL_LOG;
+
+__global__ void __launch_bounds__(TAIL_NT)
+k_fri_tail(const Ef* __restrict__ in, uint32_t L0, uint32_t blowup, DevChallenger* __restrict__ ch,
+           const uint32_t* __restrict__ Winv, Ef* __restrict__ tail_vecs,
+           uint32_t* __restrict__ tail_trees, uint32_t* __restrict__ roots_out,
+           Ef* __restrict__ betas_out, Ef* __restrict__ final_out) {
+    __shared__ Ef bufA[TAIL_MAX];
+    __shared__ Ef bufB[TAIL_MAX / 2];
+    __shared__ uint32_t digA[8 * (TAIL_MAX / 2)];
+    __shared__ uint32_t digB[8 * (TAIL_MAX / 4)];
+    __shared__ Ef s_beta;
+    Ef* cur = bufA;
+    Ef* nxt = bufB;
+    for (uint32_t i = threadIdx.x; i < L0; i += TAIL_NT) cur[i] = load_ef(in + i);
+    __syncthreads();
+    uint32_t L = L0, voff = 0, toff = 0, t = 0;
+    while (L > blowup) {
+        const uint32_t h = L >> 1;
+        for (uint32_t i = threadIdx.x; i < L; i += TAIL_NT) store_ef(tail_vecs + voff + i, cur[i]);
+        // leaves: rows (cur[2i], cur[2i+1])
+        for (uint32_t i = threadIdx.x; i < h; i += TAIL_NT) {
+            const Ef a = cur[2 * i], b = cur[2 * i + 1];
+            uint32_t m[16] = {a.c[0], a.c[1], a.c[2], a.c[3], b.c[0], b.c[1], b.c[2], b.c[3],
+                              0, 0, 0, 0, 0, 0, 0, 0};
+            uint32_t cv[8];
+            b3::iv(cv);
+            b3::compress(cv, m, 32, b3::CHUNK_START | b3::CHUNK_END | b3::ROOT);
+            uint32_t* o = tail_trees + 8 * (uint64_t)(toff + i);
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                o[k] = cv[k];
+                digA[k * (TAIL_MAX / 2) + i] = cv[k];
+            }
+        }
+        __syncthreads();
+        uint32_t* src = digA;
+        uint32_t src_stride = TAIL_MAX / 2;
+        uint32_t n = h, lvl_off = toff, lvl = 0;
+        while (n > 1) {
+            const uint32_t n_par = n >> 1;
+            uint32_t* dst = (lvl & 1) ? digA : digB;
+            const uint32_t dst_stride = (lvl & 1) ? TAIL_MAX / 2 : TAIL_MAX / 4;
+            for (uint32_t i = threadIdx.x; i < n_par; i += TAIL_NT) {
+                uint32_t m[16];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    m[k] = src[k * src_stride + 2 * i];
+                    m[8 + k] = src[k * src_stride + 2 * i + 1];
+                }
+                uint32_t cv[8];
+                b3::hash64(m, cv);
+                uint32_t* o = tail_trees + 8 * (uint64_t)(lvl_off + n + i);
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    o[k] = cv[k];
+                    dst[k * dst_stride + i] = cv[k];
+                }
+            }
+            __syncthreads();
+            src = dst;
+            src_stride = dst_stride;
+            lvl_off += n;
+            n = n_par;
+            lvl++;
+        }
+        if (threadIdx.x == 0) {
+            uint32_t root[8];
+            for (int k = 0; k < 8; k++) {
+                root[k] = src[k * src_stride];
+                roots_out[8 * t + k] = root[k];
+            }
+            const Ef beta = dc_observe_root_and_sample(ch, root);
+            s_beta = beta;
+            store_ef(betas_out + t, beta);
+        }
+        __syncthreads();
+        const Ef half_beta_mont = ef_mul_base(ef_to_mont(s_beta), HALF_MONT);
+        for (uint32_t i = threadIdx.x; i < h; i += TAIL_NT)
+            nxt[i] = fold_one(cur[2 * i], cur[2 * i + 1], Winv[h + i], half_beta_mont, HALF_MONT);
+        __syncthreads();
+        Ef* tmp = cur;
+        cur = nxt;
+        nxt = tmp;
+        voff += L;
+        toff += L - 1;
+        L = h;
+        t++;
+    }
+    for (uint32_t i = threadIdx.x; i < L; i += TAIL_NT) store_ef(final_out + i, cur[i]);
+}
+
+void launch_fri_tail(Context& ctx, const Ef* in, uint32_t L0, uint32_t blowup, DevChallenger* ch,
+                     Ef* tail_vecs, uint32_t* tail_trees, uint32_t* roots_out, Ef* betas_out,
+                     Ef* final_out) {
+    TS_REQUIRE(L0 <= (uint32_t)TAIL_MAX && L0 >= 1, TS_ERR_INVALID, "fri_tail: vector too long");
+    unsigned log_l = 0;
+    while ((1u << log_l) < L0) log_l++;
+    ctx.ensure_twiddles(log_l == 0 ? 1 : log_l);
+    TS_LAUNCH(ctx, k_fri_tail, dim3(1), dim3(TAIL_NT), 0, in, L0, blowup, ch,
+              (const uint32_t*)ctx.d_twiddle_inv, tail_vecs, tail_trees, roots_out, betas_out,
+              final_out);
     TS_HIP(hipGetLastError());
 }
 

@@ -10,6 +10,7 @@
 
 #include "air.hpp"
 #include "bb.hpp"
+#include "chal_dev.hpp"
 #include "context.hpp"
 #include "kernels.hpp"
 
@@ -32,6 +33,9 @@ public:
     bool check_witness(unsigned bits, uint32_t witness);  // mod.rs:108-114
     uint32_t grind(unsigned bits);                 // mod.rs:95-105 (throws TS_ERR_INVARIANT)
     void export_state(uint32_t out[34]) const;
+    // hand the transcript to the device for the FRI commit phase, and take it back
+    void export_dev(DevChallenger& d) const;
+    void import_dev(const DevChallenger& d);
 
 private:
     void duplexing();  // mod.rs:151-174

@@ -17,6 +17,10 @@ struct ColMat {
 
 // ---- ntt.hip ---------------------------------------------------------------------------------
 void launch_build_twiddles(Context& ctx, uint32_t* W, uint32_t* Winv, unsigned log_size);
+// per-coset scale tables: lo[beta][j] = s_beta^j * scale (j < 1024), hi[beta][j] = s_beta^(1024 j)
+void launch_build_shift_tables(Context& ctx, uint32_t* lo, uint32_t* hi, uint32_t n_hi,
+                               uint32_t n_cosets, uint32_t shift_mont, unsigned log_N,
+                               unsigned log_blowup, uint32_t scale_mont);
 // src: row-major n x w (natural rows)  ->  dst: column-major, rows in bit-reversed order
 void launch_transpose_bitrev(Context& ctx, const uint32_t* src, uint32_t* dst, unsigned log_n,
                              uint32_t w, uint64_t dst_col_stride);
@@ -90,6 +94,18 @@ void launch_reduce(Context& ctx, const ColMat& m, unsigned log_h, const uint32_t
 // If next_digests != nullptr (h >= 2) also writes the h/2 leaf digests of the next round.
 void launch_fri_fold(Context& ctx, const Ef* in, uint64_t h, Ef beta_canonical, Ef* out,
                      uint32_t* next_digests);
+// same with beta read from device memory (written by launch_chal_round)
+void launch_fri_fold_dev(Context& ctx, const Ef* in, uint64_t h, const Ef* d_beta, Ef* out,
+                         uint32_t* next_digests);
+// device-resident transcript (chal_dev.hpp): observe the root at `root`, sample beta
+struct DevChallenger;
+void launch_chal_round(Context& ctx, DevChallenger* ch, const uint32_t* root, uint32_t* root_out,
+                       Ef* beta_out);
+// all remaining commit-phase rounds once the vector has <= 2^FRI_TAIL_LOG elements, one workgroup
+constexpr int FRI_TAIL_LOG = 10;
+void launch_fri_tail(Context& ctx, const Ef* in, uint32_t L0, uint32_t blowup, DevChallenger* ch,
+                     Ef* tail_vecs, uint32_t* tail_trees, uint32_t* roots_out, Ef* betas_out,
+                     Ef* final_out);
 void launch_vec_add(Context& ctx, Ef* acc, const Ef* other, uint64_t n);
 // gathers: rows of column-major matrices and Merkle paths at given indices
 void launch_gather_rows(Context& ctx, const LeafMats& mats, const uint32_t* d_indices,

@@ -113,20 +113,77 @@ k_merkle_top(uint32_t* __restrict__ tree, unsigned log_leaves, unsigned first_le
     }
 }
 
-void launch_merkle_levels(Context& ctx, uint32_t* tree, unsigned log_leaves) {
+// A workgroup reduces a subtree of S = 2^log_s consecutive nodes of level `first_level` to its
+// root (log_s levels), storing every intermediate level in the tree.  Between levels the digests
+// stay in LDS, word-interleaved ([word][node]) so that reads and writes are bank-conflict free.
+constexpr int SUBTREE_LOG = 11;  // 2048 children per workgroup
+template <int NTH>
+__global__ void __launch_bounds__(NTH)
+k_merkle_subtree(uint32_t* __restrict__ tree, unsigned log_leaves, unsigned first_level,
+                 unsigned log_s, unsigned n_levels) {
+    __shared__ uint32_t bufA[8 * (1 << (SUBTREE_LOG - 1))];
+    __shared__ uint32_t bufB[8 * (1 << (SUBTREE_LOG - 2))];
     uint64_t off = 0;
-    unsigned l = 0;
-    for (; l < log_leaves; l++) {
-        uint64_t n_children = (uint64_t)1 << (log_leaves - l);
-        if (n_children <= 512) break;
-        uint64_t n_parents = n_children / 2;
-        TS_LAUNCH(ctx, k_merkle_level, dim3((unsigned)((n_parents + 255) / 256)), dim3(256), 0,
-                           reinterpret_cast<const uint4*>(tree + 8 * off),
-                           reinterpret_cast<uint4*>(tree + 8 * (off + n_children)), n_parents);
-        off += n_children;
+    for (unsigned l = 0; l < first_level; l++) off += (uint64_t)1 << (log_leaves - l);
+    uint64_t n_level = (uint64_t)1 << (log_leaves - first_level);  // nodes in the current level
+    const uint32_t S = 1u << log_s;
+    uint64_t sub0 = (uint64_t)blockIdx.x * S;  // first node of this subtree in the current level
+    uint32_t* src = nullptr;                   // LDS source (nullptr: read level from global)
+    uint32_t src_stride = 0;
+    for (unsigned l = 0; l < n_levels; l++) {
+        const uint32_t n_par = S >> (l + 1);
+        uint32_t* dst = (l & 1) ? bufB : bufA;
+        const uint32_t dst_stride = (l & 1) ? (1u << (SUBTREE_LOG - 2)) : (1u << (SUBTREE_LOG - 1));
+        const uint64_t par_off = off + n_level;  // next level's offset in the tree
+        for (uint32_t i = threadIdx.x; i < n_par; i += NTH) {
+            uint32_t m[16];
+            if (src == nullptr) {
+                const uint4* ch = reinterpret_cast<const uint4*>(tree + 8 * (off + sub0 + 2 * (uint64_t)i));
+                uint4 a = ch[0], b = ch[1], c = ch[2], d = ch[3];
+                m[0] = a.x; m[1] = a.y; m[2] = a.z; m[3] = a.w;
+                m[4] = b.x; m[5] = b.y; m[6] = b.z; m[7] = b.w;
+                m[8] = c.x; m[9] = c.y; m[10] = c.z; m[11] = c.w;
+                m[12] = d.x; m[13] = d.y; m[14] = d.z; m[15] = d.w;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    m[k] = src[k * src_stride + 2 * i];
+                    m[8 + k] = src[k * src_stride + 2 * i + 1];
+                }
+            }
+            uint32_t cv[8];
+            b3::hash64(m, cv);
+            uint4* o = reinterpret_cast<uint4*>(tree + 8 * (par_off + (sub0 >> 1) + i));
+            o[0] = make_uint4(cv[0], cv[1], cv[2], cv[3]);
+            o[1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
+#pragma unroll
+            for (int k = 0; k < 8; k++) dst[k * dst_stride + i] = cv[k];
+        }
+        __syncthreads();
+        src = dst;
+        src_stride = dst_stride;
+        off = par_off;
+        n_level >>= 1;
+        sub0 >>= 1;
     }
-    if (l < log_leaves)
-        TS_LAUNCH(ctx, k_merkle_top, dim3(1), dim3(256), 0, tree, log_leaves, l);
+}
+
+// Big levels: 2048 children per 256-thread workgroup, 3 levels per launch (4, 2, 1 compressions per
+// thread: every lane busy).  Once <= 2048 nodes remain, one 1024-thread workgroup finishes the tree.
+void launch_merkle_levels(Context& ctx, uint32_t* tree, unsigned log_leaves) {
+    unsigned level = 0;
+    while (log_leaves - level > (unsigned)SUBTREE_LOG) {
+        const unsigned remaining = log_leaves - level;
+        const uint64_t n_sub = (uint64_t)1 << (remaining - SUBTREE_LOG);
+        TS_LAUNCH(ctx, k_merkle_subtree<256>, dim3((unsigned)n_sub), dim3(256), 0, tree, log_leaves,
+                  level, (unsigned)SUBTREE_LOG, 3u);
+        level += 3;
+    }
+    if (level < log_leaves) {
+        const unsigned remaining = log_leaves - level;
+        TS_LAUNCH(ctx, k_merkle_subtree<1024>, dim3(1), dim3(1024), 0, tree, log_leaves, level,
+                  remaining, remaining);
+    }
     TS_HIP(hipGetLastError());
 }
 

@@ -1,0 +1,316 @@
+// Coset LDE kernels (see the header of ntt.hip for the block-twiddle formulation).
+//
+// Execution: up to 4 stages at a time are done in registers (a thread owns the 16 elements of a
+// radix-16 group), with one LDS exchange between such rounds; the LDS image is padded by one word
+// per 16 so that every round's access pattern is bank-conflict free.  Three kernels:
+//   k_intt_contig    stages log_n-1 .. sA of the inverse on 4096-element chunks   (only n > 4096)
+//   k_lde_mid        the strided stages of the inverse (sA-1 .. 0), then for every coset: scale
+//                    coefficient k by s_beta^k / n and run the strided stages of the forward
+//                    transform, writing coset block beta -- the coefficients never touch HBM
+//   k_lde_fwd_contig stages sA .. log_n-1 of the forward transform, in place on 4096-element chunks
+// For n <= 4096 k_lde_mid alone does everything.
+#include "kernels.hpp"
+
+namespace ts {
+
+constexpr int LOG_M = 12;          // contiguous chunk = 4096 elements
+constexpr int CHUNK = 1 << LOG_M;
+constexpr int NT = 256;            // threads per workgroup, contiguous kernels
+constexpr int NT_MID = 512;        // threads per workgroup, middle kernel
+constexpr int TILE_ELEMS = 8192;   // strided tile
+constexpr int SHIFT_LO_BITS = 10;  // coset scale s^k = hi[k >> 10] * lo[k & 1023]
+
+__device__ __forceinline__ uint32_t pad(uint32_t i) { return i + (i >> 4); }
+constexpr int padded(int n) { return n + (n >> 4); }
+
+// The LDS image `s` (padded) holds 2^log_total elements: a transform of 2^log_len points whose
+// element e occupies the 2^log_T consecutive slots [e << log_T, (e+1) << log_T) (log_T = 0 for a
+// contiguous chunk; for a strided tile the 2^log_T slots are independent side-by-side transforms
+// that share their twiddles).  Local stage u (distance 2^(log_total-1-u) slots) is global stage
+// s_base + u, whose block `blk` uses W[2^(s_base+u) + (c << u) + blk].
+//
+// One round = K consecutive stages u0 .. u0+K-1 on register groups of 2^K elements spaced by the
+// distance 2^log_dl of the round's last stage.  LOG_DL >= 0 fixes that distance at compile time
+// (LDS addresses become base + immediate offsets); LOG_DL = -1 takes it from the arguments.
+template <int K, bool INV, int LOG_DL, int NTH>
+__device__ __forceinline__ void radix_round(uint32_t* s, unsigned log_total, unsigned u0,
+                                            unsigned s_base, uint32_t c,
+                                            const uint32_t* __restrict__ W) {
+    constexpr int R = 1 << K;
+    const unsigned log_dl = LOG_DL >= 0 ? (unsigned)LOG_DL : log_total - u0 - K;
+    const uint32_t n_groups = 1u << (log_total - K);
+    for (uint32_t g = threadIdx.x; g < n_groups; g += NTH) {
+        const uint32_t lo = g & ((1u << log_dl) - 1);
+        const uint32_t hi = g >> log_dl;  // block index at stage u0
+        const uint32_t base = (hi << (K + log_dl)) + lo;
+        const uint32_t pbase = pad(base);
+        uint32_t addr[R];
+#pragma unroll
+        for (int q = 0; q < R; q++) {
+            if (LOG_DL >= 4)
+                addr[q] = pbase + (uint32_t)q * ((1u << (LOG_DL >= 4 ? LOG_DL : 4)) +
+                                                 (1u << (LOG_DL >= 4 ? LOG_DL - 4 : 0)));
+            else if (LOG_DL == 0 && K == 4)
+                addr[q] = pbase + (uint32_t)q;
+            else
+                addr[q] = pad(base + ((uint32_t)q << log_dl));
+        }
+        uint32_t v[R];
+#pragma unroll
+        for (int q = 0; q < R; q++) v[q] = s[addr[q]];
+        if (!INV) {
+#pragma unroll
+            for (int d = 0; d < K; d++) {
+                const int half = R >> (d + 1);
+                const uint32_t wb = (1u << (s_base + u0 + d)) + (c << (u0 + d)) + (hi << d);
+#pragma unroll
+                for (int q = 0; q < R; q++) {
+                    if ((q & half) == 0) {
+                        const uint32_t w = W[wb + (q >> (K - d))];
+                        const uint32_t a = v[q], t = mont_mul(v[q + half], w);
+                        v[q] = add(a, t);
+                        v[q + half] = sub(a, t);
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int d = K - 1; d >= 0; d--) {
+                const int half = R >> (d + 1);
+                const uint32_t wb = (1u << (s_base + u0 + d)) + (c << (u0 + d)) + (hi << d);
+#pragma unroll
+                for (int q = 0; q < R; q++) {
+                    if ((q & half) == 0) {
+                        const uint32_t w = W[wb + (q >> (K - d))];
+                        const uint32_t a = v[q], b = v[q + half];
+                        v[q] = add(a, b);
+                        v[q + half] = mont_mul(sub(a, b), w);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < R; q++) s[addr[q]] = v[q];
+    }
+    __syncthreads();
+}
+
+template <bool INV, int NTH>
+__device__ __forceinline__ void radix_round_rt(int k, uint32_t* s, unsigned log_total, unsigned u0,
+                                               unsigned s_base, uint32_t c,
+                                               const uint32_t* __restrict__ W) {
+    switch (k) {
+        case 4: radix_round<4, INV, -1, NTH>(s, log_total, u0, s_base, c, W); break;
+        case 3: radix_round<3, INV, -1, NTH>(s, log_total, u0, s_base, c, W); break;
+        case 2: radix_round<2, INV, -1, NTH>(s, log_total, u0, s_base, c, W); break;
+        default: radix_round<1, INV, -1, NTH>(s, log_total, u0, s_base, c, W); break;
+    }
+}
+
+// Generic plan: log_len stages in ceil(log_len/4) rounds of nearly equal size (10 = 4+3+3): the
+// first `rem` rounds take q+1 stages, the others q.
+template <int NTH>
+__device__ __forceinline__ void tile_forward_rt(uint32_t* s, unsigned log_len, unsigned log_T,
+                                                unsigned s_base, uint32_t c,
+                                                const uint32_t* __restrict__ W) {
+    if (log_len == 0) return;
+    const unsigned nr = (log_len + 3) / 4, q = log_len / nr, rem = log_len % nr;
+    unsigned u = 0;
+    for (unsigned r = 0; r < nr; r++) {
+        const unsigned k = q + (r < rem ? 1u : 0u);
+        radix_round_rt<false, NTH>((int)k, s, log_len + log_T, u, s_base, c, W);
+        u += k;
+    }
+}
+template <int NTH>
+__device__ __forceinline__ void tile_inverse_rt(uint32_t* s, unsigned log_len, unsigned log_T,
+                                                unsigned s_base, uint32_t c,
+                                                const uint32_t* __restrict__ Winv) {
+    if (log_len == 0) return;
+    const unsigned nr = (log_len + 3) / 4, q = log_len / nr, rem = log_len % nr;
+    unsigned u = log_len;
+    for (int r = (int)nr - 1; r >= 0; r--) {
+        const unsigned k = q + ((unsigned)r < rem ? 1u : 0u);
+        u -= k;
+        radix_round_rt<true, NTH>((int)k, s, log_len + log_T, u, s_base, c, Winv);
+    }
+}
+
+// ------------------------------------------------------------------ contiguous passes (static plan)
+// 4096-element chunk, 12 stages = 3 radix-16 rounds with last-stage distances 256, 16, 1.
+__device__ __forceinline__ void chunk_load(uint32_t* s, const uint32_t* __restrict__ g) {
+    const uint4* g4 = reinterpret_cast<const uint4*>(g);
+#pragma unroll
+    for (int k = 0; k < CHUNK / 4 / NT; k++) {
+        const uint32_t i4 = threadIdx.x + (uint32_t)k * NT;
+        const uint4 v = g4[i4];
+        const uint32_t a = 4 * i4 + (i4 >> 2);  // pad(4*i4); the 4 words stay inside one 16-group
+        s[a] = v.x;
+        s[a + 1] = v.y;
+        s[a + 2] = v.z;
+        s[a + 3] = v.w;
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ void chunk_store(const uint32_t* s, uint32_t* __restrict__ g) {
+    uint4* g4 = reinterpret_cast<uint4*>(g);
+#pragma unroll
+    for (int k = 0; k < CHUNK / 4 / NT; k++) {
+        const uint32_t i4 = threadIdx.x + (uint32_t)k * NT;
+        const uint32_t a = 4 * i4 + (i4 >> 2);
+        g4[i4] = make_uint4(s[a], s[a + 1], s[a + 2], s[a + 3]);
+    }
+}
+
+// chunk `c` of column blockIdx.y: global stages log_n-1 .. log_n-12 of the inverse (n > 4096)
+__global__ void __launch_bounds__(NT)
+k_intt_contig(uint32_t* __restrict__ data, uint64_t col_stride, unsigned log_n,
+              const uint32_t* __restrict__ Winv) {
+    __shared__ uint32_t s[padded(CHUNK)];
+    const uint32_t c = blockIdx.x;
+    uint32_t* g = data + (uint64_t)blockIdx.y * col_stride + ((uint64_t)c << LOG_M);
+    chunk_load(s, g);
+    const unsigned sb = log_n - LOG_M;
+    radix_round<4, true, 0, NT>(s, LOG_M, 8, sb, c, Winv);
+    radix_round<4, true, 4, NT>(s, LOG_M, 4, sb, c, Winv);
+    radix_round<4, true, 8, NT>(s, LOG_M, 0, sb, c, Winv);
+    chunk_store(s, g);
+}
+
+// in place on chunk `c` of coset block `beta` of column blockIdx.y: forward stages sA .. log_n-1
+__global__ void __launch_bounds__(NT)
+k_lde_fwd_contig(uint32_t* __restrict__ out, uint64_t out_col_stride, unsigned log_n,
+                 const uint32_t* __restrict__ W) {
+    __shared__ uint32_t s[padded(CHUNK)];
+    const uint32_t c = blockIdx.x;
+    const uint32_t beta = blockIdx.z;
+    uint32_t* o = out + (uint64_t)blockIdx.y * out_col_stride + ((uint64_t)beta << log_n) +
+                  ((uint64_t)c << LOG_M);
+    chunk_load(s, o);
+    const unsigned sb = log_n - LOG_M;
+    radix_round<4, false, 8, NT>(s, LOG_M, 0, sb, c, W);
+    radix_round<4, false, 4, NT>(s, LOG_M, 4, sb, c, W);
+    radix_round<4, false, 0, NT>(s, LOG_M, 8, sb, c, W);
+    chunk_store(s, o);
+}
+
+// ------------------------------------------------------------------ middle kernel
+// Tile = slots {row << row_shift + j2_0 + jj : row < 2^log_len, jj < 2^log_T} of one column
+// (row_shift = LOG_M for n > 4096, where rows are 4096 apart; 0 for n <= 4096 with log_T = 0, where
+// the tile is the whole column).  Finishes the inverse transform (stages log_len-1 .. 0), then for
+// each coset: scaled copy -> forward stages 0 .. log_len-1 -> block beta of `out`.
+// PLAN 0: generic (runtime round plan).  PLAN 1: log_len = 8, log_T = 5 (n = 2^20): two radix-16
+// rounds with compile-time distances 2^9 and 2^5.
+template <int PLAN>
+__global__ void __launch_bounds__(NT_MID)
+k_lde_mid(const uint32_t* __restrict__ evals, uint64_t in_col_stride, uint32_t* __restrict__ out,
+          uint64_t out_col_stride, unsigned log_n, unsigned log_len, unsigned log_T,
+          unsigned row_shift, unsigned n_cosets, const uint32_t* __restrict__ W,
+          const uint32_t* __restrict__ Winv, const uint32_t* __restrict__ lo,
+          const uint32_t* __restrict__ hi, uint32_t n_hi) {
+    __shared__ uint32_t s[padded(TILE_ELEMS)];
+    constexpr int PER_THREAD = TILE_ELEMS / NT_MID;
+    if (PLAN == 1) {
+        log_len = 8;
+        log_T = 5;
+    }
+    const uint32_t j2_0 = blockIdx.x << log_T;
+    const uint32_t* g = evals + (uint64_t)blockIdx.y * in_col_stride + j2_0;
+    const uint32_t total = 1u << (log_len + log_T);
+    const uint32_t tmask = (1u << log_T) - 1;
+    for (uint32_t i = threadIdx.x; i < total; i += NT_MID)
+        s[pad(i)] = g[((uint64_t)(i >> log_T) << row_shift) + (i & tmask)];
+    __syncthreads();
+    if (PLAN == 1) {
+        radix_round<4, true, 5, NT_MID>(s, 13, 4, 0, 0, Winv);
+        radix_round<4, true, 9, NT_MID>(s, 13, 0, 0, 0, Winv);
+    } else {
+        tile_inverse_rt<NT_MID>(s, log_len, log_T, 0, 0, Winv);
+    }
+    // natural-order coefficients (times n): keep this thread's share in registers
+    uint32_t coef[PER_THREAD];
+#pragma unroll
+    for (int k = 0; k < PER_THREAD; k++) {
+        const uint32_t i = threadIdx.x + (uint32_t)k * NT_MID;
+        coef[k] = i < total ? s[pad(i)] : 0u;
+    }
+    for (uint32_t beta = 0; beta < n_cosets; beta++) {
+        const uint32_t* lo_b = lo + ((uint64_t)beta << SHIFT_LO_BITS);
+        const uint32_t* hi_b = hi + (uint64_t)beta * n_hi;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < PER_THREAD; k++) {
+            const uint32_t i = threadIdx.x + (uint32_t)k * NT_MID;
+            if (i < total) {
+                // coefficient index of this slot
+                const uint32_t kk = ((i >> log_T) << row_shift) + (i & tmask) + j2_0;
+                uint32_t v = mont_mul(coef[k], lo_b[kk & ((1u << SHIFT_LO_BITS) - 1)]);
+                s[pad(i)] = mont_mul(v, hi_b[kk >> SHIFT_LO_BITS]);
+            }
+        }
+        __syncthreads();
+        if (PLAN == 1) {
+            radix_round<4, false, 9, NT_MID>(s, 13, 0, 0, 0, W);
+            radix_round<4, false, 5, NT_MID>(s, 13, 4, 0, 0, W);
+        } else {
+            tile_forward_rt<NT_MID>(s, log_len, log_T, 0, 0, W);
+        }
+        uint32_t* o = out + (uint64_t)blockIdx.y * out_col_stride + ((uint64_t)beta << log_n) + j2_0;
+        for (uint32_t i = threadIdx.x; i < total; i += NT_MID)
+            o[((uint64_t)(i >> log_T) << row_shift) + (i & tmask)] = s[pad(i)];
+    }
+}
+
+// ------------------------------------------------------------------ host driver
+void coset_lde(Context& ctx, uint32_t* evals, uint64_t in_col_stride, uint32_t ncols, unsigned log_n,
+               unsigned log_blowup, uint32_t shift, uint32_t* out, uint64_t out_col_stride) {
+    TS_REQUIRE(log_n + log_blowup <= 27, TS_ERR_INVALID, "coset_lde: log_n + log_blowup > 27");
+    TS_REQUIRE(ncols >= 1 && ncols <= 65535, TS_ERR_INVALID, "coset_lde: bad column count");
+    const bool two_pass = log_n > (unsigned)LOG_M;
+    const unsigned sA = two_pass ? log_n - LOG_M : 0;  // stages done by the strided (middle) kernel
+    TS_REQUIRE((1u << sA) <= (unsigned)TILE_ELEMS, TS_ERR_UNSUPPORTED,
+               "coset_lde: trace longer than 2^25 rows is not supported yet");
+    ctx.ensure_twiddles(log_n == 0 ? 1 : log_n);
+    const uint32_t* W = ctx.d_twiddle_fwd;
+    const uint32_t* Winv = ctx.d_twiddle_inv;
+    const uint64_t n = 1ull << log_n;
+    const uint32_t n_inv_mont = to_mont(inv_canon((uint32_t)(n % P)));
+    unsigned log_T = 0;
+    if (two_pass) {
+        while ((1u << (sA + log_T + 1)) <= (unsigned)TILE_ELEMS && log_T < 6) log_T++;
+    }
+
+    // per-coset scale tables s_beta^k / n
+    const uint32_t n_cosets = 1u << log_blowup;
+    const uint32_t n_lo = 1u << SHIFT_LO_BITS;
+    const uint32_t n_hi = log_n > (unsigned)SHIFT_LO_BITS ? 1u << (log_n - SHIFT_LO_BITS) : 1u;
+    DevBuf<uint32_t> lo(&ctx, (size_t)n_cosets * n_lo), hi(&ctx, (size_t)n_cosets * n_hi);
+    launch_build_shift_tables(ctx, lo.p, hi.p, n_hi, n_cosets, to_mont(shift), log_n + log_blowup,
+                              log_blowup, n_inv_mont);
+
+    if (two_pass) {
+        // the vectorised chunk loads need 16-byte aligned columns
+        TS_REQUIRE(in_col_stride % 4 == 0 && out_col_stride % 4 == 0, TS_ERR_INVALID,
+                   "coset_lde: column strides must be multiples of 4 elements");
+        TS_LAUNCH(ctx, k_intt_contig, dim3(1u << sA, ncols), dim3(NT), 0, evals, in_col_stride, log_n,
+                  Winv);
+        const dim3 grid(1u << (LOG_M - log_T), ncols);
+        if (sA == 8 && log_T == 5)
+            TS_LAUNCH(ctx, k_lde_mid<1>, grid, dim3(NT_MID), 0, (const uint32_t*)evals, in_col_stride,
+                      out, out_col_stride, log_n, sA, log_T, (unsigned)LOG_M, n_cosets, W, Winv,
+                      (const uint32_t*)lo.p, (const uint32_t*)hi.p, n_hi);
+        else
+            TS_LAUNCH(ctx, k_lde_mid<0>, grid, dim3(NT_MID), 0, (const uint32_t*)evals, in_col_stride,
+                      out, out_col_stride, log_n, sA, log_T, (unsigned)LOG_M, n_cosets, W, Winv,
+                      (const uint32_t*)lo.p, (const uint32_t*)hi.p, n_hi);
+        TS_LAUNCH(ctx, k_lde_fwd_contig, dim3(1u << sA, ncols, n_cosets), dim3(NT), 0, out,
+                  out_col_stride, log_n, W);
+    } else {
+        TS_LAUNCH(ctx, k_lde_mid<0>, dim3(1, ncols), dim3(NT_MID), 0, (const uint32_t*)evals,
+                  in_col_stride, out, out_col_stride, log_n, log_n, 0u, 0u, n_cosets, W, Winv,
+                  (const uint32_t*)lo.p, (const uint32_t*)hi.p, n_hi);
+    }
+    TS_HIP(hipGetLastError());
+}
+
+}  // namespace ts

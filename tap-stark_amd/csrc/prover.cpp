@@ -295,8 +295,8 @@ void TwoAdicFriPcs::open_batch(const PcsData& d, uint64_t index, std::vector<uin
 namespace {
 
 struct FriRound {
-    DevBuf<Ef> vec;          // committed vector (rows of two): length 2 * 2^log_leaves
-    DevBuf<uint32_t> tree;
+    const Ef* vec = nullptr;        // committed vector (rows of two): length 2 * 2^log_leaves
+    const uint32_t* tree = nullptr;
     unsigned log_leaves = 0;
     uint32_t root[8];
 };
@@ -342,43 +342,101 @@ std::vector<uint32_t> prove(TwoAdicFriPcs& pcs, const AirProgram& air, BfChallen
     std::vector<Ef> opened;
     DevBuf<Ef> folded = pcs.open_reduce(*trace_data, *quotient_data, zeta, batch_alpha, opened);
 
-    // ---- bf_commit_phase, fri/src/prover.rs:93-141
+    // ---- bf_commit_phase, fri/src/prover.rs:93-141.  The transcript moves to the device for the
+    // whole phase: per round a one-thread kernel observes the root and samples beta, the fold reads
+    // beta from device memory, and once the vector is short the remaining rounds run inside one
+    // workgroup (launch_fri_tail).  One D2H at the end brings back roots, betas, the final values
+    // and the challenger state.
     std::vector<FriRound> rounds;
+    std::vector<DevBuf<Ef>> keep_vecs;
+    std::vector<DevBuf<uint32_t>> keep_trees;
     Ef final_poly;
     {
         StageTimer t(&ctx, "FRI commit phase");
+        TS_REQUIRE(log_N >= fri.log_blowup, TS_ERR_INVALID, "FRI: vector shorter than the blowup");
+        const uint32_t R_total = log_N - fri.log_blowup;
+        DevChallenger hc;
+        challenger.export_dev(hc);
+        DevBuf<uint32_t> d_chal(&ctx, sizeof(DevChallenger) / 4);
+        h2d(ctx, d_chal.p, &hc, sizeof hc);
+        DevBuf<uint32_t> d_roots(&ctx, std::max<size_t>(8 * (size_t)R_total, 8));
+        DevBuf<Ef> d_betas(&ctx, std::max<size_t>(R_total, 1));
+        DevBuf<Ef> d_final(&ctx, fri.blowup());
+        DevChallenger* dch = reinterpret_cast<DevChallenger*>(d_chal.p);
+
         uint64_t len = 1ull << log_N;
         DevBuf<uint32_t> next_tree;
-        while (len > fri.blowup()) {  // :111
+        bool first = true;
+        while (len > fri.blowup() && len > (1ull << FRI_TAIL_LOG)) {  // :111, big rounds
             FriRound r;
             const uint64_t h = len / 2;
             r.log_leaves = log2_strict(h);
-            if (rounds.empty()) {
-                r.tree = DevBuf<uint32_t>(&ctx, merkle_total_digests(r.log_leaves) * 8);
-                launch_leaf_hash_ef_pairs(ctx, reinterpret_cast<const uint32_t*>(folded.p), h, r.tree.p);
+            DevBuf<uint32_t> tree;
+            if (first) {
+                tree = DevBuf<uint32_t>(&ctx, merkle_total_digests(r.log_leaves) * 8);
+                launch_leaf_hash_ef_pairs(ctx, reinterpret_cast<const uint32_t*>(folded.p), h, tree.p);
+                first = false;
             } else {
-                r.tree = std::move(next_tree);  // leaves were hashed by the previous fold
+                tree = std::move(next_tree);  // leaves were hashed by the previous fold
             }
-            launch_merkle_levels(ctx, r.tree.p, r.log_leaves);  // :113 commit_matrix
-            d2h_sync(ctx, r.root, r.tree.p + 8 * (merkle_total_digests(r.log_leaves) - 1), 32);
-            challenger.observe_commitment(r.root);  // :114
-            const Ef beta = challenger.sample();    // :116
+            launch_merkle_levels(ctx, tree.p, r.log_leaves);  // :113 commit_matrix
+            const size_t ri = rounds.size();
+            launch_chal_round(ctx, dch, tree.p + 8 * (merkle_total_digests(r.log_leaves) - 1),
+                              d_roots.p + 8 * ri, d_betas.p + ri);  // :114-116
             DevBuf<Ef> out(&ctx, h);
             uint32_t* nd = nullptr;
-            if (h > fri.blowup()) {  // another round follows: its leaves are pairs of `out`
+            if (h > fri.blowup() && h > (1ull << FRI_TAIL_LOG)) {  // next round is a big one too
                 next_tree = DevBuf<uint32_t>(&ctx, merkle_total_digests(r.log_leaves - 1) * 8);
                 nd = next_tree.p;
             }
-            launch_fri_fold(ctx, folded.p, h, beta, out.p, nd);  // :119 fold_matrix
-            r.vec = std::move(folded);
+            launch_fri_fold_dev(ctx, folded.p, h, d_betas.p + ri, out.p, nd);  // :119 fold_matrix
+            r.vec = folded.p;
+            r.tree = tree.p;
+            keep_vecs.push_back(std::move(folded));
+            keep_trees.push_back(std::move(tree));
             folded = std::move(out);
-            rounds.push_back(std::move(r));
+            rounds.push_back(r);
             len = h;
         }
+        if (len > fri.blowup()) {  // tail rounds in one workgroup
+            const uint32_t L0 = (uint32_t)len;
+            DevBuf<Ef> tail_vecs(&ctx, 2 * (size_t)L0);
+            DevBuf<uint32_t> tail_trees(&ctx, 8 * 2 * (size_t)L0);
+            const size_t ri = rounds.size();
+            launch_fri_tail(ctx, folded.p, L0, fri.blowup(), dch, tail_vecs.p, tail_trees.p,
+                            d_roots.p + 8 * ri, d_betas.p + ri, d_final.p);
+            uint32_t L = L0;
+            size_t voff = 0, toff = 0;
+            while (L > fri.blowup()) {
+                FriRound r;
+                r.log_leaves = log2_strict(L / 2);
+                r.vec = tail_vecs.p + voff;
+                r.tree = tail_trees.p + 8 * toff;
+                rounds.push_back(r);
+                voff += L;
+                toff += L - 1;
+                L >>= 1;
+            }
+            len = L;
+            keep_vecs.push_back(std::move(tail_vecs));
+            keep_trees.push_back(std::move(tail_trees));
+        } else {
+            TS_HIP(hipMemcpyAsync(d_final.p, folded.p, len * sizeof(Ef), hipMemcpyDeviceToDevice,
+                                  ctx.stream));
+        }
+        keep_vecs.push_back(std::move(folded));
         // :129-134 `blowup` evaluations of a constant polynomial
         TS_REQUIRE(len == fri.blowup(), TS_ERR_INVARIANT, "FRI: folded length != blowup");
+        TS_REQUIRE(rounds.size() == R_total, TS_ERR_INVARIANT, "FRI: round count");
         std::vector<Ef> fin(len);
-        d2h_sync(ctx, fin.data(), folded.p, len * sizeof(Ef));
+        std::vector<uint32_t> roots(std::max<size_t>(8 * (size_t)R_total, 8));
+        TS_HIP(hipMemcpyAsync(fin.data(), d_final.p, len * sizeof(Ef), hipMemcpyDeviceToHost, ctx.stream));
+        if (R_total)
+            TS_HIP(hipMemcpyAsync(roots.data(), d_roots.p, 32 * (size_t)R_total, hipMemcpyDeviceToHost,
+                                  ctx.stream));
+        d2h_sync(ctx, &hc, d_chal.p, sizeof hc);
+        challenger.import_dev(hc);
+        for (uint32_t r = 0; r < R_total; r++) memcpy(rounds[r].root, &roots[8 * (size_t)r], 32);
         final_poly = fin[0];
         for (auto& x : fin)
             TS_REQUIRE(ef_eq(x, final_poly), TS_ERR_INVARIANT,
@@ -421,8 +479,8 @@ std::vector<uint32_t> prove(TwoAdicFriPcs& pcs, const AirProgram& air, BfChallen
     launch_gather_rows(ctx, qlm, d_idx.p, Q, 0, d_out.p + o_qrows);
     launch_gather_paths(ctx, quotient_data->tree.p, log_N, d_idx.p, Q, 0, d_out.p + o_qpath);
     for (uint32_t r = 0; r < R; r++) {  // bf_answer_query :69-90: index_i = index >> i >> 1
-        launch_gather_ef_pairs(ctx, rounds[r].vec.p, d_idx.p, Q, r + 1, d_out.p + o_fvals[r]);
-        launch_gather_paths(ctx, rounds[r].tree.p, rounds[r].log_leaves, d_idx.p, Q, r + 1,
+        launch_gather_ef_pairs(ctx, rounds[r].vec, d_idx.p, Q, r + 1, d_out.p + o_fvals[r]);
+        launch_gather_paths(ctx, rounds[r].tree, rounds[r].log_leaves, d_idx.p, Q, r + 1,
                             d_out.p + o_fpath[r]);
     }
     std::vector<uint32_t> g(std::max<size_t>(off, 1));

@@ -90,6 +90,9 @@ ts_status ts_air_compile(ts_ctx* ctx, const uint32_t* tape, size_t n_words, ts_a
 /* get_log_quotient_degree, uni-stark/src/symbolic_builder.rs:15-32 */
 ts_status ts_air_info(const ts_air* air, uint32_t* width, uint32_t* n_public,
                       uint32_t* max_constraint_degree, uint32_t* log_quotient_degree);
+/* 1 if the quotient kernel was specialised for this AIR with hiprtc, 0 if the generic on-device
+ * interpreter is used (hiprtc missing, or TS_NO_JIT set in the environment) */
+int ts_air_is_jit(const ts_air* air);
 void ts_air_free(ts_ctx* ctx, ts_air* air);
 
 /* ------------------------------------------------------------------ PCS */

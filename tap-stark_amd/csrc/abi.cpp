@@ -10,6 +10,7 @@
 
 #include "../../include/tapstark.h"
 #include "host.hpp"
+#include "jit.hpp"
 
 struct ts_ctx {
     ts::Context ctx;
@@ -24,6 +25,13 @@ struct ts_pcs_data {
 struct ts_air {
     ts::AirProgram prog;
     ts::DevBuf<uint32_t> code;
+    std::string jit_log;
+    ~ts_air() {
+        ts::JitKernel jk;
+        jk.module = prog.jit_module;
+        jk.fn = prog.jit_fn;
+        ts::jit_release(jk);
+    }
 };
 struct ts_challenger {
     ts::BfChallenger c;
@@ -211,9 +219,23 @@ ts_status ts_air_compile(ts_ctx* ctx, const uint32_t* tape, size_t n_words, ts_a
                                   hipMemcpyHostToDevice, ctx->ctx.stream));
         ctx->ctx.sync();
         a->prog.d_code = a->code.p;
+        // specialise the quotient kernel for this AIR (falls back to the interpreter on failure)
+        hipDeviceProp_t prop;
+        TS_HIP(hipGetDeviceProperties(&prop, ctx->ctx.device));
+        std::string arch = prop.gcnArchName;
+        arch = arch.substr(0, arch.find(':'));
+        ts::JitKernel jk;
+        std::string log;
+        if (ts::jit_compile_quotient(a->prog, arch.c_str(), jk, log)) {
+            a->prog.jit_module = jk.module;
+            a->prog.jit_fn = jk.fn;
+        } else {
+            a->jit_log = log;
+        }
         *out = a.release();
     });
 }
+int ts_air_is_jit(const ts_air* air) { return air && air->prog.jit_fn ? 1 : 0; }
 ts_status ts_air_info(const ts_air* air, uint32_t* width, uint32_t* n_public,
                       uint32_t* max_constraint_degree, uint32_t* log_quotient_degree) {
     if (!air) return TS_ERR_INVALID;

@@ -44,6 +44,9 @@ struct AirProgram {
     std::vector<uint32_t> tape;             // the validated input (kept for the verifier side)
     // device copy of `code`, owned by the context that compiled it
     uint32_t* d_code = nullptr;
+    // hiprtc-specialised quotient kernel (jit.cpp); null => the interpreter in quotient.hip is used
+    void* jit_module = nullptr;
+    void* jit_fn = nullptr;
 };
 
 // throws ts::Error(TS_ERR_INVALID) on a malformed tape

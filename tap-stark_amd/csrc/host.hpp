@@ -76,6 +76,7 @@ struct PcsData {
     std::vector<ColMat> ldes;
     unsigned log_height = 0;
     DevBuf<uint32_t> tree;  // merkle_total_digests(log_height) x 8 words
+    DevBuf<const uint32_t*> col_table;  // one base pointer per column of the concatenated row
     uint32_t root[8] = {0};
     LeafMats leaf_mats() const;
 };

@@ -1,0 +1,204 @@
+// Run-time specialisation of the quotient kernel for one AIR: the register program produced by
+// compile_air (air.cpp) is translated 1:1 into straight-line HIP source and compiled with hiprtc
+// for the local GPU, so the constraint evaluation runs out of VGPRs with no instruction decode.
+// The AIR is user code in the reference too (a monomorphised `Air::eval`, uni-stark/src/prover.rs:180);
+// this is the GPU analogue.  If hiprtc is unavailable the interpreter in quotient.hip is used
+// (also a GPU path).  libhiprtc is loaded with dlopen so that the library itself has no hard
+// dependency on it.
+#include "jit.hpp"
+
+#include <dlfcn.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <sstream>
+
+namespace ts {
+
+namespace {
+
+typedef void* rtcProgram;
+struct Rtc {
+    void* lib = nullptr;
+    int (*create)(rtcProgram*, const char*, const char*, int, const char**, const char**) = nullptr;
+    int (*compile)(rtcProgram, int, const char**) = nullptr;
+    int (*log_size)(rtcProgram, size_t*) = nullptr;
+    int (*get_log)(rtcProgram, char*) = nullptr;
+    int (*code_size)(rtcProgram, size_t*) = nullptr;
+    int (*get_code)(rtcProgram, char*) = nullptr;
+    int (*destroy)(rtcProgram*) = nullptr;
+    bool ok = false;
+};
+
+Rtc& rtc() {
+    static Rtc r;
+    static bool tried = false;
+    if (tried) return r;
+    tried = true;
+    for (const char* name : {"libhiprtc.so", "/opt/rocm/lib/libhiprtc.so"}) {
+        r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (r.lib) break;
+    }
+    if (!r.lib) return r;
+    r.create = (decltype(r.create))dlsym(r.lib, "hiprtcCreateProgram");
+    r.compile = (decltype(r.compile))dlsym(r.lib, "hiprtcCompileProgram");
+    r.log_size = (decltype(r.log_size))dlsym(r.lib, "hiprtcGetProgramLogSize");
+    r.get_log = (decltype(r.get_log))dlsym(r.lib, "hiprtcGetProgramLog");
+    r.code_size = (decltype(r.code_size))dlsym(r.lib, "hiprtcGetCodeSize");
+    r.get_code = (decltype(r.get_code))dlsym(r.lib, "hiprtcGetCode");
+    r.destroy = (decltype(r.destroy))dlsym(r.lib, "hiprtcDestroyProgram");
+    r.ok = r.create && r.compile && r.log_size && r.get_log && r.code_size && r.get_code && r.destroy;
+    return r;
+}
+
+const char* kPrelude = R"SRC(
+typedef unsigned int u32;
+typedef unsigned long long u64;
+#define P 0x78000001u
+__device__ __forceinline__ u32 umin32(u32 a, u32 b) { return a < b ? a : b; }
+__device__ __forceinline__ u32 add(u32 a, u32 b) { u32 s = a + b; return umin32(s, s - P); }
+__device__ __forceinline__ u32 sub(u32 a, u32 b) { u32 d = a - b; return umin32(d, d + P); }
+__device__ __forceinline__ u32 neg(u32 a) { return a ? P - a : 0u; }
+__device__ __forceinline__ u32 mont_reduce(u64 t) {
+    u32 lo = (u32)t, t1, m;
+    asm("v_lshl_add_u32 %0, %1, 27, %1" : "=v"(t1) : "v"(lo));
+    asm("v_lshl_add_u32 %0, %1, 31, %2" : "=v"(m) : "v"(lo), "v"(t1));
+    u32 u = __umulhi(m, P);
+    u32 r = (u32)(t >> 32) - u;
+    return umin32(r, r + P);
+}
+__device__ __forceinline__ u32 mont_mul(u32 a, u32 b) { return mont_reduce((u64)a * b); }
+__device__ __forceinline__ u32 to_mont(u32 a) { return mont_mul(a, 0x45dddde3u); }
+__device__ __forceinline__ u64 lazy_fix(u64 acc) {
+    u32 hi = (u32)(acc >> 32);
+    u32 mask = (u32)((int)hi >> 31);
+    hi -= mask & P;
+    return ((u64)hi << 32) | (u32)acc;
+}
+__device__ __forceinline__ u32 lazy_finish(u64 acc) {
+    u32 hi = (u32)(acc >> 32);
+    hi = umin32(hi, hi - P);
+    return mont_reduce(((u64)hi << 32) | (u32)acc);
+}
+struct QC { u32 inv_zh[16]; };
+struct QO { u32* chunk[16]; };
+extern "C" __global__ void __launch_bounds__(256)
+k_quotient_jit(const u32* __restrict__ lde, u64 col_stride, unsigned log_n, unsigned log_qd,
+               const u32* __restrict__ C, const u32* __restrict__ AP, const u32* __restrict__ isf,
+               const u32* __restrict__ isl, const u32* __restrict__ ist, QC qc, QO out) {
+    const unsigned L = log_n + log_qd;
+    const u32 total = 1u << L;
+    const u32 r = blockIdx.x * 256u + threadIdx.x;
+    if (r >= total) return;
+    const u32 i = L ? (__brev(r) >> (32 - L)) : 0u;
+    const u32 i_next = (i + (1u << log_qd)) & (total - 1u);
+    const u32 r_next = L ? (__brev(i_next) >> (32 - L)) : 0u;
+    const u32* __restrict__ row0 = lde + r;
+    const u32* __restrict__ row1 = lde + r_next;
+    const u32 sel0 = isf[r], sel1 = isl[r], sel2 = ist[r];
+    u64 a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+)SRC";
+
+const char* kEpilogue = R"SRC(
+    a0 = lazy_fix(a0); a1 = lazy_fix(a1); a2 = lazy_fix(a2); a3 = lazy_fix(a3);
+    const u32 c = log_qd ? (__brev(r >> log_n) >> (32 - log_qd)) : 0u;
+    const u32 iz = qc.inv_zh[c];
+    const u64 n = 1ull << log_n;
+    u32* o = out.chunk[c] + (r & (n - 1));
+    o[0] = mont_mul(lazy_finish(a0), iz);
+    o[n] = mont_mul(lazy_finish(a1), iz);
+    o[2 * n] = mont_mul(lazy_finish(a2), iz);
+    o[3 * n] = mont_mul(lazy_finish(a3), iz);
+}
+)SRC";
+
+}  // namespace
+
+std::string jit_quotient_source(const AirProgram& air) {
+    std::ostringstream s;
+    s << kPrelude;
+    for (uint32_t r = 0; r < air.n_regs; r++) s << "    u32 r" << r << " = 0;\n";
+    const size_t n_instr = air.code.size() / 4;
+    uint32_t n_assert = 0;
+    for (size_t pc = 0; pc < n_instr; pc++) {
+        const uint32_t op = air.code[4 * pc], dst = air.code[4 * pc + 1], a = air.code[4 * pc + 2],
+                       b = air.code[4 * pc + 3];
+        switch (op) {
+            case D_LOAD:
+                s << "    r" << dst << " = to_mont(row" << a << "[" << b << "ull * col_stride]);\n";
+                break;
+            case D_CONST: s << "    r" << dst << " = C[" << a << "];\n"; break;
+            case D_SEL: s << "    r" << dst << " = sel" << a << ";\n"; break;
+            case D_ADD: s << "    r" << dst << " = add(r" << a << ", r" << b << ");\n"; break;
+            case D_SUB: s << "    r" << dst << " = sub(r" << a << ", r" << b << ");\n"; break;
+            case D_NEG: s << "    r" << dst << " = neg(r" << a << ");\n"; break;
+            case D_MUL: s << "    r" << dst << " = mont_mul(r" << a << ", r" << b << ");\n"; break;
+            default:  // D_ASSERT: acc += reg[a] * alpha_pow[b]
+                s << "    a0 += (u64)r" << a << " * AP[" << 4 * b << "]; a1 += (u64)r" << a << " * AP["
+                  << 4 * b + 1 << "]; a2 += (u64)r" << a << " * AP[" << 4 * b + 2 << "]; a3 += (u64)r"
+                  << a << " * AP[" << 4 * b + 3 << "];\n";
+                if (++n_assert % 2 == 0)
+                    s << "    a0 = lazy_fix(a0); a1 = lazy_fix(a1); a2 = lazy_fix(a2); a3 = lazy_fix(a3);\n";
+                break;
+        }
+    }
+    s << kEpilogue;
+    return s.str();
+}
+
+bool jit_compile_quotient(const AirProgram& air, const char* arch, JitKernel& out, std::string& log) {
+    if (getenv("TS_NO_JIT")) {
+        log = "disabled by TS_NO_JIT";
+        return false;
+    }
+    Rtc& r = rtc();
+    if (!r.ok) {
+        log = "libhiprtc not available";
+        return false;
+    }
+    const std::string src = jit_quotient_source(air);
+    rtcProgram prog = nullptr;
+    if (r.create(&prog, src.c_str(), "quotient_jit.hip", 0, nullptr, nullptr) != 0) {
+        log = "hiprtcCreateProgram failed";
+        return false;
+    }
+    std::string arch_opt = std::string("--offload-arch=") + arch;
+    const char* opts[] = {arch_opt.c_str(), "-O3"};
+    const int rc = r.compile(prog, 2, opts);
+    size_t sz = 0;
+    r.log_size(prog, &sz);
+    if (sz > 1) {
+        log.resize(sz);
+        r.get_log(prog, &log[0]);
+    }
+    if (rc != 0) {
+        r.destroy(&prog);
+        return false;
+    }
+    r.code_size(prog, &sz);
+    std::vector<char> code(sz);
+    r.get_code(prog, code.data());
+    r.destroy(&prog);
+    hipModule_t mod = nullptr;
+    if (hipModuleLoadData(&mod, code.data()) != hipSuccess) {
+        log += " hipModuleLoadData failed";
+        return false;
+    }
+    hipFunction_t fn = nullptr;
+    if (hipModuleGetFunction(&fn, mod, "k_quotient_jit") != hipSuccess) {
+        hipModuleUnload(mod);
+        log += " hipModuleGetFunction failed";
+        return false;
+    }
+    out.module = mod;
+    out.fn = fn;
+    return true;
+}
+
+void jit_release(JitKernel& k) {
+    if (k.module) hipModuleUnload((hipModule_t)k.module);
+    k.module = nullptr;
+    k.fn = nullptr;
+}
+
+}  // namespace ts

@@ -41,6 +41,9 @@ struct LeafMats {
     uint32_t width[MAX_BATCH_MATS];
     uint32_t n_mats;
     uint32_t total_width;
+    // device array of total_width column base pointers (column c of the concatenated row), so
+    // that the leaf kernel addresses a row element with one uniform pointer load
+    const uint32_t* const* cols;
 };
 // leaf digests (8 words each) of `height` rows: Blake3(row of mat 0 || row of mat 1 || ...)
 void launch_leaf_hash(Context& ctx, const LeafMats& mats, uint64_t height, uint32_t* digests);
@@ -75,8 +78,8 @@ void launch_quotient(Context& ctx, const AirProgram& air, const ColMat& trace_ld
 // for up to 2 points; out layout [point][n] of Ef
 void launch_bary_weights(Context& ctx, unsigned log_n, const Ef* points_mont, uint32_t n_points,
                          Ef* out);
-// partial[c][p] = sum_i m[c][i] * d[p][i]   (canonical EF4), i over the first n rows
-void launch_bary_sums(Context& ctx, const ColMat& m, unsigned log_n, const Ef* weights,
+// out[col][p] = sum_i m[col][i] * d[p][i]   (canonical EF4), i over the first n rows
+void launch_bary_dots(Context& ctx, const ColMat& m, unsigned log_n, const Ef* weights,
                       uint32_t n_points, Ef* out /* width * n_points */);
 // ro[X] (+)= sum_p off_p * (S(X) - rys_p) / (x_X - z_p),  S(X) = sum_i alpha^i m[i][X]
 struct ReduceArgs {
@@ -88,6 +91,19 @@ struct ReduceArgs {
 };
 void launch_reduce(Context& ctx, const ColMat& m, unsigned log_h, const uint32_t* d_alpha_pows_mont,
                    const ReduceArgs& args, Ef* ro);
+// the prove() shape in one pass: trace opened at (zeta, zeta*omega), n_chunks width-4 matrices at zeta
+struct FusedReduceArgs {
+    Ef z_mont[2];
+    Ef off_t[2];   // alpha^0, alpha^w            (Montgomery)
+    Ef rys_t[2];   // reduced opened values       (canonical)
+    Ef off_c[16];  // alpha^(2w + 4c)
+    Ef rys_c[16];
+    const uint32_t* chunk[16];
+    uint64_t chunk_stride;
+    uint32_t n_chunks;
+};
+void launch_reduce_fused(Context& ctx, const ColMat& trace, unsigned log_h,
+                         const uint32_t* d_alpha_pows_mont, const FusedReduceArgs& args, Ef* ro);
 
 // ---- fri.hip ---------------------------------------------------------------------------------
 // out[i] = fold(in[2i], in[2i+1]; beta) (reference two_adic_pcs.rs:116-147); h = output length.

@@ -10,30 +10,21 @@
 namespace ts {
 
 __global__ void __launch_bounds__(256)
-k_leaf_hash(LeafMats mats, uint64_t height, uint32_t* __restrict__ digests) {
+k_leaf_hash(const uint32_t* const* __restrict__ cols, uint32_t total, uint64_t height,
+            uint32_t* __restrict__ digests) {
     uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= height) return;
     uint32_t cv[8];
     b3::iv(cv);
-    const uint32_t total = mats.total_width;
     const uint32_t n_blocks = total == 0 ? 1 : (total + 15) / 16;
-    // walk the concatenated row 16 words (one Blake3 block) at a time
-    uint32_t mi = 0;   // current matrix
-    uint32_t ci = 0;   // current column inside it
+    // walk the concatenated row 16 words (one Blake3 block) at a time; the 16 loads of a block are
+    // independent and issue back to back
     for (uint32_t blk = 0; blk < n_blocks; blk++) {
         uint32_t m[16];
 #pragma unroll
         for (int j = 0; j < 16; j++) {
-            uint32_t v = 0;
-            if (blk * 16 + j < total) {
-                while (ci >= mats.width[mi]) {
-                    ci = 0;
-                    mi++;
-                }
-                v = mats.d[mi][(uint64_t)ci * mats.col_stride[mi] + r];
-                ci++;
-            }
-            m[j] = v;
+            const uint32_t c = blk * 16 + j;
+            m[j] = c < total ? cols[c][r] : 0u;
         }
         uint32_t words = total - blk * 16 < 16 ? total - blk * 16 : 16;
         uint32_t flags = (blk == 0 ? b3::CHUNK_START : 0u) |
@@ -48,7 +39,9 @@ k_leaf_hash(LeafMats mats, uint64_t height, uint32_t* __restrict__ digests) {
 void launch_leaf_hash(Context& ctx, const LeafMats& mats, uint64_t height, uint32_t* digests) {
     TS_REQUIRE(mats.total_width <= 256, TS_ERR_UNSUPPORTED,
                "leaf rows wider than 256 field elements (one Blake3 chunk) are not supported");
-    TS_LAUNCH(ctx, k_leaf_hash, dim3((unsigned)((height + 255) / 256)), dim3(256), 0, mats, height, digests);
+    TS_REQUIRE(mats.cols != nullptr, TS_ERR_INVALID, "leaf_hash: column pointer table missing");
+    TS_LAUNCH(ctx, k_leaf_hash, dim3((unsigned)((height + 255) / 256)), dim3(256), 0, mats.cols,
+              mats.total_width, height, digests);
     TS_HIP(hipGetLastError());
 }
 

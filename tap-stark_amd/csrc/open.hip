@@ -1,9 +1,10 @@
 // Opening kernels (reference fri/src/two_adic_pcs.rs:260-389 `open`):
-//   :358-369  ys = interpolate_coset(BitRev(first n rows), 31, z)     -> bary_weights + bary_sums
+//   :358-369  ys = interpolate_coset(BitRev(first n rows), 31, z)     -> bary_weights + bary_dots
 //   :678-720  inv_denoms[X] = 1/(x_X - z), x_X = 31 * w_N^bitrev(X)   -> computed on the fly
 //   :371-381  ro[X] += alpha^offset * (sum_i alpha^i p_i[X] - reduced_ys) * inv_denom[X]  -> reduce
 // All matrices are column-major with bit-reversed rows, so "row X" is a coalesced read per column.
-// A matrix opened at two points (trace at zeta and zeta*w_n) shares one pass over its columns.
+// Dot products are accumulated lazily: 64-bit multiply-adds (one v_mad_u64_u32 each) with a cheap
+// range fix every two terms and a single Montgomery reduction at the end.
 #include "kernels.hpp"
 
 namespace ts {
@@ -13,6 +14,26 @@ __device__ __forceinline__ uint32_t root_bitrev(const uint32_t* __restrict__ W, 
     if (L == 0) return R_MOD_P;
     uint32_t w = W[((uint64_t)1 << (L - 1)) + (r >> 1)];
     return (r & 1) ? neg(w) : w;
+}
+
+// ---- lazy accumulation -------------------------------------------------------------------------
+// acc < 2^63 on entry of every pair of macs; each product is < p^2 < 2^61.82, so two of them keep
+// acc below 2^64.  fix(): if acc >= 2^63 subtract p*2^32 (< 2^62.91), which preserves acc mod p
+// and brings it back below 2^63.
+__device__ __forceinline__ uint64_t lazy_mac(uint64_t acc, uint32_t a, uint32_t b) {
+    return acc + (uint64_t)a * b;
+}
+__device__ __forceinline__ uint64_t lazy_fix(uint64_t acc) {
+    uint32_t hi = (uint32_t)(acc >> 32);
+    uint32_t mask = (uint32_t)((int32_t)hi >> 31);
+    hi -= mask & P;
+    return ((uint64_t)hi << 32) | (uint32_t)acc;
+}
+// final: acc < 2^63 -> acc * 2^-32 mod p, canonical
+__device__ __forceinline__ uint32_t lazy_finish(uint64_t acc) {
+    uint32_t hi = (uint32_t)(acc >> 32);  // < 2^31 <= ... may still be >= p
+    hi = umin32(hi, hi - P);
+    return mont_reduce(((uint64_t)hi << 32) | (uint32_t)acc);
 }
 
 // ------------------------------------------------------------------ barycentric weights
@@ -64,109 +85,191 @@ void launch_bary_weights(Context& ctx, unsigned log_n, const Ef* points_mont, ui
     ctx.ensure_twiddles(log_n == 0 ? 1 : log_n);
     const uint64_t threads = (((uint64_t)1 << log_n) + BW_ROWS - 1) / BW_ROWS;
     Ef z0 = points_mont[0], z1 = n_points > 1 ? points_mont[1] : points_mont[0];
-    TS_LAUNCH(ctx, k_bary_weights, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
-                       log_n, ctx.d_twiddle_fwd, to_mont(GENERATOR), z0, z1, n_points, out);
+    TS_LAUNCH(ctx, k_bary_weights, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, log_n,
+              ctx.d_twiddle_fwd, to_mont(GENERATOR), z0, z1, n_points, out);
     TS_HIP(hipGetLastError());
 }
 
-// ------------------------------------------------------------------ barycentric sums
-// partial[chunk][col][p] = sum over the chunk's rows of m[col][t] * weights[p][t]
-constexpr int BS_COLS = 8;           // columns per workgroup
-constexpr int BS_ROWS_PER_THREAD = 16;
-constexpr int BS_CHUNK = 256 * BS_ROWS_PER_THREAD;
-
-__device__ __forceinline__ uint32_t wave_sum_modp(uint32_t v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = add(v, __shfl_down(v, off, 64));
-    return v;
-}
-
-template <int NP>
+// ------------------------------------------------------------------ barycentric dot products
+// acc[col][p][k] += sum_t m[col][t] * weights[p][t].c[k]  over the first n rows (a skinny product
+// [w x n].[n x 4 NP]).  A workgroup streams tiles of COLS columns x TR rows through LDS (loads
+// coalesced along rows, all in flight at once); then each lane owns one column and one row subset
+// and reads the tile's weights as LDS broadcasts.  COLS = 64 for wide matrices, 8 for the width-4
+// quotient chunks (so that all 64 lanes stay busy).  Per-workgroup sums go to a partial buffer
+// [block][col][NP*4] that k_bary_finish adds up.
+template <int NP, int COLS>
 __global__ void __launch_bounds__(256)
-k_bary_sums(const uint32_t* __restrict__ m, uint64_t col_stride, uint32_t width, unsigned log_n,
-            const Ef* __restrict__ weights, Ef* __restrict__ partial) {
+k_bary_dots(const uint32_t* __restrict__ m, uint64_t col_stride, uint32_t width, unsigned log_n,
+            const Ef* __restrict__ weights, uint32_t* __restrict__ partial, uint32_t rows_per_block) {
+    constexpr int RS = 64 / COLS;        // row subsets per wave
+    constexpr int TR = 16 * 4 * RS;      // tile rows: 16 per (wave, row subset)
+    constexpr int PER_THREAD = COLS * TR / 256;  // = 16
+    // tile element (column c, row t = 16*sub + rr) lives at rr*257 + sub*COLS + c: the compute
+    // phase reads it conflict-free (lanes = (sub, c)), the store phase with small conflicts only
+    __shared__ uint32_t tile[16 * 257];
+    __shared__ uint32_t wts[TR][NP * 4];
+    __shared__ uint32_t red[4 * RS][COLS][NP * 4];
     const uint64_t n = 1ull << log_n;
-    const uint32_t chunk = blockIdx.x;
-    const uint32_t c0 = blockIdx.y * BS_COLS;
-    uint32_t acc[BS_COLS][NP][4];
+    const uint32_t c0 = blockIdx.y * COLS;
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t cl = lane % COLS, rs = lane / COLS;
+    const uint32_t sub = wv * RS + rs;  // which 16-row slice of the tile this thread reduces
+    const uint64_t row_begin = (uint64_t)blockIdx.x * rows_per_block;
+    const uint64_t row_end = row_begin + rows_per_block < n ? row_begin + rows_per_block : n;
+    uint64_t acc[NP * 4];
 #pragma unroll
-    for (int c = 0; c < BS_COLS; c++)
+    for (int j = 0; j < NP * 4; j++) acc[j] = 0;
+    for (uint64_t row0 = row_begin; row0 < row_end; row0 += TR) {
+        uint32_t v[PER_THREAD];
 #pragma unroll
-        for (int p = 0; p < NP; p++)
+        for (int k = 0; k < PER_THREAD; k++) {
+            const uint32_t e = threadIdx.x + (uint32_t)k * 256;
+            const uint32_t c = c0 + e / TR;
+            const uint64_t t = row0 + e % TR;
+            v[k] = (c < width && t < row_end) ? m[(uint64_t)c * col_stride + t] : 0u;
+        }
+        for (uint32_t e = threadIdx.x; e < (uint32_t)(TR * NP); e += 256) {
+            const uint32_t p = e / TR, tt = e % TR;
+            const uint64_t t = row0 + tt;
+            Ef w = ef_zero();
+            if (t < row_end) w = weights[(uint64_t)p * n + t];
+            wts[tt][p * 4 + 0] = w.c[0];
+            wts[tt][p * 4 + 1] = w.c[1];
+            wts[tt][p * 4 + 2] = w.c[2];
+            wts[tt][p * 4 + 3] = w.c[3];
+        }
 #pragma unroll
-            for (int k = 0; k < 4; k++) acc[c][p][k] = 0;
-    for (int it = 0; it < BS_ROWS_PER_THREAD; it++) {
-        const uint64_t t = (uint64_t)chunk * BS_CHUNK + (uint64_t)it * 256 + threadIdx.x;
-        if (t >= n) break;
-        Ef wgt[NP];
+        for (int k = 0; k < PER_THREAD; k++) {
+            const uint32_t e = threadIdx.x + (uint32_t)k * 256;
+            const uint32_t t = e % TR;
+            tile[(t & 15) * 257 + (t >> 4) * COLS + e / TR] = v[k];
+        }
+        __syncthreads();
 #pragma unroll
-        for (int p = 0; p < NP; p++) wgt[p] = weights[(uint64_t)p * n + t];
+        for (int rr = 0; rr < 16; rr++) {
+            const uint32_t tt = sub * 16 + rr;
+            const uint32_t x = tile[rr * 257 + sub * COLS + cl];
 #pragma unroll
-        for (int c = 0; c < BS_COLS; c++) {
-            if (c0 + c < width) {
-                const uint32_t v = m[(uint64_t)(c0 + c) * col_stride + t];
+            for (int j = 0; j < NP * 4; j++) acc[j] = lazy_mac(acc[j], x, wts[tt][j]);
+            if (rr & 1) {
 #pragma unroll
-                for (int p = 0; p < NP; p++)
-#pragma unroll
-                    for (int k = 0; k < 4; k++)
-                        acc[c][p][k] = add(acc[c][p][k], mont_mul(v, wgt[p].c[k]));
+                for (int j = 0; j < NP * 4; j++) acc[j] = lazy_fix(acc[j]);
             }
         }
+        __syncthreads();
     }
-    // workgroup reduction: wave shuffles, then 4 wave leaders through LDS
-    __shared__ uint32_t red[4][BS_COLS * NP * 4];
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int c = 0; c < BS_COLS; c++)
-#pragma unroll
-        for (int p = 0; p < NP; p++)
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                uint32_t v = wave_sum_modp(acc[c][p][k]);
-                if (lane == 0) red[wave][(c * NP + p) * 4 + k] = v;
-            }
+    for (int j = 0; j < NP * 4; j++) red[sub][cl][j] = lazy_finish(acc[j]);
     __syncthreads();
-    if (threadIdx.x < BS_COLS * NP * 4) {
-        const uint32_t j = threadIdx.x;
-        uint32_t v = add(add(red[0][j], red[1][j]), add(red[2][j], red[3][j]));
-        const uint32_t c = j / (NP * 4), rem = j % (NP * 4);
-        if (c0 + c < width) {
-            uint32_t* o = reinterpret_cast<uint32_t*>(partial + ((uint64_t)chunk * width + c0 + c) * NP);
-            o[rem] = v;
-        }
+    for (uint32_t idx = threadIdx.x; idx < (uint32_t)(COLS * NP * 4); idx += 256) {
+        const uint32_t c = idx / (NP * 4), j = idx % (NP * 4);
+        uint32_t sum = 0;
+#pragma unroll
+        for (int q = 0; q < 4 * RS; q++) sum = add(sum, red[q][c][j]);
+        if (c0 + c < width)
+            partial[((uint64_t)blockIdx.x * width + c0 + c) * (NP * 4) + j] = sum;
     }
 }
 
-// out[col][p] = sum over chunks of partial[chunk][col][p]
+// out[j] = sum over blocks of partial[block][j]  (mod p); one workgroup per 4 output words
 __global__ void __launch_bounds__(256)
-k_bary_finish(const uint32_t* __restrict__ partial, uint32_t n_chunks, uint32_t n_words,
+k_bary_finish(const uint32_t* __restrict__ partial, uint32_t n_blocks, uint32_t n_words,
               uint32_t* __restrict__ out) {
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n_words) return;
+    __shared__ uint32_t red[4][4];
+    const uint32_t j = blockIdx.x * 4 + (threadIdx.x & 3);
     uint32_t v = 0;
-    for (uint32_t ch = 0; ch < n_chunks; ch++) v = add(v, partial[(uint64_t)ch * n_words + j]);
-    out[j] = v;
+    if (j < n_words)
+        for (uint32_t b = threadIdx.x >> 2; b < n_blocks; b += 64)
+            v = add(v, partial[(uint64_t)b * n_words + j]);
+    // reduce over the 64 threads that share (threadIdx.x & 3): lanes 4 apart within a wave, 4 waves
+#pragma unroll
+    for (int off = 32; off >= 4; off >>= 1) v = add(v, __shfl_down(v, off, 64));
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane < 4) red[wv][lane] = v;
+    __syncthreads();
+    if (threadIdx.x < 4 && j < n_words)
+        out[j] = add(add(red[0][threadIdx.x], red[1][threadIdx.x]),
+                     add(red[2][threadIdx.x], red[3][threadIdx.x]));
 }
 
-void launch_bary_sums(Context& ctx, const ColMat& m, unsigned log_n, const Ef* weights,
+void launch_bary_dots(Context& ctx, const ColMat& m, unsigned log_n, const Ef* weights,
                       uint32_t n_points, Ef* out) {
     const uint64_t n = 1ull << log_n;
-    const uint32_t n_chunks = (uint32_t)((n + BS_CHUNK - 1) / BS_CHUNK);
-    DevBuf<Ef> partial(&ctx, (size_t)n_chunks * m.width * n_points);
-    dim3 grid(n_chunks, (m.width + BS_COLS - 1) / BS_COLS);
-    if (n_points == 2)
-        TS_LAUNCH(ctx, k_bary_sums<2>, grid, dim3(256), 0, m.d, m.col_stride, m.width,
-                           log_n, weights, partial.p);
-    else
-        TS_LAUNCH(ctx, k_bary_sums<1>, grid, dim3(256), 0, m.d, m.col_stride, m.width,
-                           log_n, weights, partial.p);
+    const bool narrow = m.width <= 8;
+    const uint32_t tr = narrow ? 512 : 64;
+    uint32_t n_blocks = (uint32_t)((n + tr - 1) / tr);
+    if (n_blocks > 2048) n_blocks = 2048;
+    uint32_t rows_per_block = (uint32_t)(((n + n_blocks - 1) / n_blocks + tr - 1) / tr * tr);
+    n_blocks = (uint32_t)((n + rows_per_block - 1) / rows_per_block);
     const uint32_t n_words = m.width * n_points * 4;
-    TS_LAUNCH(ctx, k_bary_finish, dim3((n_words + 255) / 256), dim3(256), 0, reinterpret_cast<const uint32_t*>(partial.p), n_chunks, n_words,
-                       reinterpret_cast<uint32_t*>(out));
+    DevBuf<uint32_t> partial(&ctx, (size_t)n_blocks * n_words);
+    const uint32_t* md = m.d;
+    if (narrow) {
+        dim3 grid(n_blocks, (m.width + 7) / 8);
+        if (n_points == 2)
+            TS_LAUNCH(ctx, (k_bary_dots<2, 8>), grid, dim3(256), 0, md, m.col_stride, m.width, log_n,
+                      weights, partial.p, rows_per_block);
+        else
+            TS_LAUNCH(ctx, (k_bary_dots<1, 8>), grid, dim3(256), 0, md, m.col_stride, m.width, log_n,
+                      weights, partial.p, rows_per_block);
+    } else {
+        dim3 grid(n_blocks, (m.width + 63) / 64);
+        if (n_points == 2)
+            TS_LAUNCH(ctx, (k_bary_dots<2, 64>), grid, dim3(256), 0, md, m.col_stride, m.width, log_n,
+                      weights, partial.p, rows_per_block);
+        else
+            TS_LAUNCH(ctx, (k_bary_dots<1, 64>), grid, dim3(256), 0, md, m.col_stride, m.width, log_n,
+                      weights, partial.p, rows_per_block);
+    }
+    TS_LAUNCH(ctx, k_bary_finish, dim3((n_words + 3) / 4), dim3(256), 0, (const uint32_t*)partial.p,
+              n_blocks, n_words, reinterpret_cast<uint32_t*>(out));
     TS_HIP(hipGetLastError());
 }
 
-// ------------------------------------------------------------------ reduce
+// ------------------------------------------------------------------ reduce (generic)
+// S(X) = sum_i alpha^i * p_i[X]  (dot_ext_powers, :375), canonical; alpha powers are wave-uniform
+__device__ __forceinline__ Ef row_dot_alpha(const uint32_t* __restrict__ m, uint64_t col_stride,
+                                            uint32_t width, uint64_t X,
+                                            const uint32_t* __restrict__ alpha_pows) {
+    uint64_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    for (uint32_t i = 0; i < width; i++) {
+        const uint32_t v = m[(uint64_t)i * col_stride + X];
+        const uint32_t* ap = alpha_pows + 4 * i;
+        a0 = lazy_mac(a0, v, ap[0]);
+        a1 = lazy_mac(a1, v, ap[1]);
+        a2 = lazy_mac(a2, v, ap[2]);
+        a3 = lazy_mac(a3, v, ap[3]);
+        if (i & 1) {
+            a0 = lazy_fix(a0);
+            a1 = lazy_fix(a1);
+            a2 = lazy_fix(a2);
+            a3 = lazy_fix(a3);
+        }
+    }
+    return Ef{{lazy_finish(lazy_fix(a0)), lazy_finish(lazy_fix(a1)), lazy_finish(lazy_fix(a2)),
+               lazy_finish(lazy_fix(a3))}};
+}
+
+// 1/(x - z_p) for NP points with one shared base-field inversion (Montgomery)
+template <int NP>
+__device__ __forceinline__ void inv_denoms(uint32_t x_mont, const Ef* z_mont, Ef* out) {
+    Ef num[NP];
+    uint32_t nrm[NP];
+#pragma unroll
+    for (int p = 0; p < NP; p++) {
+        const Ef z = z_mont[p];
+        Ef u = Ef{{sub(x_mont, z.c[0]), neg(z.c[1]), neg(z.c[2]), neg(z.c[3])}};  // x - z
+        ef_inv_parts(u, num[p], nrm[p]);
+    }
+    if (NP == 2) {
+        uint32_t inv = mont_inv(mont_mul(nrm[0], nrm[NP - 1]));
+        out[0] = ef_mul_base(num[0], mont_mul(inv, nrm[NP - 1]));
+        out[NP - 1] = ef_mul_base(num[NP - 1], mont_mul(inv, nrm[0]));
+    } else {
+        out[0] = ef_mul_base(num[0], mont_inv(nrm[0]));
+    }
+}
+
 template <int NP>
 __global__ void __launch_bounds__(256)
 k_reduce(const uint32_t* __restrict__ m, uint64_t col_stride, uint32_t width, unsigned log_h,
@@ -175,41 +278,16 @@ k_reduce(const uint32_t* __restrict__ m, uint64_t col_stride, uint32_t width, un
     const uint64_t h = 1ull << log_h;
     const uint64_t X = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (X >= h) return;
-    // S(X) = sum_i alpha^i * p_i[X]  (dot_ext_powers, :375) -- canonical
-    uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-    for (uint32_t i = 0; i < width; i++) {
-        const uint32_t v = m[(uint64_t)i * col_stride + X];
-        const uint32_t* ap = alpha_pows + 4 * i;  // wave-uniform
-        s0 = add(s0, mont_mul(v, ap[0]));
-        s1 = add(s1, mont_mul(v, ap[1]));
-        s2 = add(s2, mont_mul(v, ap[2]));
-        s3 = add(s3, mont_mul(v, ap[3]));
-    }
-    const Ef S = Ef{{s0, s1, s2, s3}};
+    const Ef S = row_dot_alpha(m, col_stride, width, X, alpha_pows);
     // x_X = 31 * omega_h^bitrev(X)  (:698-705), Montgomery
     const uint32_t x = mont_mul(gen_mont, root_bitrev(W, log_h, X));
-    Ef num[NP];
-    uint32_t nrm[NP];
-#pragma unroll
-    for (int p = 0; p < NP; p++) {
-        const Ef z = args.z_mont[p];
-        Ef u = Ef{{sub(x, z.c[0]), neg(z.c[1]), neg(z.c[2]), neg(z.c[3])}};  // x - z
-        ef_inv_parts(u, num[p], nrm[p]);
-    }
-    uint32_t ninv[NP];
-    if (NP == 2) {
-        uint32_t inv = mont_inv(mont_mul(nrm[0], nrm[1]));
-        ninv[0] = mont_mul(inv, nrm[NP - 1]);
-        ninv[NP - 1] = mont_mul(inv, nrm[0]);
-    } else {
-        ninv[0] = mont_inv(nrm[0]);
-    }
+    Ef inv_d[NP];
+    inv_denoms<NP>(x, args.z_mont, inv_d);
     Ef acc = args.accumulate ? ro[X] : ef_zero();
 #pragma unroll
     for (int p = 0; p < NP; p++) {
-        Ef inv_denom = ef_mul_base(num[p], ninv[p]);            // Montgomery
         Ef t = ef_mul(ef_sub(S, args.rys[p]), args.off_mont[p]);  // canonical
-        acc = ef_add(acc, ef_mul(t, inv_denom));                 // canonical
+        acc = ef_add(acc, ef_mul(t, inv_d[p]));                   // canonical
     }
     ro[X] = acc;
 }
@@ -221,11 +299,49 @@ void launch_reduce(Context& ctx, const ColMat& m, unsigned log_h, const uint32_t
     const uint64_t h = 1ull << log_h;
     dim3 grid((unsigned)((h + 255) / 256));
     if (args.n_points == 2)
-        TS_LAUNCH(ctx, k_reduce<2>, grid, dim3(256), 0, m.d, m.col_stride, m.width,
-                           log_h, ctx.d_twiddle_fwd, to_mont(GENERATOR), d_alpha_pows_mont, args, ro);
+        TS_LAUNCH(ctx, k_reduce<2>, grid, dim3(256), 0, (const uint32_t*)m.d, m.col_stride, m.width,
+                  log_h, (const uint32_t*)ctx.d_twiddle_fwd, to_mont(GENERATOR), d_alpha_pows_mont, args,
+                  ro);
     else
-        TS_LAUNCH(ctx, k_reduce<1>, grid, dim3(256), 0, m.d, m.col_stride, m.width,
-                           log_h, ctx.d_twiddle_fwd, to_mont(GENERATOR), d_alpha_pows_mont, args, ro);
+        TS_LAUNCH(ctx, k_reduce<1>, grid, dim3(256), 0, (const uint32_t*)m.d, m.col_stride, m.width,
+                  log_h, (const uint32_t*)ctx.d_twiddle_fwd, to_mont(GENERATOR), d_alpha_pows_mont, args,
+                  ro);
+    TS_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------ reduce, prove() shape, one pass
+// ro[X] = inv(x - zeta)      * [ off_t0 (S_t - rys_t0) + sum_c off_c (S_c - rys_c) ]
+//       + inv(x - zeta omega) *   off_t1 (S_t - rys_t1)
+// where S_t is shared by the two trace openings (two_adic_pcs.rs:344-387 visits the trace twice).
+__global__ void __launch_bounds__(256)
+k_reduce_fused(const uint32_t* __restrict__ trace, uint64_t trace_stride, uint32_t width,
+               unsigned log_h, const uint32_t* __restrict__ W, uint32_t gen_mont,
+               const uint32_t* __restrict__ alpha_pows, FusedReduceArgs a, Ef* __restrict__ ro) {
+    const uint64_t h = 1ull << log_h;
+    const uint64_t X = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (X >= h) return;
+    const Ef St = row_dot_alpha(trace, trace_stride, width, X, alpha_pows);
+    const uint32_t x = mont_mul(gen_mont, root_bitrev(W, log_h, X));
+    Ef inv_d[2];
+    inv_denoms<2>(x, a.z_mont, inv_d);
+    Ef g0 = ef_mul(ef_sub(St, a.rys_t[0]), a.off_t[0]);
+    for (uint32_t c = 0; c < a.n_chunks; c++) {
+        const Ef Sc = row_dot_alpha(a.chunk[c], a.chunk_stride, 4, X, alpha_pows);
+        g0 = ef_add(g0, ef_mul(ef_sub(Sc, a.rys_c[c]), a.off_c[c]));
+    }
+    const Ef g1 = ef_mul(ef_sub(St, a.rys_t[1]), a.off_t[1]);
+    const Ef r = ef_add(ef_mul(g0, inv_d[0]), ef_mul(g1, inv_d[1]));
+    *reinterpret_cast<uint4*>(ro + X) = make_uint4(r.c[0], r.c[1], r.c[2], r.c[3]);
+}
+
+void launch_reduce_fused(Context& ctx, const ColMat& trace, unsigned log_h,
+                         const uint32_t* d_alpha_pows_mont, const FusedReduceArgs& args, Ef* ro) {
+    TS_REQUIRE(args.n_chunks <= 16, TS_ERR_INVALID, "reduce_fused: too many chunks");
+    ctx.ensure_twiddles(log_h == 0 ? 1 : log_h);
+    const uint64_t h = 1ull << log_h;
+    TS_LAUNCH(ctx, k_reduce_fused, dim3((unsigned)((h + 255) / 256)), dim3(256), 0,
+              (const uint32_t*)trace.d, trace.col_stride, trace.width, log_h,
+              (const uint32_t*)ctx.d_twiddle_fwd, to_mont(GENERATOR), d_alpha_pows_mont, args, ro);
     TS_HIP(hipGetLastError());
 }
 

@@ -52,6 +52,7 @@ LeafMats PcsData::leaf_mats() const {
         lm.width[i] = ldes[i].width;
         lm.total_width += ldes[i].width;
     }
+    lm.cols = col_table.p;
     return lm;
 }
 
@@ -104,6 +105,11 @@ std::unique_ptr<PcsData> TwoAdicFriPcs::commit(std::vector<DeviceMatrix>& evals,
     {
         StageTimer t(&ctx_, "merkle_commit");
         data->tree = DevBuf<uint32_t>(&ctx_, merkle_total_digests(log_N) * 8);
+        std::vector<const uint32_t*> cols;
+        for (auto& cm : data->ldes)
+            for (uint32_t c = 0; c < cm.width; c++) cols.push_back(cm.d + (uint64_t)c * cm.col_stride);
+        data->col_table = DevBuf<const uint32_t*>(&ctx_, cols.size());
+        h2d(ctx_, data->col_table.p, cols.data(), cols.size() * sizeof(const uint32_t*));
         launch_leaf_hash(ctx_, data->leaf_mats(), N, data->tree.p);
         launch_merkle_levels(ctx_, data->tree.p, log_N);
         d2h_sync(ctx_, data->root, data->tree.p + 8 * (merkle_total_digests(log_N) - 1), 32);
@@ -196,9 +202,9 @@ DevBuf<Ef> TwoAdicFriPcs::open_reduce(const PcsData& trace_data, const PcsData& 
         DevBuf<Ef> weights(&ctx_, 2 * n);
         launch_bary_weights(ctx_, log_n, pts_mont, 2, weights.p);
         DevBuf<Ef> sums(&ctx_, raw.size());
-        launch_bary_sums(ctx_, tr, log_n, weights.p, 2, sums.p);  // [col][point]
+        launch_bary_dots(ctx_, tr, log_n, weights.p, 2, sums.p);  // [col][point]
         for (uint32_t c = 0; c < qd; c++)
-            launch_bary_sums(ctx_, quotient_data.ldes[c], log_n, weights.p, 1, sums.p + 2 * w + 4 * c);
+            launch_bary_dots(ctx_, quotient_data.ldes[c], log_n, weights.p, 1, sums.p + 2 * w + 4 * c);
         d2h_sync(ctx_, raw.data(), sums.p, raw.size() * sizeof(Ef));
     }
     // p(z) = ((z/31)^n - 1)/n * sum_i p_i x_i/(z - x_i)
@@ -242,32 +248,31 @@ DevBuf<Ef> TwoAdicFriPcs::open_reduce(const PcsData& trace_data, const PcsData& 
         return acc;
     };
     DevBuf<Ef> ro(&ctx_, N);
-    uint64_t num_reduced = 0;  // :329, all matrices share log_height here
     {
-        ReduceArgs a;
+        // offsets follow two_adic_pcs.rs:371,383: num_reduced grows by the width after every
+        // (matrix, point); all matrices share log_height here
+        TS_REQUIRE(qd <= 16, TS_ERR_UNSUPPORTED, "open: more than 16 quotient chunks");
+        FusedReduceArgs a;
         memset(&a, 0, sizeof a);
-        a.n_points = 2;
-        a.accumulate = 0;
         a.z_mont[0] = pts_mont[0];
         a.z_mont[1] = pts_mont[1];
-        a.off_mont[0] = ef_pow(am, num_reduced);  // :371 alpha^num_reduced
-        a.rys[0] = reduced_ys(&opened_values[0], w);
+        uint64_t num_reduced = 0;
+        a.off_t[0] = ef_pow(am, num_reduced);
+        a.rys_t[0] = reduced_ys(&opened_values[0], w);
         num_reduced += w;
-        a.off_mont[1] = ef_pow(am, num_reduced);
-        a.rys[1] = reduced_ys(&opened_values[w], w);
+        a.off_t[1] = ef_pow(am, num_reduced);
+        a.rys_t[1] = reduced_ys(&opened_values[w], w);
         num_reduced += w;
-        launch_reduce(ctx_, tr, log_N, d_apow.p, a, ro.p);
-    }
-    for (uint32_t c = 0; c < qd; c++) {
-        ReduceArgs a;
-        memset(&a, 0, sizeof a);
-        a.n_points = 1;
-        a.accumulate = 1;
-        a.z_mont[0] = pts_mont[0];
-        a.off_mont[0] = ef_pow(am, num_reduced);
-        a.rys[0] = reduced_ys(&opened_values[2 * w + 4 * c], 4);
-        num_reduced += 4;
-        launch_reduce(ctx_, quotient_data.ldes[c], log_N, d_apow.p, a, ro.p);
+        a.n_chunks = qd;
+        a.chunk_stride = N;
+        for (uint32_t c = 0; c < qd; c++) {
+            TS_REQUIRE(quotient_data.ldes[c].col_stride == N, TS_ERR_INVALID, "open: chunk stride");
+            a.chunk[c] = quotient_data.ldes[c].d;
+            a.off_c[c] = ef_pow(am, num_reduced);
+            a.rys_c[c] = reduced_ys(&opened_values[2 * w + 4 * c], 4);
+            num_reduced += 4;
+        }
+        launch_reduce_fused(ctx_, tr, log_N, d_apow.p, a, ro.p);
     }
     ctx_.sync();  // pageable apow must outlive its async copy
     return ro;

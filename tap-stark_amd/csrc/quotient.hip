@@ -170,6 +170,18 @@ void launch_quotient(Context& ctx, const AirProgram& air, const ColMat& trace_ld
         qc.inv_zh_canonical[c] = inv_canon(sub(mul(s_pow_n, pow_canon(gqd, c)), 1));
     const uint32_t n_instr = (uint32_t)(air.code.size() / 4);
     const uint64_t total = 1ull << (log_n + log_qd);
+    if (air.jit_fn) {
+        // specialised straight-line kernel (jit.cpp); same arguments, same results
+        const uint32_t* lde_p = trace_lde.d;
+        uint64_t stride = trace_lde.col_stride;
+        QuotOut qo = out;
+        void* args[] = {&lde_p, &stride, &log_n, &log_qd, &d_consts_mont, &d_alpha_pows_mont,
+                        &is_first, &is_last, &is_transition, &qc, &qo};
+        KernelTimer kt(&ctx, "k_quotient_jit");
+        TS_HIP(hipModuleLaunchKernel((hipFunction_t)air.jit_fn, (unsigned)((total + 255) / 256), 1, 1,
+                                     256, 1, 1, 0, ctx.stream, args, nullptr));
+        return;
+    }
     // LDS register file: <= 48 KiB per workgroup
     int nthreads = 256;
     while (nthreads > 64 && (size_t)air.n_regs * nthreads * 4 > 48 * 1024) nthreads >>= 1;

@@ -158,6 +158,7 @@ class CompiledAir:
         ctx.check(ctx._l.ts_air_info(h, C.byref(w), C.byref(npub), C.byref(deg), C.byref(lqd)))
         self.width, self.n_public = int(w.value), int(npub.value)
         self.max_constraint_degree, self.log_quotient_degree = int(deg.value), int(lqd.value)
+        self.is_jit = bool(ctx._l.ts_air_is_jit(h))
 
     def __del__(self):
         try:

@@ -91,12 +91,17 @@ AIRS = [
 
 @pytest.mark.parametrize("name,make,has_pis", AIRS, ids=[a[0] for a in AIRS])
 @pytest.mark.parametrize("log_n", [3, 8, 13])
-def test_quotient_chunks(ctx, orc, name, make, has_pis, log_n):
+@pytest.mark.parametrize("jit", [True, False], ids=["jit", "interp"])
+def test_quotient_chunks(ctx, orc, monkeypatch, name, make, has_pis, log_n, jit):
+    # both quotient paths run on the GPU: the hiprtc-specialised kernel and the tape interpreter
+    if not jit:
+        monkeypatch.setenv("TS_NO_JIT", "1")
     b = 2
     air, trace = make(1 << log_n)
     pis = fibonacci_public_values(trace) if has_pis else np.zeros(0, dtype=np.uint32)
     tape = ts.air_tape(air, len(pis))
     cair = ts.CompiledAir(ctx, tape)
+    assert cair.is_jit == jit, "hiprtc specialisation expected on the GPU box"
     assert cair.log_quotient_degree == orc.log_quotient_degree(tape)
     assert cair.max_constraint_degree == orc.max_constraint_degree(tape)
     pcs = ts.TwoAdicFriPcs(ts.FriConfig(b, 4, 8), ctx)

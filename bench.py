@@ -61,19 +61,20 @@ def algorithmic_bytes_per_proof(n: int, w: int, b: int, qd: int) -> dict:
     return {
         "k_transpose_bitrev": 8 * n * w,
         "k_intt_contig": 8 * n * wall,
-        "k_intt_strided": 8 * n * wall,
-        "k_lde_fwd_strided": 4 * n * wall + 4 * N * wall,
+        "k_lde_mid<1>": 4 * n * wall + 4 * N * wall,
+        "k_lde_mid<0>": 4 * n * wall + 4 * N * wall,
         "k_lde_fwd_contig": 8 * N * wall,
         "k_leaf_hash": 4 * N * wall + 2 * 32 * N,
         "k_leaf_hash_ef_pairs": 16 * N + 16 * N,
-        "k_merkle_level": 96 * (N + N + N // 2),
+        # every parent reads 64 B and writes 32 B: two N-leaf trees + the FRI trees (N/2 + N/4 + ..)
+        "k_merkle_subtree<256>": 96 * (N + N + N // 2),
         "k_selectors": 12 * n * qd,
+        "k_quotient_jit": 4 * n * qd * w + 12 * n * qd + 16 * n * qd,
         "k_quotient<256>": 4 * n * qd * w + 12 * n * qd + 16 * n * qd,
         "k_bary_weights": 32 * n,
-        "k_bary_sums<2>": 4 * n * w + 32 * n,
-        "k_bary_sums<1>": qd * (16 * n + 16 * n),
-        "k_reduce<2>": 4 * N * w + 16 * N,
-        "k_reduce<1>": qd * (16 * N + 32 * N),
+        "(k_bary_dots<2, 64>)": 4 * n * w + 32 * n,
+        "(k_bary_dots<1, 8>)": qd * (16 * n + 16 * n),
+        "k_reduce_fused": 4 * N * wall + 16 * N,
         "k_fri_fold_pairs": 16 * fri_elems + 8 * fri_elems + 8 * fri_elems,
     }
 

@@ -303,4 +303,34 @@ void launch_fri_tail(Context& ctx, const Ef* in, uint32_t L0, uint32_t blowup, D
     TS_HIP(hipGetLastError());
 }
 
+// every commit-phase opening of every query in one launch (bf_answer_query, fri/src/prover.rs:69-90):
+// blockIdx.y = round; per query 8 value words (the row of two EF4) then 8*log_leaves path words
+__global__ void k_gather_fri(const FriGatherDesc* __restrict__ descs, const uint32_t* __restrict__ indices,
+                             uint32_t n_idx, uint32_t* __restrict__ out) {
+    const FriGatherDesc d = descs[blockIdx.y];
+    const uint32_t per_q = 8 + 8 * d.log_leaves;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_idx * per_q) return;
+    const uint32_t q = t / per_q, e = t % per_q;
+    const uint64_t row = indices[q] >> d.shift;
+    if (e < 8) {
+        out[d.out_vals + (uint64_t)q * 8 + e] = d.vec[8 * row + e];
+    } else {
+        const uint32_t l = (e - 8) >> 3, word = (e - 8) & 7;
+        uint64_t off = 0;
+        for (unsigned k = 0; k < l; k++) off += (uint64_t)1 << (d.log_leaves - k);
+        const uint64_t node = off + ((row >> l) ^ 1);
+        out[d.out_path + ((uint64_t)q * d.log_leaves + l) * 8 + word] = d.tree[8 * node + word];
+    }
+}
+void launch_gather_fri(Context& ctx, const FriGatherDesc* d_descs, uint32_t n_rounds,
+                       uint32_t max_log_leaves, const uint32_t* d_indices, uint32_t n_idx,
+                       uint32_t* out) {
+    if (!n_rounds || !n_idx) return;
+    const uint32_t per_q = 8 + 8 * max_log_leaves;
+    TS_LAUNCH(ctx, k_gather_fri, dim3((n_idx * per_q + 255) / 256, n_rounds), dim3(256), 0, d_descs,
+              d_indices, n_idx, out);
+    TS_HIP(hipGetLastError());
+}
+
 }  // namespace ts

@@ -50,7 +50,13 @@ void launch_leaf_hash(Context& ctx, const LeafMats& mats, uint64_t height, uint3
 // leaf digests of an array-of-EF4 vector taken as rows of two elements (FRI commit-phase matrix)
 void launch_leaf_hash_ef_pairs(Context& ctx, const uint32_t* vec, uint64_t n_rows, uint32_t* digests);
 // builds every upper level of the tree; `tree` holds level l at offset level_off(l) (in digests)
-void launch_merkle_levels(Context& ctx, uint32_t* tree, unsigned log_leaves);
+// If `ch` is given, the kernel that produces the root also observes it on the device challenger
+// and writes the root and the sampled challenge (returns false if no kernel could do it, i.e. the
+// tree is a single leaf).
+struct DevChallenger;
+bool launch_merkle_levels(Context& ctx, uint32_t* tree, unsigned log_leaves,
+                          DevChallenger* ch = nullptr, uint32_t* root_out = nullptr,
+                          Ef* beta_out = nullptr);
 inline uint64_t merkle_level_offset(unsigned log_leaves, unsigned level) {
     // levels are stored back to back: leaves first
     uint64_t off = 0;
@@ -131,5 +137,17 @@ void launch_gather_paths(Context& ctx, const uint32_t* tree, unsigned log_leaves
                          uint32_t* out);
 void launch_gather_ef_pairs(Context& ctx, const Ef* vec, const uint32_t* d_indices, uint32_t n_idx,
                             unsigned index_shift, uint32_t* out);
+// all commit-phase openings in one launch: one descriptor per FRI round (device array)
+struct FriGatherDesc {
+    const uint32_t* vec;   // committed vector as words (8 per row)
+    const uint32_t* tree;  // its Merkle tree
+    uint32_t log_leaves;
+    uint32_t shift;        // row = index >> shift
+    uint64_t out_vals;     // word offset of [query][8] in `out`
+    uint64_t out_path;     // word offset of [query][log_leaves][8] in `out`
+};
+void launch_gather_fri(Context& ctx, const FriGatherDesc* d_descs, uint32_t n_rounds,
+                       uint32_t max_log_leaves, const uint32_t* d_indices, uint32_t n_idx,
+                       uint32_t* out);
 
 }  // namespace ts

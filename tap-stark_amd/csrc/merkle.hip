@@ -5,6 +5,7 @@
 // Leaves: one thread per row; column-major matrices make every column read a coalesced 256 B
 // per wavefront.  Digests are stored as 8 consecutive words per node, levels back to back.
 #include "blake3.hpp"
+#include "chal_dev.hpp"
 #include "kernels.hpp"
 
 namespace ts {
@@ -109,11 +110,11 @@ k_merkle_top(uint32_t* __restrict__ tree, unsigned log_leaves, unsigned first_le
 // A workgroup reduces a subtree of S = 2^log_s consecutive nodes of level `first_level` to its
 // root (log_s levels), storing every intermediate level in the tree.  Between levels the digests
 // stay in LDS, word-interleaved ([word][node]) so that reads and writes are bank-conflict free.
-constexpr int SUBTREE_LOG = 11;  // 2048 children per workgroup
-template <int NTH>
+template <int NTH, int SUBTREE_LOG>
 __global__ void __launch_bounds__(NTH)
 k_merkle_subtree(uint32_t* __restrict__ tree, unsigned log_leaves, unsigned first_level,
-                 unsigned log_s, unsigned n_levels) {
+                 unsigned log_s, unsigned n_levels, DevChallenger* __restrict__ ch,
+                 uint32_t* __restrict__ root_out, Ef* __restrict__ beta_out) {
     __shared__ uint32_t bufA[8 * (1 << (SUBTREE_LOG - 1))];
     __shared__ uint32_t bufB[8 * (1 << (SUBTREE_LOG - 2))];
     uint64_t off = 0;
@@ -159,25 +160,61 @@ k_merkle_subtree(uint32_t* __restrict__ tree, unsigned log_leaves, unsigned firs
         n_level >>= 1;
         sub0 >>= 1;
     }
+    // device-resident transcript (fri/src/prover.rs:114-116): the workgroup that produced the root
+    // observes it and samples the next challenge, saving a kernel launch per FRI round
+    if (ch != nullptr && n_level == 1 && threadIdx.x == 0 && blockIdx.x == 0 && src != nullptr) {
+        uint32_t root[8];
+        for (int k = 0; k < 8; k++) {
+            root[k] = src[k * src_stride];
+            root_out[k] = root[k];
+        }
+        const Ef beta = dc_observe_root_and_sample(ch, root);
+        *reinterpret_cast<uint4*>(beta_out) = make_uint4(beta.c[0], beta.c[1], beta.c[2], beta.c[3]);
+    }
 }
 
-// Big levels: 2048 children per 256-thread workgroup, 3 levels per launch (4, 2, 1 compressions per
-// thread: every lane busy).  Once <= 2048 nodes remain, one 1024-thread workgroup finishes the tree.
-void launch_merkle_levels(Context& ctx, uint32_t* tree, unsigned log_leaves) {
+// Levels with more than 2^16 children: one launch per level (bandwidth-bound, ~3.7 TB/s of digest
+// traffic).  The last <= 16 levels are latency-bound (one Blake3 compression of ~680 dependent
+// instructions per level): they are done by at most two launches of the LDS subtree kernel, the
+// first with many small workgroups, the second with one workgroup that reaches the root (and, if
+// asked, feeds the device challenger).
+template <int NTH, int LOG_S>
+static void launch_subtree(Context& ctx, uint32_t* tree, unsigned log_leaves, unsigned level,
+                           unsigned log_s, unsigned n_levels, uint64_t n_sub, DevChallenger* ch,
+                           uint32_t* root_out, Ef* beta_out) {
+    TS_LAUNCH(ctx, (k_merkle_subtree<NTH, LOG_S>), dim3((unsigned)n_sub), dim3(NTH), 0, tree,
+              log_leaves, level, log_s, n_levels, ch, root_out, beta_out);
+}
+
+bool launch_merkle_levels(Context& ctx, uint32_t* tree, unsigned log_leaves, DevChallenger* ch,
+                          uint32_t* root_out, Ef* beta_out) {
     unsigned level = 0;
-    while (log_leaves - level > (unsigned)SUBTREE_LOG) {
-        const unsigned remaining = log_leaves - level;
-        const uint64_t n_sub = (uint64_t)1 << (remaining - SUBTREE_LOG);
-        TS_LAUNCH(ctx, k_merkle_subtree<256>, dim3((unsigned)n_sub), dim3(256), 0, tree, log_leaves,
-                  level, (unsigned)SUBTREE_LOG, 3u);
-        level += 3;
+    uint64_t off = 0;
+    while (log_leaves - level > 16) {
+        const uint64_t n_children = (uint64_t)1 << (log_leaves - level);
+        const uint64_t n_parents = n_children / 2;
+        TS_LAUNCH(ctx, k_merkle_level, dim3((unsigned)((n_parents + 255) / 256)), dim3(256), 0,
+                  reinterpret_cast<const uint4*>(tree + 8 * off),
+                  reinterpret_cast<uint4*>(tree + 8 * (off + n_children)), n_parents);
+        off += n_children;
+        level++;
     }
-    if (level < log_leaves) {
-        const unsigned remaining = log_leaves - level;
-        TS_LAUNCH(ctx, k_merkle_subtree<1024>, dim3(1), dim3(1024), 0, tree, log_leaves, level,
-                  remaining, remaining);
+    bool chal_done = false;
+    unsigned remaining = log_leaves - level;
+    if (remaining > 8) {  // first half: 2^(remaining - a) workgroups of 2^a children each
+        const unsigned a = (remaining + 1) / 2;  // <= 8
+        launch_subtree<128, 8>(ctx, tree, log_leaves, level, a, a, (uint64_t)1 << (remaining - a),
+                               nullptr, nullptr, nullptr);
+        level += a;
+        remaining -= a;
+    }
+    if (remaining > 0) {
+        launch_subtree<128, 8>(ctx, tree, log_leaves, level, remaining, remaining, 1, ch, root_out,
+                               beta_out);
+        chal_done = ch != nullptr;
     }
     TS_HIP(hipGetLastError());
+    return chal_done;
 }
 
 }  // namespace ts

@@ -384,10 +384,11 @@ std::vector<uint32_t> prove(TwoAdicFriPcs& pcs, const AirProgram& air, BfChallen
             } else {
                 tree = std::move(next_tree);  // leaves were hashed by the previous fold
             }
-            launch_merkle_levels(ctx, tree.p, r.log_leaves);  // :113 commit_matrix
             const size_t ri = rounds.size();
-            launch_chal_round(ctx, dch, tree.p + 8 * (merkle_total_digests(r.log_leaves) - 1),
-                              d_roots.p + 8 * ri, d_betas.p + ri);  // :114-116
+            // :113 commit_matrix, :114-116 observe + sample (in the kernel that makes the root)
+            if (!launch_merkle_levels(ctx, tree.p, r.log_leaves, dch, d_roots.p + 8 * ri, d_betas.p + ri))
+                launch_chal_round(ctx, dch, tree.p + 8 * (merkle_total_digests(r.log_leaves) - 1),
+                                  d_roots.p + 8 * ri, d_betas.p + ri);
             DevBuf<Ef> out(&ctx, h);
             uint32_t* nd = nullptr;
             if (h > fri.blowup() && h > (1ull << FRI_TAIL_LOG)) {  // next round is a big one too
@@ -483,11 +484,21 @@ std::vector<uint32_t> prove(TwoAdicFriPcs& pcs, const AirProgram& air, BfChallen
     launch_gather_paths(ctx, trace_data->tree.p, log_N, d_idx.p, Q, 0, d_out.p + o_tpath);
     launch_gather_rows(ctx, qlm, d_idx.p, Q, 0, d_out.p + o_qrows);
     launch_gather_paths(ctx, quotient_data->tree.p, log_N, d_idx.p, Q, 0, d_out.p + o_qpath);
-    for (uint32_t r = 0; r < R; r++) {  // bf_answer_query :69-90: index_i = index >> i >> 1
-        launch_gather_ef_pairs(ctx, rounds[r].vec, d_idx.p, Q, r + 1, d_out.p + o_fvals[r]);
-        launch_gather_paths(ctx, rounds[r].tree, rounds[r].log_leaves, d_idx.p, Q, r + 1,
-                            d_out.p + o_fpath[r]);
+    // bf_answer_query :69-90: index_i = index >> i >> 1, all rounds in one launch
+    std::vector<FriGatherDesc> descs(std::max(R, 1u));
+    uint32_t max_ll = 0;
+    for (uint32_t r = 0; r < R; r++) {
+        descs[r].vec = reinterpret_cast<const uint32_t*>(rounds[r].vec);
+        descs[r].tree = rounds[r].tree;
+        descs[r].log_leaves = rounds[r].log_leaves;
+        descs[r].shift = r + 1;
+        descs[r].out_vals = o_fvals[r];
+        descs[r].out_path = o_fpath[r];
+        max_ll = std::max(max_ll, rounds[r].log_leaves);
     }
+    DevBuf<FriGatherDesc> d_descs(&ctx, descs.size());
+    h2d(ctx, d_descs.p, descs.data(), descs.size() * sizeof(FriGatherDesc));
+    launch_gather_fri(ctx, d_descs.p, R, max_ll, d_idx.p, Q, d_out.p);
     std::vector<uint32_t> g(std::max<size_t>(off, 1));
     d2h_sync(ctx, g.data(), d_out.p, off * 4);
 

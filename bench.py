@@ -58,6 +58,10 @@ def algorithmic_bytes_per_proof(n: int, w: int, b: int, qd: int) -> dict:
     N = n << b
     wall = w + 4 * qd  # every committed column (trace + quotient chunks)
     fri_elems = 2 * N  # sum over rounds of the folded vector lengths (N + N/2 + ...)
+    # Merkle parents (64 B read + 32 B written each): two N-leaf trees + FRI trees (N/2 + N/4 + ..);
+    # levels with > 2^16 children go through k_merkle_level, the rest through the subtree kernel
+    parents_all = N + N + N // 2
+    small = 14 * (1 << 16)  # <= 2^16 parents per tree in the subtree kernels (14 trees reach it)
     return {
         "k_transpose_bitrev": 8 * n * w,
         "k_intt_contig": 8 * n * wall,
@@ -66,8 +70,8 @@ def algorithmic_bytes_per_proof(n: int, w: int, b: int, qd: int) -> dict:
         "k_lde_fwd_contig": 8 * N * wall,
         "k_leaf_hash": 4 * N * wall + 2 * 32 * N,
         "k_leaf_hash_ef_pairs": 16 * N + 16 * N,
-        # every parent reads 64 B and writes 32 B: two N-leaf trees + the FRI trees (N/2 + N/4 + ..)
-        "k_merkle_subtree<256>": 96 * (N + N + N // 2),
+        "k_merkle_level": 96 * max(parents_all - small, 0),
+        "(k_merkle_subtree<NTH, LOG_S>)": 96 * min(small, parents_all),
         "k_selectors": 12 * n * qd,
         "k_quotient_jit": 4 * n * qd * w + 12 * n * qd + 16 * n * qd,
         "k_quotient<256>": 4 * n * qd * w + 12 * n * qd + 16 * n * qd,
@@ -121,28 +125,18 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    from tapstark_amd.benchutil import init_dist, run_timed
 
-    dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist_mod
-
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        dist = dist_mod
+    env = init_dist()
+    if env.world != args.gpus and env.world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={env.world}")
 
     import tapstark_amd as ts
     from tapstark_amd.build import build
 
     if not os.path.exists(ts._lib.LIB_PATH):
         build()
-    ctx = ts.Context(local_rank)  # raises without a GPU: there is no fallback path
+    ctx = ts.Context(env.local_rank)  # raises without a GPU: there is no fallback path
 
     air, trace, pis, desc, cfg = workload(args.workload, args.log_n)
     n, w = trace.shape
@@ -154,34 +148,21 @@ def main():
     # reference's moved RowMajorMatrix, so one copy per step)
     total = args.warmup + args.steps
     mats = [ts.DeviceMatrix.upload(ctx, trace) for _ in range(total)]
+    last = {}
 
-    def barrier():
+    def step(i):
+        last["proof"] = ts.prove(config, cair, ts.BfChallenger(), mats[i], pis)
+
+    def local_sync():
         ctx.synchronize()
-        if dist is not None:
+        if env.dist is not None:
             import torch
             torch.cuda.synchronize()
-            dist.barrier()
 
-    proofs = []
-    for i in range(args.warmup):
-        proofs.append(ts.prove(config, cair, ts.BfChallenger(), mats[i], pis))
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.warmup, total):
-        p = ts.prove(config, cair, ts.BfChallenger(), mats[i], pis)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], device=f"cuda:{local_rank}", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    ms_per_step = 1e3 * elapsed / args.steps
-    proofs_per_sec = world * args.steps / elapsed
-    cells_per_sec = proofs_per_sec * n * w
+    res = run_timed(env, step, args.steps, args.warmup, local_sync, units_per_step=float(n * w))
 
     out = None
-    if rank == 0:
+    if env.rank == 0:
         # ---- roofline leg: per-kernel HIP-event timings over 3 extra (untimed) proofs
         reps = 3
         extra = [ts.DeviceMatrix.upload(ctx, trace) for _ in range(reps)]
@@ -197,7 +178,7 @@ def main():
         stage_sum = {}
         for k, v in stages:  # a stage name can occur twice (trace commit, quotient commit)
             stage_sum[k] = round(stage_sum.get(k, 0.0) + v, 3)
-        alg =algorithmic_bytes_per_proof(n, w, cfg[0], qd)
+        alg = algorithmic_bytes_per_proof(n, w, cfg[0], qd)
         per_kernel = {}
         for name, (cnt, ms) in kt.items():
             ms_pp = ms / reps
@@ -217,23 +198,24 @@ def main():
                     "alg_bytes_per_proof": alg.get(dom),
                     "kernel_ms_total_per_proof": round(sum(v[1] for v in kt.values()) / reps, 3)}
         cpu = None if args.no_cpu_baseline else cpu_baseline()
+        proof = last["proof"]
         out = {
             "metric": "trace cells/sec (proofs/sec alongside), 2^20x64 BabyBear trace",
-            "value": cells_per_sec, "unit": "trace cells/sec", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "value": res["value"], "unit": "trace cells/sec", "n_gpus": env.world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
+            "data": "synthetic",
             "config": {"workload": desc, "rows": n, "width": w, "log_blowup": cfg[0],
                        "num_queries": cfg[1], "proof_of_work_bits": cfg[2], "quotient_degree": qd,
-                       "parallelism": "1 proof per GPU (replicas)" if world > 1 else "1 GPU",
-                       "proof_words": int(len(p.words))},
-            "proofs_per_sec": proofs_per_sec,
+                       "parallelism": "1 proof per GPU (replicas)" if env.world > 1 else "1 GPU",
+                       "quotient_kernel": "hiprtc-specialised" if cair.is_jit else "interpreter",
+                       "proof_words": int(len(proof.words))},
+            "proofs_per_sec": res["steps_per_sec"],
             "roofline": roofline, "cpu_baseline": cpu,
             "stages_ms": stage_sum,
             "kernels": per_kernel,
         }
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    env.close()
     if out is not None:
         print(json.dumps(out))
 

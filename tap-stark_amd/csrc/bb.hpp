@@ -49,18 +49,12 @@ TS_HD uint32_t mulhi32(uint32_t a, uint32_t b) {
 }
 
 // Montgomery reduction of t < p * 2^32: returns t * 2^-32 mod p in [0, p).
-// m = lo * p^-1 mod 2^32 with p^-1 = 2^31 + 2^27 + 1 costs two shift-adds instead of a
-// quarter-rate 32-bit multiply.
+// (Measured on gfx950, tools/microbench*.hip: every 3-operand VOP3 integer op -- v_mul_lo_u32,
+// v_mul_hi_u32, v_mad_u64_u32, v_lshl_add_u32, v_alignbit_b32 -- costs ~2.5 issue slots against 1
+// for a VOP2 add/sub/min, so one v_mul_lo_u32 beats the two shift-adds that p^-1 = 2^31+2^27+1
+// would allow.)
 TS_HD uint32_t mont_reduce(uint64_t t) {
-    uint32_t lo = (uint32_t)t;
-#if defined(__HIP_DEVICE_COMPILE__)
-    // (inline asm keeps LLVM from folding the two shift-adds back into a v_mul_lo_u32)
-    uint32_t t1, m;
-    asm("v_lshl_add_u32 %0, %1, 27, %1" : "=v"(t1) : "v"(lo));
-    asm("v_lshl_add_u32 %0, %1, 31, %2" : "=v"(m) : "v"(lo), "v"(t1));
-#else
-    uint32_t m = lo + (lo << 27) + (lo << 31);
-#endif
+    uint32_t m = (uint32_t)t * P_INV;
     uint32_t u = mulhi32(m, P);
     uint32_t r = (uint32_t)(t >> 32) - u;
     return umin32(r, r + P);

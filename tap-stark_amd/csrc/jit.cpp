@@ -60,9 +60,7 @@ __device__ __forceinline__ u32 add(u32 a, u32 b) { u32 s = a + b; return umin32(
 __device__ __forceinline__ u32 sub(u32 a, u32 b) { u32 d = a - b; return umin32(d, d + P); }
 __device__ __forceinline__ u32 neg(u32 a) { return a ? P - a : 0u; }
 __device__ __forceinline__ u32 mont_reduce(u64 t) {
-    u32 lo = (u32)t, t1, m;
-    asm("v_lshl_add_u32 %0, %1, 27, %1" : "=v"(t1) : "v"(lo));
-    asm("v_lshl_add_u32 %0, %1, 31, %2" : "=v"(m) : "v"(lo), "v"(t1));
+    u32 m = (u32)t * 0x88000001u;
     u32 u = __umulhi(m, P);
     u32 r = (u32)(t >> 32) - u;
     return umin32(r, r + P);
@@ -71,15 +69,10 @@ __device__ __forceinline__ u32 mont_mul(u32 a, u32 b) { return mont_reduce((u64)
 __device__ __forceinline__ u32 to_mont(u32 a) { return mont_mul(a, 0x45dddde3u); }
 __device__ __forceinline__ u64 lazy_fix(u64 acc) {
     u32 hi = (u32)(acc >> 32);
-    u32 mask = (u32)((int)hi >> 31);
-    hi -= mask & P;
+    hi = umin32(hi, hi - P);
     return ((u64)hi << 32) | (u32)acc;
 }
-__device__ __forceinline__ u32 lazy_finish(u64 acc) {
-    u32 hi = (u32)(acc >> 32);
-    hi = umin32(hi, hi - P);
-    return mont_reduce(((u64)hi << 32) | (u32)acc);
-}
+__device__ __forceinline__ u32 lazy_finish(u64 acc) { return mont_reduce(lazy_fix(acc)); }
 struct QC { u32 inv_zh[16]; };
 struct QO { u32* chunk[16]; };
 extern "C" __global__ void __launch_bounds__(256)

@@ -23,18 +23,16 @@ __device__ __forceinline__ uint32_t root_bitrev(const uint32_t* __restrict__ W, 
 __device__ __forceinline__ uint64_t lazy_mac(uint64_t acc, uint32_t a, uint32_t b) {
     return acc + (uint64_t)a * b;
 }
+// Invariant: acc < p*2^32 (2^62.91) after a fix; two products (each < p^2 < 2^61.82) later it is
+// still < 2p*2^32, so its high word is < 2p and one conditional subtraction of p (sub + min, two
+// VOP2 ops) restores the invariant without changing acc mod p.
 __device__ __forceinline__ uint64_t lazy_fix(uint64_t acc) {
     uint32_t hi = (uint32_t)(acc >> 32);
-    uint32_t mask = (uint32_t)((int32_t)hi >> 31);
-    hi -= mask & P;
+    hi = umin32(hi, hi - P);
     return ((uint64_t)hi << 32) | (uint32_t)acc;
 }
-// final: acc < 2^63 -> acc * 2^-32 mod p, canonical
-__device__ __forceinline__ uint32_t lazy_finish(uint64_t acc) {
-    uint32_t hi = (uint32_t)(acc >> 32);  // < 2^31 <= ... may still be >= p
-    hi = umin32(hi, hi - P);
-    return mont_reduce(((uint64_t)hi << 32) | (uint32_t)acc);
-}
+// final: acc < 2p*2^32 -> acc * 2^-32 mod p, canonical
+__device__ __forceinline__ uint32_t lazy_finish(uint64_t acc) { return mont_reduce(lazy_fix(acc)); }
 
 // ------------------------------------------------------------------ barycentric weights
 // out[p][t] = x_t / (z_p - x_t), x_t = 31 * omega_n^bitrev(t)   (Montgomery EF4)
@@ -246,8 +244,7 @@ __device__ __forceinline__ Ef row_dot_alpha(const uint32_t* __restrict__ m, uint
             a3 = lazy_fix(a3);
         }
     }
-    return Ef{{lazy_finish(lazy_fix(a0)), lazy_finish(lazy_fix(a1)), lazy_finish(lazy_fix(a2)),
-               lazy_finish(lazy_fix(a3))}};
+    return Ef{{lazy_finish(a0), lazy_finish(a1), lazy_finish(a2), lazy_finish(a3)}};
 }
 
 // 1/(x - z_p) for NP points with one shared base-field inversion (Montgomery)

@@ -123,6 +123,9 @@ def main():
     ap.add_argument("--workload", default="config3", choices=["config3", "config2"])
     ap.add_argument("--log-n", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("TS_BENCH_STREAMS", "4")),
+                    help="independent proofs in flight per GPU (one context = one HIP stream and one "
+                         "host thread each); the K timed steps are shared among them")
     args = ap.parse_args()
 
     from tapstark_amd.benchutil import init_dist, run_timed
@@ -136,7 +139,9 @@ def main():
 
     if not os.path.exists(ts._lib.LIB_PATH):
         build()
-    ctx = ts.Context(env.local_rank)  # raises without a GPU: there is no fallback path
+    # one GPU per rank (TS_BENCH_SHARE_GPU=1 lets a rehearsal put every rank on GPU 0)
+    dev = 0 if os.environ.get("TS_BENCH_SHARE_GPU") else env.local_rank
+    ctx = ts.Context(dev)  # raises without a GPU: there is no fallback path
 
     air, trace, pis, desc, cfg = workload(args.workload, args.log_n)
     n, w = trace.shape
@@ -144,22 +149,50 @@ def main():
     cair = ts.CompiledAir(ctx, ts.air_tape(air, len(pis)))
     qd = 1 << cair.log_quotient_degree
 
+    # Proofs are independent, so S of them are kept in flight per GPU: S contexts (one HIP stream,
+    # one device pool and one host thread each).  The serial transcript of one proof leaves the
+    # GPU idle at its host round trips; the next proof's kernels fill those gaps.
+    S = max(1, min(args.streams, args.steps))
+    lanes = [(ctx, config, cair)]
+    for _ in range(1, S):
+        c2 = ts.Context(dev)
+        lanes.append((c2, ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(*cfg), c2)),
+                      ts.CompiledAir(c2, ts.air_tape(air, len(pis)))))
+
     # inputs resident in HBM before the timed region (prove() consumes its trace, like the
-    # reference's moved RowMajorMatrix, so one copy per step)
+    # reference's moved RowMajorMatrix, so one copy per step); step i runs on lane i % S
     total = args.warmup + args.steps
-    mats = [ts.DeviceMatrix.upload(ctx, trace) for _ in range(total)]
+    mats = [ts.DeviceMatrix.upload(lanes[i % S][0], trace) for i in range(total)]
     last = {}
 
-    def step(i):
-        last["proof"] = ts.prove(config, cair, ts.BfChallenger(), mats[i], pis)
+    def prove_one(i):
+        c, conf, ca = lanes[i % S]
+        last["proof"] = ts.prove(conf, ca, ts.BfChallenger(), mats[i], pis)
+
+    if S == 1:
+        step = prove_one
+        run_steps = None
+    else:
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=S)
+        step = prove_one
+
+        def run_steps(first, count):
+            # lane l proves steps first+l, first+l+S, ... in its own thread (ctypes drops the GIL)
+            def lane_job(l):
+                for i in range(first + l, first + count, S):
+                    prove_one(i)
+            list(pool.map(lane_job, range(S)))
 
     def local_sync():
-        ctx.synchronize()
-        if env.dist is not None:
+        for c, _, _ in lanes:
+            c.synchronize()
+        if env.dist is not None and env.device is not None:
             import torch
             torch.cuda.synchronize()
 
-    res = run_timed(env, step, args.steps, args.warmup, local_sync, units_per_step=float(n * w))
+    res = run_timed(env, step, args.steps, args.warmup, local_sync, units_per_step=float(n * w),
+                    run_steps=run_steps)
 
     out = None
     if env.rank == 0:
@@ -207,7 +240,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": desc, "rows": n, "width": w, "log_blowup": cfg[0],
                        "num_queries": cfg[1], "proof_of_work_bits": cfg[2], "quotient_degree": qd,
-                       "parallelism": "1 proof per GPU (replicas)" if env.world > 1 else "1 GPU",
+                       "parallelism": ("1 rank per GPU (replicas)" if env.world > 1 else "1 GPU")
+                                      + f", {S} proofs in flight per GPU",
                        "quotient_kernel": "hiprtc-specialised" if cair.is_jit else "interpreter",
                        "proof_words": int(len(proof.words))},
             "proofs_per_sec": res["steps_per_sec"],

@@ -86,6 +86,7 @@ void ts_matrix_free(ts_ctx* ctx, ts_matrix* m);
  * ops (symbolic_expression.rs:12-37): 0 CONST(a=value) 1 MAIN(a=offset 0|1,b=column)
  *   2 PUBLIC(a=index) 3 IS_FIRST_ROW 4 IS_LAST_ROW 5 IS_TRANSITION 6 ADD(a,b) 7 SUB(a,b) 8 NEG(a)
  *   9 MUL(a,b) */
+/* ctx == NULL builds a host-only AIR (degree rules + verifier use; no kernels) */
 ts_status ts_air_compile(ts_ctx* ctx, const uint32_t* tape, size_t n_words, ts_air** out);
 /* get_log_quotient_degree, uni-stark/src/symbolic_builder.rs:15-32 */
 ts_status ts_air_info(const ts_air* air, uint32_t* width, uint32_t* n_public,
@@ -161,6 +162,16 @@ void ts_chal_state(const ts_challenger* c, uint32_t out[34]);
 ts_status ts_prove(ts_ctx* ctx, const ts_fri_config* cfg, const ts_air* air, ts_challenger* chal,
                    ts_matrix* trace, const uint32_t* public_values, uint32_t n_public,
                    uint32_t* proof_out, size_t cap_words, size_t* n_words_out);
+
+/* ------------------------------------------------------------------ verify (host only) */
+/* uni_stark::verify (uni-stark/src/verifier.rs:19-25; pcs.verify fri/src/two_adic_pcs.rs:421-534;
+ * fri/src/verifier.rs:20-165).  Needs no GPU: `air` may come from ts_air_compile(NULL, ...).
+ * *verdict: 0 accept, 1 InvalidProofShape, 2 InvalidOpeningArgument (FRI shape), 3 InvalidPowWitness,
+ * 4 input-MMCS error, 5 commit-phase MMCS error, 6 FinalPolyMismatch, 7 OodEvaluationMismatch,
+ * 8 folded-evaluation mismatch (the reference asserts), 9 malformed proof buffer. */
+ts_status ts_verify(const ts_fri_config* cfg, const ts_air* air, ts_challenger* chal,
+                    const uint32_t* proof, size_t n_words, const uint32_t* public_values,
+                    uint32_t n_public, int* verdict);
 
 /* library/ABI version (bumped on any incompatible change) */
 uint32_t ts_abi_version(void);

@@ -62,7 +62,10 @@ def init_dist(backend: Optional[str] = None) -> DistEnv:
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+    # TS_BENCH_BACKEND=gloo rehearses the N > 1 path on boxes where RCCL cannot be used (e.g. all
+    # ranks sharing one GPU); the default on GPUs is nccl (= RCCL on ROCm)
+    backend = backend or os.environ.get("TS_BENCH_BACKEND") or (
+        "nccl" if torch.cuda.is_available() else "gloo")
     device = None
     if backend == "nccl":
         torch.cuda.set_device(local_rank)
@@ -74,15 +77,20 @@ def init_dist(backend: Optional[str] = None) -> DistEnv:
 
 
 def run_timed(env: DistEnv, step: Callable[[int], None], steps: int, warmup: int,
-              local_sync: Callable[[], None], units_per_step: float) -> dict:
-    """W untimed warm-up steps, then K timed steps bracketed by barrier + device sync on both
-    sides; returns the job-level numbers (identical on every rank)."""
-    for i in range(warmup):
-        step(i)
+              local_sync: Callable[[], None], units_per_step: float,
+              run_steps: Optional[Callable[[int, int], None]] = None) -> dict:
+    """W untimed warm-up steps, then EXACTLY K timed steps bracketed by barrier + device sync on
+    both sides; returns the job-level numbers (identical on every rank).  `run_steps(first, count)`
+    may replace the sequential loop (e.g. to keep several independent steps in flight); it must
+    complete exactly the steps first .. first+count-1."""
+    if run_steps is None:
+        def run_steps(first, count):
+            for i in range(first, first + count):
+                step(i)
+    run_steps(0, warmup)
     env.barrier(local_sync)
     t0 = time.perf_counter()
-    for i in range(warmup, warmup + steps):
-        step(i)
+    run_steps(warmup, steps)
     env.barrier(local_sync)
     elapsed = env.max_over_ranks(time.perf_counter() - t0)
     total_units = env.sum_over_ranks(units_per_step * steps)

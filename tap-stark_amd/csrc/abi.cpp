@@ -208,8 +208,15 @@ void ts_matrix_free(ts_ctx* ctx, ts_matrix* m) {
 
 // ------------------------------------------------------------------ AIR
 ts_status ts_air_compile(ts_ctx* ctx, const uint32_t* tape, size_t n_words, ts_air** out) {
-    if (!ctx || !out) return TS_ERR_INVALID;
+    if (!out) return TS_ERR_INVALID;
     *out = nullptr;
+    if (!ctx) {  // host-only AIR (no GPU needed): usable by ts_verify
+        return guard(nullptr, [&] {
+            auto a = std::make_unique<ts_air>();
+            a->prog = ts::compile_air(tape, n_words);
+            *out = a.release();
+        });
+    }
     return guard(ctx, [&] {
         auto a = std::make_unique<ts_air>();
         a->prog = ts::compile_air(tape, n_words);
@@ -420,6 +427,23 @@ ts_status ts_prove(ts_ctx* ctx, const ts_fri_config* cfg, const ts_air* air, ts_
         *n_words_out = proof.size();
         TS_REQUIRE(proof.size() <= cap_words, ts::TS_ERR_BUFFER, "proof buffer too small");
         memcpy(proof_out, proof.data(), proof.size() * 4);
+    });
+}
+
+// ------------------------------------------------------------------ verify
+ts_status ts_verify(const ts_fri_config* cfg, const ts_air* air, ts_challenger* chal,
+                    const uint32_t* proof, size_t n_words, const uint32_t* public_values,
+                    uint32_t n_public, int* verdict) {
+    if (!air || !chal || !proof || !verdict) return TS_ERR_INVALID;
+    *verdict = -1;
+    return guard(nullptr, [&] {
+        ts::FriConfig f = load_cfg(cfg);
+        std::vector<uint32_t> pis;
+        if (n_public) {
+            TS_REQUIRE(public_values, ts::TS_ERR_INVALID, "null public values");
+            pis.assign(public_values, public_values + n_public);
+        }
+        *verdict = ts::verify(f, air->prog, chal->c, proof, n_words, pis);
     });
 }
 

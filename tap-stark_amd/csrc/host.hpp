@@ -5,6 +5,7 @@
 #pragma once
 #include <stdint.h>
 
+#include <algorithm>
 #include <memory>
 #include <vector>
 
@@ -113,5 +114,12 @@ private:
 // uni-stark/src/prover.rs:25-119.  Returns the proof in TSPF v1 words.
 std::vector<uint32_t> prove(TwoAdicFriPcs& pcs, const AirProgram& air, BfChallenger& challenger,
                             DeviceMatrix trace, const std::vector<uint32_t>& public_values);
+
+// ------------------------------------------------------------------ verify (host only)
+// uni-stark/src/verifier.rs:19-161.  0 = accept; 1 InvalidProofShape, 2 InvalidOpeningArgument
+// (FRI proof shape), 3 InvalidPowWitness, 4 input MMCS error, 5 commit-phase MMCS error,
+// 6 FinalPolyMismatch, 7 OodEvaluationMismatch, 8 folded evaluation mismatch, 9 malformed buffer.
+int verify(const FriConfig& fri, const AirProgram& air, BfChallenger& challenger,
+           const uint32_t* proof, size_t n_words, const std::vector<uint32_t>& public_values);
 
 }  // namespace ts

@@ -148,22 +148,28 @@ class DeviceMatrix:
 
 
 class CompiledAir:
-    def __init__(self, ctx: Context, tape):
+    """``ts_air``.  With ``ctx=None`` the AIR is host-only (degree rules, ``verify``): no GPU."""
+
+    def __init__(self, ctx: "Context | None", tape):
         self.ctx = ctx
+        self._l = _lib.lib()
         self.tape = _u32(tape)
         h = C.c_void_p()
-        ctx.check(ctx._l.ts_air_compile(ctx.h, _p(self.tape), len(self.tape), C.byref(h)))
+        rc = self._l.ts_air_compile(ctx.h if ctx else None, _p(self.tape), len(self.tape), C.byref(h))
+        if rc:
+            msg = self._l.ts_last_error(ctx.h if ctx else None) or b""
+            raise _lib.TsError(rc, msg.decode())
         self.h = h
         w, npub, deg, lqd = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
-        ctx.check(ctx._l.ts_air_info(h, C.byref(w), C.byref(npub), C.byref(deg), C.byref(lqd)))
+        self._l.ts_air_info(h, C.byref(w), C.byref(npub), C.byref(deg), C.byref(lqd))
         self.width, self.n_public = int(w.value), int(npub.value)
         self.max_constraint_degree, self.log_quotient_degree = int(deg.value), int(lqd.value)
-        self.is_jit = bool(ctx._l.ts_air_is_jit(h))
+        self.is_jit = bool(self._l.ts_air_is_jit(h))
 
     def __del__(self):
         try:
-            if self.h and self.ctx.h:
-                self.ctx._l.ts_air_free(self.ctx.h, self.h)
+            if self.h and (self.ctx is None or self.ctx.h):
+                self._l.ts_air_free(self.ctx.h if self.ctx else None, self.h)
         except Exception:
             pass
 
@@ -218,9 +224,9 @@ class PcsData:
 class TwoAdicFriPcs:
     """reference fri/src/two_adic_pcs.rs:38-61,203-419 on the device."""
 
-    def __init__(self, fri: FriConfig, ctx: Context | None = None):
+    def __init__(self, fri: FriConfig, ctx: Context | None = None, host_only: bool = False):
         self.fri = fri
-        self.ctx = ctx or default_context()
+        self.ctx = None if host_only else (ctx or default_context())
 
     def natural_domain_for_degree(self, degree: int):
         return (degree.bit_length() - 1, 1)  # (log_n, shift), two_adic_pcs.rs:220-226
@@ -438,3 +444,36 @@ def prove(config: StarkConfig, air, challenger: BfChallenger, trace, public_valu
     ctx.check(ctx._l.ts_prove(ctx.h, C.byref(cfg), air.h, challenger.h, trace.h, pis_p, len(pis),
                               _p(out), cap, C.byref(n_words)))
     return Proof.parse(out[: n_words.value].copy())
+
+
+VERIFY_ERRORS = {0: "Ok", 1: "InvalidProofShape", 2: "InvalidOpeningArgument(InvalidProofShape)",
+                 3: "InvalidOpeningArgument(InvalidPowWitness)", 4: "InvalidOpeningArgument(InputError)",
+                 5: "InvalidOpeningArgument(CommitPhaseMmcsError)",
+                 6: "InvalidOpeningArgument(FinalPolyMismatch)", 7: "OodEvaluationMismatch",
+                 8: "folded evaluation mismatch", 9: "malformed proof"}
+
+
+class VerificationError(Exception):
+    """reference uni-stark/src/verifier.rs:163-171 / fri/src/error.rs:21-29"""
+
+    def __init__(self, code: int):
+        super().__init__(VERIFY_ERRORS.get(code, str(code)))
+        self.code = code
+
+
+def verify(config: StarkConfig, air, challenger: BfChallenger, proof, public_values) -> None:
+    """``uni_stark::verify`` (reference uni-stark/src/verifier.rs:19-25); host only, no GPU.
+    Raises ``VerificationError``; returns None on acceptance (``Ok(())``)."""
+    pis = _u32(public_values)
+    if isinstance(air, BaseAir):
+        air = CompiledAir(None, air_tape(air, len(pis)))
+    words = _u32(proof.words if isinstance(proof, Proof) else proof)
+    cfg = config.pcs.fri._c()
+    verdict = C.c_int(-1)
+    l = _lib.lib()
+    rc = l.ts_verify(C.byref(cfg), air.h, challenger.h, _p(words), len(words),
+                     _p(pis) if len(pis) else None, len(pis), C.byref(verdict))
+    if rc:
+        raise _lib.TsError(rc, "ts_verify")
+    if verdict.value != 0:
+        raise VerificationError(verdict.value)

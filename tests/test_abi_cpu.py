@@ -86,3 +86,68 @@ def test_clone_is_independent(lib):
     assert a.sample().tolist() == b.sample().tolist()
     a.observe(1)
     assert a.state().tolist() != b.state().tolist()
+
+
+# ------------------------------------------------------------------ native verifier (host only)
+def _cases():
+    from tapstark_amd.airs import (SynthExtAir, fibonacci_public_values, generate_fibonacci_trace,
+                                   generate_synth_ext_trace, generate_synth_mul_trace)
+    t = generate_fibonacci_trace(0, 1, 8)
+    yield "fib8", FibonacciAir(), t, fibonacci_public_values(t), (2, 28, 8)
+    t = generate_fibonacci_trace(2, 7, 64)
+    yield "fib64_b1", FibonacciAir(), t, fibonacci_public_values(t), (1, 7, 8)
+    yield "mul64", SynthMulAir(64), generate_synth_mul_trace(32), np.zeros(0, dtype=np.uint32), (2, 9, 8)
+    yield "mul7_b3", SynthMulAir(7), generate_synth_mul_trace(16, 7), np.zeros(0, dtype=np.uint32), (3, 5, 4)
+    yield "ext25", SynthExtAir(25), generate_synth_ext_trace(64, 25), np.zeros(0, dtype=np.uint32), (2, 6, 8)
+
+
+def test_native_verifier_accepts_oracle_proofs_and_agrees_on_tampering(lib, orc):
+    """uni_stark::verify shipped in the product (host C++), against the oracle's restatement:
+    same verdict on valid proofs and on every single-word corruption tried."""
+    rng = np.random.default_rng(7)
+    for name, air, trace, pis, cfg in _cases():
+        tape = ts.air_tape(air, len(pis))
+        ocfg = orc.FriConfig(*cfg)
+        proof = orc.prove(ocfg, tape, trace, pis)
+        config = ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(*cfg), host_only=True))
+        chal = ts.BfChallenger()
+        ts.verify(config, air, chal, proof, pis)  # Ok(())
+        ochal = orc.OracleChallenger()
+        assert orc.verify(ocfg, tape, proof, pis, ochal) == 0
+        assert chal.state()[:16].tolist() == list(ochal.c.state), "verifier transcripts differ"
+        positions = list(rng.integers(5, len(proof), size=40)) + [len(proof) - 1, len(proof) - 5, 5, 13]
+        for pos in positions:
+            bad = proof.copy()
+            bad[pos] = (int(bad[pos]) + 1) % 0x78000001
+            want = orc.verify(ocfg, tape, bad, pis)
+            try:
+                ts.verify(config, air, ts.BfChallenger(), bad, pis)
+                got = 0
+            except ts.VerificationError as e:
+                got = e.code
+            assert (got == 0) == (want == 0), (name, pos, got, want)
+            if want != 0:
+                assert got == want, (name, pos, got, want)
+        # wrong public values / wrong query count / truncated
+        if len(pis):
+            wrong = pis.copy()
+            wrong[-1] = (int(wrong[-1]) + 1) % 0x78000001
+            with pytest.raises(ts.VerificationError) as ei:
+                ts.verify(config, air, ts.BfChallenger(), proof, wrong)
+            assert ei.value.code == 7
+        other = ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(cfg[0], cfg[1] + 1, cfg[2]), host_only=True))
+        with pytest.raises(ts.VerificationError) as ei:
+            ts.verify(other, air, ts.BfChallenger(), proof, pis)
+        assert ei.value.code == 2
+        with pytest.raises(ts.VerificationError) as ei:
+            ts.verify(config, air, ts.BfChallenger(), proof[:-2], pis)
+        assert ei.value.code == 9
+
+
+def test_host_only_air_reports_degrees(lib, orc):
+    for air, npub in ((FibonacciAir(), 3), (SynthMulAir(64), 0)):
+        tape = ts.air_tape(air, npub)
+        cair = ts.CompiledAir(None, tape)
+        assert cair.log_quotient_degree == orc.log_quotient_degree(tape) == ts.get_log_quotient_degree(air, npub)
+        assert cair.max_constraint_degree == orc.max_constraint_degree(tape)
+        assert not cair.is_jit

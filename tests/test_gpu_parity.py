@@ -173,6 +173,9 @@ def test_prove_bit_identical_to_oracle(ctx, orc, name, make, has_pis, cfg):
     ochal = orc.OracleChallenger()
     want = orc.prove(ocfg, tape, trace, pis, ochal)
     assert orc.verify(ocfg, tape, proof.words, pis) == 0, "oracle verifier rejects the GPU proof"
+    # the reference's own test shape (uni-stark/tests/fib_air.rs:144-148): prove, then verify with
+    # a fresh challenger -- here with the product's native verifier
+    ts.verify(config, air, ts.BfChallenger(), proof, pis)
     assert len(proof.words) == len(want)
     assert (proof.words == want).all(), f"{int((proof.words != want).sum())} proof words differ"
     # the caller's challenger must end in the same transcript state (prover.rs takes &mut)

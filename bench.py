@@ -223,9 +223,25 @@ def main():
         dom = max(kt.items(), key=lambda kv: kv[1][1])[0]
         dom_ms_pp = kt[dom][1] / reps
         achieved = alg.get(dom, 0) / (dom_ms_pp * 1e-3)
+        # HBM traffic of that kernel from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE and
+        # --pmc WRITE_SIZE in separate passes, KiB units, FETCH_SIZE doubled for gfx950:
+        # profiles/*_pmc_traffic.json, made from tools/prof_prove.py); bytes per launch, or null
+        traffic = None
+        try:
+            import glob
+            pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+            if pmc_files and args.workload == "config3" and args.log_n == 20:
+                pk = json.load(open(pmc_files[-1]))["kernels"].get(dom)
+                if pk:
+                    traffic = round((pk["fetch_bytes_per_proof_corrected"] + pk["write_bytes_per_proof"])
+                                    / pk["launches_per_proof"])
+        except Exception:
+            traffic = None
+        lpp = kt[dom][0] / reps
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved / 1e9, 2),
                     "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 4),
-                    "traffic": None,
+                    "traffic": traffic,
+                    "alg_bytes_per_launch": round(alg.get(dom, 0) / lpp) if lpp else None,
                     "avg_launch_ms": round(kt[dom][1] / kt[dom][0], 5),
                     "launches_per_proof": kt[dom][0] / reps,
                     "alg_bytes_per_proof": alg.get(dom),

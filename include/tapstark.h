@@ -163,6 +163,13 @@ ts_status ts_prove(ts_ctx* ctx, const ts_fri_config* cfg, const ts_air* air, ts_
                    ts_matrix* trace, const uint32_t* public_values, uint32_t n_public,
                    uint32_t* proof_out, size_t cap_words, size_t* n_words_out);
 
+/* check_constraints (uni-stark/src/check_constraints.rs:11-39; what a debug build of prove() runs
+ * first, prover.rs:40-41) on the GPU.  `trace` is NOT consumed.  *first_violation = -1 if every
+ * constraint holds on every row, else row * 65536 + constraint index of the first failure. */
+ts_status ts_check_constraints(ts_ctx* ctx, const ts_air* air, const ts_matrix* trace,
+                               const uint32_t* public_values, uint32_t n_public,
+                               int64_t* first_violation);
+
 /* ------------------------------------------------------------------ verify (host only) */
 /* uni_stark::verify (uni-stark/src/verifier.rs:19-25; pcs.verify fri/src/two_adic_pcs.rs:421-534;
  * fri/src/verifier.rs:20-165).  Needs no GPU: `air` may come from ts_air_compile(NULL, ...).

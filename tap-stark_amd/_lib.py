@@ -24,7 +24,7 @@ ABI_SYMBOLS = [
     "ts_pcs_data_info", "ts_pcs_data_digests", "ts_pcs_open_batch", "ts_pcs_data_free",
     "ts_quotient_chunks", "ts_pcs_open_reduce", "ts_fri_fold", "ts_chal_new", "ts_chal_clone",
     "ts_chal_free", "ts_chal_observe", "ts_chal_observe_commitment", "ts_chal_sample",
-    "ts_chal_sample_bits", "ts_chal_check_witness", "ts_chal_grind", "ts_chal_state", "ts_prove", "ts_verify",
+    "ts_chal_sample_bits", "ts_chal_check_witness", "ts_chal_grind", "ts_chal_state", "ts_prove", "ts_verify", "ts_check_constraints",
 ]
 
 STATUS = {0: "TS_OK", 1: "TS_ERR_INVALID", 2: "TS_ERR_HIP", 3: "TS_ERR_OOM",
@@ -103,6 +103,8 @@ def lib() -> C.CDLL:
         l.ts_fri_fold.argtypes = [C.c_void_p, u32p, C.c_uint64, u32p, u32p]
         l.ts_prove.argtypes = [C.c_void_p, C.POINTER(FriConfigC), C.c_void_p, C.c_void_p, C.c_void_p,
                                u32p, C.c_uint32, u32p, C.c_size_t, C.POINTER(C.c_size_t)]
+        l.ts_check_constraints.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, u32p, C.c_uint32,
+                                           C.POINTER(C.c_int64)]
         l.ts_verify.argtypes = [C.POINTER(FriConfigC), C.c_void_p, C.c_void_p, u32p, C.c_size_t, u32p,
                                 C.c_uint32, C.POINTER(C.c_int)]
         _lib = l

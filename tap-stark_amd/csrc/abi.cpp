@@ -430,6 +430,38 @@ ts_status ts_prove(ts_ctx* ctx, const ts_fri_config* cfg, const ts_air* air, ts_
     });
 }
 
+// ------------------------------------------------------------------ check_constraints
+ts_status ts_check_constraints(ts_ctx* ctx, const ts_air* air, const ts_matrix* trace,
+                               const uint32_t* public_values, uint32_t n_public,
+                               int64_t* first_violation) {
+    if (!ctx || !air || !trace || !first_violation) return TS_ERR_INVALID;
+    *first_violation = -1;
+    return guard(ctx, [&] {
+        const ts::AirProgram& p = air->prog;
+        TS_REQUIRE(trace->m.buf.p && trace->m.layout == ts::DeviceMatrix::ROW_MAJOR, ts::TS_ERR_INVALID,
+                   "check_constraints: needs an uploaded (row-major, unconsumed) trace");
+        TS_REQUIRE(trace->m.width == p.width, ts::TS_ERR_INVALID, "check_constraints: width != AIR width");
+        TS_REQUIRE(n_public == p.n_public, ts::TS_ERR_INVALID, "check_constraints: public value count");
+        std::vector<uint32_t> consts(std::max<size_t>(p.const_canonical.size(), 1), 0);
+        for (size_t k = 0; k < p.const_canonical.size(); k++) {
+            uint32_t v = p.const_public_idx[k] != ~0u ? public_values[p.const_public_idx[k]]
+                                                      : p.const_canonical[k];
+            TS_REQUIRE(v < ts::P, ts::TS_ERR_INVALID, "non-canonical public value");
+            consts[k] = ts::to_mont(v);
+        }
+        ts::DevBuf<uint32_t> d_consts(&ctx->ctx, consts.size());
+        ts::DevBuf<unsigned long long> d_v(&ctx->ctx, 1);
+        TS_HIP(hipMemcpyAsync(d_consts.p, consts.data(), consts.size() * 4, hipMemcpyHostToDevice,
+                              ctx->ctx.stream));
+        TS_HIP(hipMemsetAsync(d_v.p, 0xff, 8, ctx->ctx.stream));
+        ts::launch_check_constraints(ctx->ctx, p, trace->m.buf.p, trace->m.height, d_consts.p, d_v.p);
+        unsigned long long v = 0;
+        TS_HIP(hipMemcpyAsync(&v, d_v.p, 8, hipMemcpyDeviceToHost, ctx->ctx.stream));
+        ctx->ctx.sync();
+        *first_violation = v == ~0ull ? -1 : (int64_t)v;
+    });
+}
+
 // ------------------------------------------------------------------ verify
 ts_status ts_verify(const ts_fri_config* cfg, const ts_air* air, ts_challenger* chal,
                     const uint32_t* proof, size_t n_words, const uint32_t* public_values,

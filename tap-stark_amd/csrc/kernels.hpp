@@ -79,6 +79,12 @@ void launch_quotient(Context& ctx, const AirProgram& air, const ColMat& trace_ld
                      const uint32_t* is_first, const uint32_t* is_last, const uint32_t* is_transition,
                      const QuotOut& out);
 
+// check_constraints.rs:11-39 on the row-major trace; *d_violation (preset to ~0) receives
+// row * 2^16 + constraint index of the first violated constraint
+void launch_check_constraints(Context& ctx, const AirProgram& air, const uint32_t* trace_row_major,
+                              uint64_t n, const uint32_t* d_consts_mont,
+                              unsigned long long* d_violation);
+
 // ---- open.hip --------------------------------------------------------------------------------
 // d[p][i] = x_i / (z_p - x_i) (Montgomery EF4) for the low coset 31*H_n in bit-reversed order,
 // for up to 2 points; out layout [point][n] of Ef

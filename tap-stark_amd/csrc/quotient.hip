@@ -200,4 +200,69 @@ void launch_quotient(Context& ctx, const AirProgram& air, const ColMat& trace_ld
     TS_HIP(hipGetLastError());
 }
 
+// ------------------------------------------------------------------ check_constraints
+// reference uni-stark/src/check_constraints.rs:11-39 (debug builds of prove(), prover.rs:40-41):
+// every constraint must vanish on every row of the trace itself, with is_first_row = (i == 0),
+// is_last_row = (i == h-1), is_transition = (i != h-1) and the next row wrapping around.
+// One thread per row of the row-major trace; the first violation (row * 2^16 + constraint index,
+// smallest wins) is left in *violation.
+template <int NTHREADS>
+__global__ void __launch_bounds__(NTHREADS)
+k_check_constraints(const uint32_t* __restrict__ code, uint32_t n_instr, const uint32_t* __restrict__ trace,
+                    uint32_t width, uint64_t n, const uint32_t* __restrict__ consts_mont,
+                    unsigned long long* __restrict__ violation) {
+    extern __shared__ uint32_t regs[];
+    const uint64_t i = (uint64_t)blockIdx.x * NTHREADS + threadIdx.x;
+    const bool active = i < n;
+    const uint64_t ii = active ? i : 0;
+    const uint32_t* row_local = trace + ii * width;
+    const uint32_t* row_next = trace + ((ii + 1) % n) * width;
+    const uint32_t sel0 = ii == 0 ? R_MOD_P : 0u;
+    const uint32_t sel1 = ii == n - 1 ? R_MOD_P : 0u;
+    const uint32_t sel2 = ii != n - 1 ? R_MOD_P : 0u;
+    uint32_t* my = regs + threadIdx.x;
+    unsigned long long bad = ~0ull;
+    for (uint32_t pc = 0; pc < n_instr; pc++) {
+        const uint32_t op = code[4 * pc], dst = code[4 * pc + 1], a = code[4 * pc + 2],
+                       b = code[4 * pc + 3];
+        uint32_t v;
+        switch (op) {
+            case D_LOAD: v = to_mont((a ? row_next : row_local)[b]); break;
+            case D_CONST: v = consts_mont[a]; break;
+            case D_SEL: v = a == 0 ? sel0 : (a == 1 ? sel1 : sel2); break;
+            case D_ADD: v = add(my[a * NTHREADS], my[b * NTHREADS]); break;
+            case D_SUB: v = sub(my[a * NTHREADS], my[b * NTHREADS]); break;
+            case D_NEG: v = neg(my[a * NTHREADS]); break;
+            case D_MUL: v = mont_mul(my[a * NTHREADS], my[b * NTHREADS]); break;
+            default: {  // D_ASSERT
+                if (my[a * NTHREADS] != 0 && bad == ~0ull) bad = ii * 65536ull + b;
+                continue;
+            }
+        }
+        my[dst * NTHREADS] = v;
+    }
+    if (active && bad != ~0ull) atomicMin(violation, bad);
+}
+
+void launch_check_constraints(Context& ctx, const AirProgram& air, const uint32_t* trace_row_major,
+                              uint64_t n, const uint32_t* d_consts_mont,
+                              unsigned long long* d_violation) {
+    TS_REQUIRE(air.d_code != nullptr, TS_ERR_INVALID, "air program not uploaded");
+    const uint32_t n_instr = (uint32_t)(air.code.size() / 4);
+    int nthreads = 256;
+    while (nthreads > 64 && (size_t)air.n_regs * nthreads * 4 > 48 * 1024) nthreads >>= 1;
+    TS_REQUIRE((size_t)air.n_regs * nthreads * 4 <= 64 * 1024, TS_ERR_UNSUPPORTED,
+               "constraint program needs too many live registers for the interpreter");
+    const size_t lds = (size_t)air.n_regs * nthreads * 4;
+    const unsigned grid = (unsigned)((n + nthreads - 1) / nthreads);
+#define TS_LAUNCH_C(NTH)                                                                       \
+    TS_LAUNCH(ctx, k_check_constraints<NTH>, dim3(grid), dim3(NTH), lds, air.d_code, n_instr,  \
+              trace_row_major, air.width, n, d_consts_mont, d_violation)
+    if (nthreads == 256) TS_LAUNCH_C(256);
+    else if (nthreads == 128) TS_LAUNCH_C(128);
+    else TS_LAUNCH_C(64);
+#undef TS_LAUNCH_C
+    TS_HIP(hipGetLastError());
+}
+
 }  // namespace ts

@@ -477,3 +477,18 @@ def verify(config: StarkConfig, air, challenger: BfChallenger, proof, public_val
         raise _lib.TsError(rc, "ts_verify")
     if verdict.value != 0:
         raise VerificationError(verdict.value)
+
+
+def check_constraints(air, trace, public_values, ctx: Context | None = None) -> int:
+    """reference uni-stark/src/check_constraints.rs:11-39 on the GPU.  Returns -1 if every
+    constraint holds on every row, else ``row * 65536 + constraint_index`` of the first failure."""
+    ctx = ctx or default_context()
+    pis = _u32(public_values)
+    if isinstance(air, BaseAir):
+        air = CompiledAir(ctx, air_tape(air, len(pis)))
+    if not isinstance(trace, DeviceMatrix):
+        trace = DeviceMatrix.upload(ctx, trace)
+    out = C.c_int64(-1)
+    ctx.check(ctx._l.ts_check_constraints(ctx.h, air.h, trace.h, _p(pis) if len(pis) else None,
+                                          len(pis), C.byref(out)))
+    return int(out.value)

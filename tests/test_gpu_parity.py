@@ -264,3 +264,56 @@ def test_full_size_proof_is_accepted(ctx, orc, name, make, has_pis, cfg):
     bad[30] = (int(bad[30]) + 1) % P
     assert orc.verify(ocfg, tape, bad, pis) != 0
     assert p1.degree_bits == 20 and len(p1.commit_phase_commits) == 20
+
+
+# ------------------------------------------------------------------ check_constraints on the GPU
+def test_check_constraints_matches_oracle(ctx, orc):
+    # reference uni-stark/src/check_constraints.rs:11-39 (what a debug build of prove() runs first)
+    fib = FibonacciAir()
+    t = generate_fibonacci_trace(0, 1, 1 << 10)
+    pis = fibonacci_public_values(t)
+    tape = ts.air_tape(fib, 3)
+    assert ts.check_constraints(fib, t, pis, ctx) == -1 == orc.check_constraints(tape, t, pis)
+    for row, col in ((5, 1), (0, 0), (1023, 1), (700, 0)):
+        bad = t.copy()
+        bad[row, col] = (int(bad[row, col]) + 1) % P
+        assert ts.check_constraints(fib, bad, pis, ctx) == orc.check_constraints(tape, bad, pis) >= 0
+    wrong_pis = np.array([0, 1, 5], dtype=np.uint32)
+    assert ts.check_constraints(fib, t, wrong_pis, ctx) == orc.check_constraints(tape, t, wrong_pis) >= 0
+    for air, tr in ((SynthMulAir(64), generate_synth_mul_trace(1 << 9)),
+                    (SynthExtAir(163), generate_synth_ext_trace(1 << 7, 163))):
+        tp = ts.air_tape(air, 0)
+        assert ts.check_constraints(air, tr, [], ctx) == -1
+        bad = tr.copy()
+        bad[77, 2] = (int(bad[77, 2]) + 3) % P
+        assert ts.check_constraints(air, bad, [], ctx) == orc.check_constraints(tp, bad, []) >= 0
+
+
+# ------------------------------------------------------------------ the other BASELINE shapes
+def test_config4_shape_single_gpu(ctx, orc):
+    """BASELINE config 4's shape on ONE GPU (n = 2^22 x 64, log_blowup 4, 16 queries): a 16 GiB LDE,
+    the three-round strided NTT plan, 22 FRI rounds; accepted by the oracle's verifier."""
+    air = SynthMulAir(64)
+    trace = generate_synth_mul_trace(1 << 22)
+    tape = ts.air_tape(air, 0)
+    cfg = (4, 16, 8)
+    config = ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(*cfg), ctx))
+    proof = ts.prove(config, air, ts.BfChallenger(), trace, [])
+    assert orc.verify(orc.FriConfig(*cfg), tape, proof.words, []) == 0
+    ts.verify(config, air, ts.BfChallenger(), proof, [])
+    assert proof.degree_bits == 22 and len(proof.commit_phase_commits) == 22
+
+
+def test_config5_shape(ctx, orc):
+    """BASELINE config 5's stand-in (SynthExt-163: EF4 column groups, width 163, log_blowup 4,
+    16 queries) at 2^18 rows: 652-byte leaves (11 Blake3 blocks) and a wide quotient program."""
+    air = SynthExtAir(163)
+    trace = generate_synth_ext_trace(1 << 18, 163)
+    tape = ts.air_tape(air, 0)
+    cfg = (4, 16, 8)
+    config = ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(*cfg), ctx))
+    proof = ts.prove(config, air, ts.BfChallenger(), trace, [])
+    assert orc.verify(orc.FriConfig(*cfg), tape, proof.words, []) == 0
+    bad = proof.words.copy()
+    bad[40] = (int(bad[40]) + 1) % P
+    assert orc.verify(orc.FriConfig(*cfg), tape, bad, []) != 0

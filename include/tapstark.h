@@ -108,6 +108,8 @@ ts_status ts_pcs_commit(ts_ctx* ctx, const ts_fri_config* cfg, uint32_t n_mats,
  * bit-reversed row order, N x width */
 ts_status ts_pcs_data_lde(ts_ctx* ctx, const ts_pcs_data* d, uint32_t idx, uint32_t* host_row_major);
 ts_status ts_pcs_data_info(const ts_pcs_data* d, uint32_t* n_mats, uint32_t* log_height);
+/* height (LDE rows) and width of committed matrix `idx`; log_height above is the tallest one's */
+ts_status ts_pcs_data_matrix_info(const ts_pcs_data* d, uint32_t idx, uint64_t* height, uint32_t* width);
 /* Merkle digest layer `level` (0 = leaves), (N >> level) x 8 words */
 ts_status ts_pcs_data_digests(ts_ctx* ctx, const ts_pcs_data* d, uint32_t level, uint32_t* host_out);
 /* BFMmcs::open_batch (bf_mmcs.rs:37-42; taptree_mmcs.rs:46-63): rows of every matrix at `index`
@@ -132,6 +134,23 @@ ts_status ts_pcs_open_reduce(ts_ctx* ctx, const ts_fri_config* cfg, const ts_pcs
                              const ts_pcs_data* quotient_data, const uint32_t zeta[4],
                              const uint32_t batch_alpha[4], uint32_t* opened_out,
                              uint32_t* reduced_out);
+
+/* Pcs::open, fri/src/two_adic_pcs.rs:260-419, for any rounds x matrices x points (the shapes of
+ * fri/tests/pcs.rs:62-90 and uni-stark/src/prover.rs:94-104 alike; matrices of different heights in
+ * one batch and several batches are allowed).  Samples the batch challenge from `chal`, computes the
+ * opened values and runs bf_prove (fri/src/prover.rs:19-63) on the reduced openings.
+ *   rounds[r]   committed batches (Pcs::ProverData), in the order the verifier will list them
+ *   n_points[k] number of opening points of matrix k, k running over (round, matrix)
+ *   points      4 canonical words per point, in the same order
+ *   opened_out  EF4 values in (round, matrix, point, column) order
+ *   proof_out   the FriProof in TSPF v1 words (commit-phase round count first; DESIGN.md "Proof
+ *               format"); per query the input proof holds one BatchOpening per round
+ * TS_ERR_BUFFER if a buffer is too small (the needed sizes are still written). */
+ts_status ts_pcs_open(ts_ctx* ctx, const ts_fri_config* cfg, ts_challenger* chal, uint32_t n_rounds,
+                      const ts_pcs_data* const* rounds, const uint32_t* n_points,
+                      const uint32_t* points, uint32_t* opened_out, size_t opened_cap_words,
+                      size_t* n_opened_words, uint32_t* proof_out, size_t proof_cap_words,
+                      size_t* n_proof_words);
 
 /* FriGenericConfig::fold_matrix, two_adic_pcs.rs:116-147 (host in, host out; 2h EF4 -> h EF4) */
 ts_status ts_fri_fold(ts_ctx* ctx, const uint32_t* in, uint64_t h, const uint32_t beta[4],

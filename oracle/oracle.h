@@ -177,6 +177,14 @@ int ts_or_pcs_roundtrip(const ts_or_fri_config* cfg, int n_rounds, const int* ma
 int ts_or_fri_roundtrip(const ts_or_fri_config* cfg, int n_inputs, const unsigned* log_lens,
                         const uint32_t* const* inputs, int base_field, int perm_kind);
 
+/* fri/tests/pcs.rs:62-90 with everything returned (commit every round, observe, sample zeta, open
+ * every matrix at zeta); see stark.c */
+int64_t ts_or_pcs_commit_open(const ts_or_fri_config* cfg, ts_or_challenger* chal, int n_rounds,
+                              const int* mats_per_round, const unsigned* log_degrees,
+                              const size_t* widths, const uint32_t* const* evals,
+                              uint32_t* roots_out, uint32_t* zeta_out, uint32_t* opened_out,
+                              uint32_t* proof_out, size_t cap_words);
+
 #ifdef __cplusplus
 }
 #endif

@@ -336,3 +336,31 @@ def fri_roundtrip(cfg: FriConfig, inputs, sample_ext: bool = True, perm_kind: in
     return int(lib().ts_or_fri_roundtrip(C.byref(cfg), k, (C.c_uint * k)(*logs),
                                          (u32p * k)(*[_p(v) for v in inputs]), int(sample_ext),
                                          perm_kind))
+
+
+def pcs_commit_open(cfg: FriConfig, log_degrees_by_round, evals_by_round,
+                    chal: OracleChallenger | None = None):
+    """fri/tests/pcs.rs:62-90 flow on the oracle: returns (roots, zeta, opened (sum_w x 4), proof)."""
+    flat_logs, flat_w, flat_e, per_round = [], [], [], []
+    for logs, evs in zip(log_degrees_by_round, evals_by_round):
+        per_round.append(len(logs))
+        for lg, e in zip(logs, evs):
+            e = _u32(e)
+            flat_logs.append(lg)
+            flat_w.append(e.shape[1])
+            flat_e.append(e)
+    k = len(flat_e)
+    chal = chal or OracleChallenger()
+    roots = np.zeros((len(per_round), 8), dtype=np.uint32)
+    zeta = np.zeros(4, dtype=np.uint32)
+    opened = np.zeros((sum(flat_w), 4), dtype=np.uint32)
+    cap = 1 << 22
+    proof = np.zeros(cap, dtype=np.uint32)
+    lib().ts_or_pcs_commit_open.restype = C.c_int64
+    n = lib().ts_or_pcs_commit_open(
+        C.byref(cfg), C.byref(chal.c), len(per_round), (C.c_int * len(per_round))(*per_round),
+        (C.c_uint * k)(*flat_logs), (C.c_size_t * k)(*flat_w), (u32p * k)(*[_p(e) for e in flat_e]),
+        _p(roots), _p(zeta), _p(opened), _p(proof), C.c_size_t(cap))
+    if n < 0:
+        raise RuntimeError(f"oracle pcs_commit_open failed: {n}")
+    return roots, zeta, opened, proof[:n].copy()

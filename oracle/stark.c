@@ -913,3 +913,54 @@ int ts_or_fri_roundtrip(const ts_or_fri_config* cfg, int n_inputs, const unsigne
     free(buf);
     return rc;
 }
+
+/* ------------------------------------------------------ Pcs::commit + Pcs::open, exported
+ * The pcs.rs flow (fri/tests/pcs.rs:62-90) with everything returned, so that the GPU path can be
+ * compared bit for bit: commit every round, observe the commitments, sample zeta, open every matrix
+ * at zeta.  roots_out: n_rounds x 8 words; opened_out: sum(widths) x 4 words in (round, matrix,
+ * column) order; proof_out: the FriProof part of the TSPF format.  Returns proof words or < 0. */
+int64_t ts_or_pcs_commit_open(const ts_or_fri_config* cfg, ts_or_challenger* chal, int n_rounds,
+                              const int* mats_per_round, const unsigned* log_degrees,
+                              const size_t* widths, const uint32_t* const* evals,
+                              uint32_t* roots_out, uint32_t* zeta_out, uint32_t* opened_out,
+                              uint32_t* proof_out, size_t cap_words) {
+    ts_or_mmcs_data* datas[16];
+    int k = 0;
+    for (int r = 0; r < n_rounds; r++) {
+        dom_t doms[16];
+        for (int i = 0; i < mats_per_round[r]; i++) {
+            doms[i].log_n = log_degrees[k + i];
+            doms[i].shift = 1;
+        }
+        datas[r] = pcs_commit(cfg, mats_per_round[r], doms, evals + k, widths + k, roots_out + 8 * r);
+        k += mats_per_round[r];
+    }
+    for (int r = 0; r < n_rounds; r++) ts_or_chal_observe_digest(chal, roots_out + 8 * r);
+    ef4 zeta = chal_sample_ef(chal);
+    memcpy(zeta_out, zeta.c, 16);
+    open_round rounds[16];
+    int npts[16][16];
+    const ef4* ppts[16][16];
+    size_t total_w = 0;
+    for (int r = 0; r < n_rounds; r++) {
+        for (int i = 0; i < mats_per_round[r]; i++) {
+            npts[r][i] = 1;
+            ppts[r][i] = &zeta;
+        }
+        rounds[r].data = datas[r];
+        rounds[r].n_points = npts[r];
+        rounds[r].points = ppts[r];
+    }
+    for (int i = 0; i < k; i++) total_w += widths[i];
+    ef4* opened = (ef4*)malloc((total_w + 1) * sizeof(ef4));
+    size_t n_opened = 0;
+    ts_or_wbuf b;
+    wb_init(&b, proof_out, cap_words);
+    int rc = pcs_open(cfg, n_rounds, rounds, chal, opened, &n_opened, &b);
+    memcpy(opened_out, opened, n_opened * 16);
+    free(opened);
+    for (int r = 0; r < n_rounds; r++) ts_or_mmcs_free(datas[r]);
+    if (rc) return rc;
+    if (b.overflow) return -1;
+    return (int64_t)b.len;
+}

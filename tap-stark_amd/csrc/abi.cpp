@@ -296,6 +296,12 @@ ts_status ts_pcs_data_lde(ts_ctx* ctx, const ts_pcs_data* d, uint32_t idx, uint3
         ctx->ctx.sync();
     });
 }
+ts_status ts_pcs_data_matrix_info(const ts_pcs_data* d, uint32_t idx, uint64_t* height, uint32_t* width) {
+    if (!d || !d->d || idx >= d->d->ldes.size()) return TS_ERR_INVALID;
+    if (height) *height = d->d->ldes[idx].height;
+    if (width) *width = d->d->ldes[idx].width;
+    return TS_OK;
+}
 ts_status ts_pcs_data_digests(ts_ctx* ctx, const ts_pcs_data* d, uint32_t level, uint32_t* host) {
     if (!ctx || !d || !d->d || !host) return TS_ERR_INVALID;
     return guard(ctx, [&] {
@@ -361,6 +367,44 @@ ts_status ts_pcs_open_reduce(ts_ctx* ctx, const ts_fri_config* cfg, const ts_pcs
                                   ctx->ctx.stream));
             ctx->ctx.sync();
         }
+    });
+}
+
+ts_status ts_pcs_open(ts_ctx* ctx, const ts_fri_config* cfg, ts_challenger* chal, uint32_t n_rounds,
+                      const ts_pcs_data* const* rounds, const uint32_t* n_points,
+                      const uint32_t* points, uint32_t* opened_out, size_t opened_cap_words,
+                      size_t* n_opened_words, uint32_t* proof_out, size_t proof_cap_words,
+                      size_t* n_proof_words) {
+    if (!ctx || !chal || !rounds || !n_points || !opened_out || !n_opened_words || !proof_out ||
+        !n_proof_words || n_rounds == 0)
+        return TS_ERR_INVALID;
+    *n_opened_words = *n_proof_words = 0;
+    return guard(ctx, [&] {
+        ts::TwoAdicFriPcs pcs(ctx->ctx, load_cfg(cfg));
+        std::vector<ts::TwoAdicFriPcs::OpenRound> rs(n_rounds);
+        size_t k = 0, pw = 0;
+        for (uint32_t r = 0; r < n_rounds; r++) {
+            TS_REQUIRE(rounds[r] && rounds[r]->d, ts::TS_ERR_INVALID, "open: null round data");
+            rs[r].data = rounds[r]->d.get();
+            rs[r].points.resize(rs[r].data->ldes.size());
+            for (auto& pl : rs[r].points) {
+                const uint32_t np = n_points[k++];
+                TS_REQUIRE(np == 0 || points, ts::TS_ERR_INVALID, "open: null points");
+                for (uint32_t p = 0; p < np; p++, pw += 4) {
+                    for (int j = 0; j < 4; j++)
+                        TS_REQUIRE(points[pw + j] < ts::P, ts::TS_ERR_INVALID, "open: non-canonical point");
+                    pl.push_back(load_ef(points + pw));
+                }
+            }
+        }
+        std::vector<ts::Ef> opened;
+        std::vector<uint32_t> proof = pcs.open(rs, chal->c, opened);
+        *n_opened_words = opened.size() * 4;
+        *n_proof_words = proof.size();
+        TS_REQUIRE(opened.size() * 4 <= opened_cap_words, ts::TS_ERR_BUFFER, "opened-values buffer too small");
+        TS_REQUIRE(proof.size() <= proof_cap_words, ts::TS_ERR_BUFFER, "proof buffer too small");
+        memcpy(opened_out, opened.data(), opened.size() * sizeof(ts::Ef));
+        memcpy(proof_out, proof.data(), proof.size() * 4);
     });
 }
 

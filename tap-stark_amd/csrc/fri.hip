@@ -114,12 +114,12 @@ __global__ void k_gather_rows(LeafMats mats, const uint32_t* __restrict__ indice
     if (t >= n_idx * total) return;
     const uint32_t q = t / total;
     uint32_t c = t % total;
-    const uint64_t row = indices[q] >> shift;
     uint32_t mi = 0;
     while (c >= mats.width[mi]) {
         c -= mats.width[mi];
         mi++;
     }
+    const uint64_t row = ((uint64_t)indices[q] >> shift) >> mats.row_shift[mi];
     out[t] = mats.d[mi][(uint64_t)c * mats.col_stride[mi] + row];
 }
 void launch_gather_rows(Context& ctx, const LeafMats& mats, const uint32_t* d_indices,

@@ -101,6 +101,22 @@ public:
     DevBuf<Ef> open_reduce(const PcsData& trace_data, const PcsData& quotient_data, Ef zeta,
                            Ef batch_alpha, std::vector<Ef>& opened_values);
 
+    // two_adic_pcs.rs:260-419 for any rounds x matrices x points: samples the batch challenge,
+    // computes the opened values ((round, matrix, point, column) order) and returns the FriProof
+    // (TSPF v1 words from the commit-phase round count on).
+    struct OpenRound {
+        const PcsData* data = nullptr;
+        std::vector<std::vector<Ef>> points;  // per matrix, canonical EF4
+    };
+    std::vector<uint32_t> open(const std::vector<OpenRound>& rounds, BfChallenger& challenger,
+                               std::vector<Ef>& opened_values);
+
+    // fri/src/prover.rs:19-141 bf_prove over the reduced openings (strictly descending heights),
+    // with the input openings of two_adic_pcs.rs:399-414; appends the FriProof to `pf`
+    void fri_prove(std::vector<DevBuf<Ef>>& inputs, const std::vector<unsigned>& log_lens,
+                   BfChallenger& challenger, const std::vector<const PcsData*>& input_rounds,
+                   std::vector<uint32_t>& pf);
+
     // BFMmcs::open_batch
     void open_batch(const PcsData& d, uint64_t index, std::vector<uint32_t>& rows,
                     std::vector<uint32_t>& path);

@@ -39,6 +39,9 @@ struct LeafMats {
     const uint32_t* d[MAX_BATCH_MATS];
     uint64_t col_stride[MAX_BATCH_MATS];
     uint32_t width[MAX_BATCH_MATS];
+    // row of matrix i opened for leaf index r: r >> row_shift[i] (log_max_height - log_height_i;
+    // basic/src/mmcs/bf_mmcs.rs:37-42)
+    uint8_t row_shift[MAX_BATCH_MATS];
     uint32_t n_mats;
     uint32_t total_width;
     // device array of total_width column base pointers (column c of the concatenated row), so
@@ -57,6 +60,11 @@ struct DevChallenger;
 bool launch_merkle_levels(Context& ctx, uint32_t* tree, unsigned log_leaves,
                           DevChallenger* ch = nullptr, uint32_t* root_out = nullptr,
                           Ef* beta_out = nullptr);
+// mixed-height batches: one level at a time, with the digests of the rows of the matrices whose
+// height equals the level's node count compressed into the nodes (node = Blake3(node || inj))
+void launch_merkle_one_level(Context& ctx, const uint32_t* children, uint32_t* parents,
+                             uint64_t n_parents);
+void launch_merkle_inject(Context& ctx, uint32_t* nodes, const uint32_t* inj, uint64_t n);
 inline uint64_t merkle_level_offset(unsigned log_leaves, unsigned level) {
     // levels are stored back to back: leaves first
     uint64_t off = 0;

@@ -80,6 +80,31 @@ k_merkle_level(const uint4* __restrict__ children, uint4* __restrict__ parents, 
     parents[2 * i + 1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
 }
 
+void launch_merkle_one_level(Context& ctx, const uint32_t* children, uint32_t* parents,
+                             uint64_t n_parents) {
+    TS_LAUNCH(ctx, k_merkle_level, dim3((unsigned)((n_parents + 255) / 256)), dim3(256), 0,
+              reinterpret_cast<const uint4*>(children), reinterpret_cast<uint4*>(parents), n_parents);
+    TS_HIP(hipGetLastError());
+}
+
+// mixed-height injection: nodes[i] = Blake3(nodes[i] || inj[i])
+__global__ void __launch_bounds__(256)
+k_merkle_inject(uint4* __restrict__ nodes, const uint4* __restrict__ inj, uint64_t n) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint4 a = nodes[2 * i], b = nodes[2 * i + 1], c = inj[2 * i], d = inj[2 * i + 1];
+    uint32_t m[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+    uint32_t cv[8];
+    b3::hash64(m, cv);
+    nodes[2 * i] = make_uint4(cv[0], cv[1], cv[2], cv[3]);
+    nodes[2 * i + 1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
+}
+void launch_merkle_inject(Context& ctx, uint32_t* nodes, const uint32_t* inj, uint64_t n) {
+    TS_LAUNCH(ctx, k_merkle_inject, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+              reinterpret_cast<uint4*>(nodes), reinterpret_cast<const uint4*>(inj), n);
+    TS_HIP(hipGetLastError());
+}
+
 // the top of the tree (<= 512 children) in one workgroup: avoids ~9 tiny launches per tree
 __global__ void __launch_bounds__(256)
 k_merkle_top(uint32_t* __restrict__ tree, unsigned log_leaves, unsigned first_level) {

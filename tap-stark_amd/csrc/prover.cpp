@@ -50,6 +50,7 @@ LeafMats PcsData::leaf_mats() const {
         lm.d[i] = ldes[i].d;
         lm.col_stride[i] = ldes[i].col_stride;
         lm.width[i] = ldes[i].width;
+        lm.row_shift[i] = (uint8_t)(log_height - log2_strict(ldes[i].height));
         lm.total_width += ldes[i].width;
     }
     lm.cols = col_table.p;
@@ -57,19 +58,23 @@ LeafMats PcsData::leaf_mats() const {
 }
 
 // ------------------------------------------------------------------ commit
+// Matrices of different heights share one tree (basic/src/mmcs/bf_mmcs.rs:22-35 commits a mixed batch;
+// the tree itself is build-defined, see merkle.hip): leaves hash the rows of the tallest matrices,
+// and the rows of the matrices of height h are compressed into the level that has h nodes.
 std::unique_ptr<PcsData> TwoAdicFriPcs::commit(std::vector<DeviceMatrix>& evals,
                                                const std::vector<uint32_t>& domain_shifts) {
     TS_REQUIRE(!evals.empty() && evals.size() <= (size_t)MAX_BATCH_MATS, TS_ERR_INVALID,
                "commit: between 1 and 16 matrices per batch");
     TS_REQUIRE(evals.size() == domain_shifts.size(), TS_ERR_INVALID, "commit: one domain per matrix");
-    const uint64_t n = evals[0].height;
+    uint64_t max_n = 0;
+    bool uniform = true;
     for (auto& m : evals) {
-        TS_REQUIRE(m.height == n, TS_ERR_UNSUPPORTED,
-                   "commit: matrices of different heights in one batch are not supported yet");
         TS_REQUIRE(m.width >= 1 && m.buf.p, TS_ERR_INVALID, "commit: empty matrix");
+        log2_strict(m.height);
+        max_n = std::max(max_n, m.height);
+        uniform = uniform && m.height == evals[0].height;
     }
-    const unsigned log_n = log2_strict(n);
-    const unsigned log_N = log_n + fri_.log_blowup;
+    const unsigned log_N = log2_strict(max_n) + fri_.log_blowup;
     TS_REQUIRE(log_N <= 27, TS_ERR_INVALID, "commit: LDE larger than the two-adic subgroup");
     const uint64_t N = 1ull << log_N;
     ctx_.ensure_twiddles(std::max(1u, log_N));
@@ -81,6 +86,9 @@ std::unique_ptr<PcsData> TwoAdicFriPcs::commit(std::vector<DeviceMatrix>& evals,
         for (size_t i = 0; i < evals.size(); i++) {
             DeviceMatrix& m = evals[i];
             TS_REQUIRE(domain_shifts[i] != 0 && domain_shifts[i] < P, TS_ERR_INVALID, "bad domain shift");
+            const uint64_t n = m.height;
+            const unsigned log_n = log2_strict(n);
+            const uint64_t Ni = n << fri_.log_blowup;
             DevBuf<uint32_t> colmajor;
             uint32_t* ev = m.buf.p;
             if (m.layout == DeviceMatrix::ROW_MAJOR) {
@@ -88,15 +96,15 @@ std::unique_ptr<PcsData> TwoAdicFriPcs::commit(std::vector<DeviceMatrix>& evals,
                 launch_transpose_bitrev(ctx_, m.buf.p, colmajor.p, log_n, m.width, n);
                 ev = colmajor.p;
             }
-            DevBuf<uint32_t> lde(&ctx_, (size_t)m.width * N);
+            DevBuf<uint32_t> lde(&ctx_, (size_t)m.width * Ni);
             // two_adic_pcs.rs:235: shift = Val::generator() / domain.shift
             const uint32_t shift = mul(GENERATOR, inv_canon(domain_shifts[i]));
-            coset_lde(ctx_, ev, n, m.width, log_n, fri_.log_blowup, shift, lde.p, N);
+            coset_lde(ctx_, ev, n, m.width, log_n, fri_.log_blowup, shift, lde.p, Ni);
             ColMat cm;
             cm.d = lde.p;
-            cm.height = N;
+            cm.height = Ni;
             cm.width = m.width;
-            cm.col_stride = N;
+            cm.col_stride = Ni;
             data->ldes.push_back(cm);
             data->lde_storage.push_back(std::move(lde));
             m.buf.reset();  // consumed
@@ -105,13 +113,46 @@ std::unique_ptr<PcsData> TwoAdicFriPcs::commit(std::vector<DeviceMatrix>& evals,
     {
         StageTimer t(&ctx_, "merkle_commit");
         data->tree = DevBuf<uint32_t>(&ctx_, merkle_total_digests(log_N) * 8);
+        // column pointers grouped by height (tallest first), commit order inside a group
         std::vector<const uint32_t*> cols;
-        for (auto& cm : data->ldes)
-            for (uint32_t c = 0; c < cm.width; c++) cols.push_back(cm.d + (uint64_t)c * cm.col_stride);
+        struct Group { uint64_t height; size_t first; uint32_t total; };
+        std::vector<Group> groups;
+        for (unsigned lh = log_N + 1; lh-- > 0;) {
+            Group g{1ull << lh, cols.size(), 0};
+            for (auto& cm : data->ldes)
+                if (cm.height == g.height) {
+                    for (uint32_t c = 0; c < cm.width; c++) cols.push_back(cm.d + (uint64_t)c * cm.col_stride);
+                    g.total += cm.width;
+                }
+            if (g.total) groups.push_back(g);
+        }
         data->col_table = DevBuf<const uint32_t*>(&ctx_, cols.size());
         h2d(ctx_, data->col_table.p, cols.data(), cols.size() * sizeof(const uint32_t*));
-        launch_leaf_hash(ctx_, data->leaf_mats(), N, data->tree.p);
-        launch_merkle_levels(ctx_, data->tree.p, log_N);
+        auto group_leaves = [&](const Group& g, uint32_t* digests) {
+            LeafMats lm;
+            memset(&lm, 0, sizeof lm);
+            lm.cols = data->col_table.p + g.first;
+            lm.total_width = g.total;
+            launch_leaf_hash(ctx_, lm, g.height, digests);
+        };
+        group_leaves(groups[0], data->tree.p);
+        if (uniform) {
+            launch_merkle_levels(ctx_, data->tree.p, log_N);
+        } else {
+            DevBuf<uint32_t> inj(&ctx_, 8 * (N / 2));
+            size_t gi = 1;
+            for (unsigned l = 1; l <= log_N; l++) {
+                uint32_t* children = data->tree.p + 8 * merkle_level_offset(log_N, l - 1);
+                uint32_t* parents = data->tree.p + 8 * merkle_level_offset(log_N, l);
+                const uint64_t n_par = N >> l;
+                launch_merkle_one_level(ctx_, children, parents, n_par);
+                if (gi < groups.size() && groups[gi].height == n_par) {
+                    group_leaves(groups[gi], inj.p);
+                    launch_merkle_inject(ctx_, parents, inj.p, n_par);
+                    gi++;
+                }
+            }
+        }
         d2h_sync(ctx_, data->root, data->tree.p + 8 * (merkle_total_digests(log_N) - 1), 32);
     }
     return data;
@@ -296,7 +337,7 @@ void TwoAdicFriPcs::open_batch(const PcsData& d, uint64_t index, std::vector<uin
     ctx_.sync();
 }
 
-// ------------------------------------------------------------------ prove
+// ------------------------------------------------------------------ bf_prove
 namespace {
 
 struct FriRound {
@@ -308,58 +349,36 @@ struct FriRound {
 
 }  // namespace
 
-std::vector<uint32_t> prove(TwoAdicFriPcs& pcs, const AirProgram& air, BfChallenger& challenger,
-                            DeviceMatrix trace, const std::vector<uint32_t>& public_values) {
-    Context& ctx = pcs.ctx();
-    const FriConfig& fri = pcs.fri();
-    TS_REQUIRE(trace.width == air.width, TS_ERR_INVALID, "prove: trace width != AIR width");
-    TS_REQUIRE(public_values.size() == air.n_public, TS_ERR_INVALID,
-               "prove: wrong number of public values");
-    const uint64_t degree = trace.height;  // prover.rs:43-44
-    const unsigned log_degree = log2_strict(degree);
-    const unsigned lqd = air.log_quotient_degree;  // :46
-    const uint32_t qd = 1u << lqd;
-    const unsigned log_N = log_degree + fri.log_blowup;
-    const uint32_t w = air.width;
-    TS_REQUIRE(lqd <= fri.log_blowup, TS_ERR_INVARIANT,
-               "quotient domain larger than the committed LDE (log_quotient_degree > log_blowup)");
-    ctx.ensure_twiddles(std::max(1u, log_N));
+// fri/src/prover.rs:19-141 (bf_prove, bf_commit_phase, bf_answer_query) with the open_input closure
+// of two_adic_pcs.rs:399-414.  `inputs` are the reduced openings by strictly descending height.
+// Appends the FriProof to `pf`.
+void TwoAdicFriPcs::fri_prove(std::vector<DevBuf<Ef>>& inputs, const std::vector<unsigned>& log_lens,
+                              BfChallenger& challenger,
+                              const std::vector<const PcsData*>& input_rounds,
+                              std::vector<uint32_t>& pf) {
+    Context& ctx = ctx_;
+    const FriConfig& fri = fri_;
+    TS_REQUIRE(!inputs.empty() && inputs.size() == log_lens.size(), TS_ERR_INVALID, "FRI: no input");
+    for (size_t k = 1; k < log_lens.size(); k++)
+        TS_REQUIRE(log_lens[k] < log_lens[k - 1], TS_ERR_INVALID, "FRI: inputs must descend in height");
+    const unsigned log_max_height = log_lens[0];  // prover.rs:30
+    TS_REQUIRE(log_lens.back() >= fri.log_blowup, TS_ERR_INVALID, "FRI: vector shorter than the blowup");
+    for (const PcsData* d : input_rounds)
+        TS_REQUIRE(d->log_height <= log_max_height, TS_ERR_INVALID,
+                   "FRI: a committed batch is taller than every opened matrix");
 
-    // :50-53 commit to trace data (natural domain: shift 1)
-    std::vector<DeviceMatrix> tv;
-    tv.push_back(std::move(trace));
-    std::unique_ptr<PcsData> trace_data = pcs.commit(tv, {1u});
-    challenger.observe_commitment(trace_data->root);  // :60
-    const Ef alpha = challenger.sample();              // :63
-
-    // :65-80 quotient on the disjoint domain, flattened and split into qd chunks
-    std::vector<DeviceMatrix> chunks = pcs.quotient_chunks(*trace_data, air, public_values, alpha);
-    // split_domains (:80): chunk c lives on {log_n, shift = 31 * omega_{n*qd}^c}
-    std::vector<uint32_t> qshifts(qd);
-    const uint32_t gq = two_adic_generator(log_degree + lqd);
-    for (uint32_t c = 0; c < qd; c++) qshifts[c] = mul(GENERATOR, pow_canon(gq, c));
-    std::unique_ptr<PcsData> quotient_data = pcs.commit(chunks, qshifts);  // :82-83
-    challenger.observe_commitment(quotient_data->root);                    // :84
-    const Ef zeta = challenger.sample();                                   // :91
-
-    // :94-104 open; two_adic_pcs.rs:312 batch-combination challenge first
-    const Ef batch_alpha = challenger.sample();
-    std::vector<Ef> opened;
-    DevBuf<Ef> folded = pcs.open_reduce(*trace_data, *quotient_data, zeta, batch_alpha, opened);
-
-    // ---- bf_commit_phase, fri/src/prover.rs:93-141.  The transcript moves to the device for the
-    // whole phase: per round a one-thread kernel observes the root and samples beta, the fold reads
-    // beta from device memory, and once the vector is short the remaining rounds run inside one
-    // workgroup (launch_fri_tail).  One D2H at the end brings back roots, betas, the final values
-    // and the challenger state.
+    // ---- bf_commit_phase, prover.rs:93-141.  The transcript moves to the device for the whole
+    // phase: per round the kernel that makes the root observes it and samples beta, the fold reads
+    // beta from device memory, and once the vector is short (and no further input is waiting to be
+    // added) the remaining rounds run inside one workgroup (launch_fri_tail).  One D2H at the end
+    // brings back roots, the final values and the challenger state.
     std::vector<FriRound> rounds;
     std::vector<DevBuf<Ef>> keep_vecs;
     std::vector<DevBuf<uint32_t>> keep_trees;
     Ef final_poly;
     {
         StageTimer t(&ctx, "FRI commit phase");
-        TS_REQUIRE(log_N >= fri.log_blowup, TS_ERR_INVALID, "FRI: vector shorter than the blowup");
-        const uint32_t R_total = log_N - fri.log_blowup;
+        const uint32_t R_total = log_max_height - fri.log_blowup;
         DevChallenger hc;
         challenger.export_dev(hc);
         DevBuf<uint32_t> d_chal(&ctx, sizeof(DevChallenger) / 4);
@@ -369,20 +388,25 @@ std::vector<uint32_t> prove(TwoAdicFriPcs& pcs, const AirProgram& air, BfChallen
         DevBuf<Ef> d_final(&ctx, fri.blowup());
         DevChallenger* dch = reinterpret_cast<DevChallenger*>(d_chal.p);
 
-        uint64_t len = 1ull << log_N;
+        uint64_t len = 1ull << log_max_height;
+        DevBuf<Ef> folded = std::move(inputs[0]);
+        size_t next_in = 1;
         DevBuf<uint32_t> next_tree;
-        bool first = true;
-        while (len > fri.blowup() && len > (1ull << FRI_TAIL_LOG)) {  // :111, big rounds
+        bool leaves_ready = false;
+        // rounds done with one launch set each; the rest goes to the tail kernel
+        auto big = [&](uint64_t l) {
+            return l > fri.blowup() && (l > (1ull << FRI_TAIL_LOG) || next_in < inputs.size());
+        };
+        while (big(len)) {  // :111
             FriRound r;
             const uint64_t h = len / 2;
             r.log_leaves = log2_strict(h);
             DevBuf<uint32_t> tree;
-            if (first) {
+            if (leaves_ready) {
+                tree = std::move(next_tree);  // leaves were hashed by the previous fold
+            } else {
                 tree = DevBuf<uint32_t>(&ctx, merkle_total_digests(r.log_leaves) * 8);
                 launch_leaf_hash_ef_pairs(ctx, reinterpret_cast<const uint32_t*>(folded.p), h, tree.p);
-                first = false;
-            } else {
-                tree = std::move(next_tree);  // leaves were hashed by the previous fold
             }
             const size_t ri = rounds.size();
             // :113 commit_matrix, :114-116 observe + sample (in the kernel that makes the root)
@@ -390,12 +414,20 @@ std::vector<uint32_t> prove(TwoAdicFriPcs& pcs, const AirProgram& air, BfChallen
                 launch_chal_round(ctx, dch, tree.p + 8 * (merkle_total_digests(r.log_leaves) - 1),
                                   d_roots.p + 8 * ri, d_betas.p + ri);
             DevBuf<Ef> out(&ctx, h);
+            const bool add_pending = next_in < inputs.size() && (1ull << log_lens[next_in]) == h;
             uint32_t* nd = nullptr;
-            if (h > fri.blowup() && h > (1ull << FRI_TAIL_LOG)) {  // next round is a big one too
+            leaves_ready = false;
+            if (!add_pending && big(h)) {  // the next round's leaves can be hashed by this fold
                 next_tree = DevBuf<uint32_t>(&ctx, merkle_total_digests(r.log_leaves - 1) * 8);
                 nd = next_tree.p;
+                leaves_ready = true;
             }
             launch_fri_fold_dev(ctx, folded.p, h, d_betas.p + ri, out.p, nd);  // :119 fold_matrix
+            if (add_pending) {  // :124-126 izip!(&mut folded, v).for_each(|(c, x)| *c += x)
+                launch_vec_add(ctx, out.p, inputs[next_in].p, h);
+                keep_vecs.push_back(std::move(inputs[next_in]));
+                next_in++;
+            }
             r.vec = folded.p;
             r.tree = tree.p;
             keep_vecs.push_back(std::move(folded));
@@ -404,6 +436,7 @@ std::vector<uint32_t> prove(TwoAdicFriPcs& pcs, const AirProgram& air, BfChallen
             rounds.push_back(r);
             len = h;
         }
+        TS_REQUIRE(next_in == inputs.size(), TS_ERR_INVARIANT, "FRI: an input was never folded in");
         if (len > fri.blowup()) {  // tail rounds in one workgroup
             const uint32_t L0 = (uint32_t)len;
             DevBuf<Ef> tail_vecs(&ctx, 2 * (size_t)L0);
@@ -461,29 +494,33 @@ std::vector<uint32_t> prove(TwoAdicFriPcs& pcs, const AirProgram& air, BfChallen
     StageTimer tq(&ctx, "query phase");
     const uint32_t Q = fri.num_queries;
     std::vector<uint32_t> indices(std::max(Q, 1u));
-    for (uint32_t q = 0; q < Q; q++) indices[q] = (uint32_t)challenger.sample_bits(log_N);
+    for (uint32_t q = 0; q < Q; q++) indices[q] = (uint32_t)challenger.sample_bits(log_max_height);
     DevBuf<uint32_t> d_idx(&ctx, indices.size());
     h2d(ctx, d_idx.p, indices.data(), indices.size() * 4);
 
     // gather everything into one buffer, one D2H
-    const size_t path_words = 8 * (size_t)log_N;
+    const size_t n_in_rounds = input_rounds.size();
+    std::vector<LeafMats> lms(n_in_rounds);
+    std::vector<size_t> o_rows(n_in_rounds), o_path(n_in_rounds);
     size_t off = 0;
-    const size_t o_trows = off; off += (size_t)Q * w;
-    const size_t o_tpath = off; off += (size_t)Q * path_words;
-    const size_t o_qrows = off; off += (size_t)Q * 4 * qd;
-    const size_t o_qpath = off; off += (size_t)Q * path_words;
+    for (size_t k = 0; k < n_in_rounds; k++) {
+        lms[k] = input_rounds[k]->leaf_mats();
+        o_rows[k] = off; off += (size_t)Q * lms[k].total_width;
+        o_path[k] = off; off += (size_t)Q * 8 * input_rounds[k]->log_height;
+    }
     std::vector<size_t> o_fvals(R), o_fpath(R);
     for (uint32_t r = 0; r < R; r++) {
         o_fvals[r] = off; off += (size_t)Q * 8;
         o_fpath[r] = off; off += (size_t)Q * 8 * rounds[r].log_leaves;
     }
     DevBuf<uint32_t> d_out(&ctx, std::max<size_t>(off, 1));
-    const LeafMats tlm = trace_data->leaf_mats(), qlm = quotient_data->leaf_mats();
-    // two_adic_pcs.rs:399-414: both input batches have the global max height => bits_reduced = 0
-    launch_gather_rows(ctx, tlm, d_idx.p, Q, 0, d_out.p + o_trows);
-    launch_gather_paths(ctx, trace_data->tree.p, log_N, d_idx.p, Q, 0, d_out.p + o_tpath);
-    launch_gather_rows(ctx, qlm, d_idx.p, Q, 0, d_out.p + o_qrows);
-    launch_gather_paths(ctx, quotient_data->tree.p, log_N, d_idx.p, Q, 0, d_out.p + o_qpath);
+    for (size_t k = 0; k < n_in_rounds; k++) {
+        // two_adic_pcs.rs:403-409: bits_reduced = log_global_max_height - log_max_height(batch)
+        const unsigned bits_reduced = log_max_height - input_rounds[k]->log_height;
+        launch_gather_rows(ctx, lms[k], d_idx.p, Q, bits_reduced, d_out.p + o_rows[k]);
+        launch_gather_paths(ctx, input_rounds[k]->tree.p, input_rounds[k]->log_height, d_idx.p, Q,
+                            bits_reduced, d_out.p + o_path[k]);
+    }
     // bf_answer_query :69-90: index_i = index >> i >> 1, all rounds in one launch
     std::vector<FriGatherDesc> descs(std::max(R, 1u));
     uint32_t max_ll = 0;
@@ -502,36 +539,28 @@ std::vector<uint32_t> prove(TwoAdicFriPcs& pcs, const AirProgram& air, BfChallen
     std::vector<uint32_t> g(std::max<size_t>(off, 1));
     d2h_sync(ctx, g.data(), d_out.p, off * 4);
 
-    // ---- assemble Proof (prover.rs:105-118) in TSPF v1 order
-    std::vector<uint32_t> pf;
-    pf.reserve(64 + opened.size() * 4 + off + (size_t)Q * (8 + 2 * R));
+    // ---- FriProof (fri/src/proof.rs) in TSPF v1 order
+    pf.reserve(pf.size() + 16 + off + (size_t)Q * (8 + 2 * R + 4 * n_in_rounds));
     auto push = [&](uint32_t v) { pf.push_back(v); };
     auto push_n = [&](const uint32_t* p, size_t k) { pf.insert(pf.end(), p, p + k); };
-    push(TSPF_MAGIC);
-    push(1);
-    push(log_degree);
-    push(w);
-    push(qd);
-    push_n(trace_data->root, 8);
-    push_n(quotient_data->root, 8);
-    for (auto& e : opened) push_n(e.c, 4);
     push(R);
     for (uint32_t r = 0; r < R; r++) push_n(rounds[r].root, 8);
     push(Q);
     for (uint32_t q = 0; q < Q; q++) {
-        push(2);  // input_proof: one BatchOpening per commit round
-        push(1);
-        push(w);
-        push_n(&g[o_trows + (size_t)q * w], w);
-        push(log_N);
-        push_n(&g[o_tpath + (size_t)q * path_words], path_words);
-        push(qd);
-        for (uint32_t c = 0; c < qd; c++) {
-            push(4);
-            push_n(&g[o_qrows + (size_t)q * 4 * qd + 4 * c], 4);
+        push((uint32_t)n_in_rounds);  // input_proof: one BatchOpening per commit round
+        for (size_t k = 0; k < n_in_rounds; k++) {
+            const LeafMats& lm = lms[k];
+            push(lm.n_mats);
+            size_t c = o_rows[k] + (size_t)q * lm.total_width;
+            for (uint32_t i = 0; i < lm.n_mats; i++) {
+                push(lm.width[i]);
+                push_n(&g[c], lm.width[i]);
+                c += lm.width[i];
+            }
+            const unsigned lh = input_rounds[k]->log_height;
+            push(lh);
+            push_n(&g[o_path[k] + (size_t)q * 8 * lh], 8 * (size_t)lh);
         }
-        push(log_N);
-        push_n(&g[o_qpath + (size_t)q * path_words], path_words);
         for (uint32_t r = 0; r < R; r++) {  // commit_phase_openings
             push_n(&g[o_fvals[r] + (size_t)q * 8], 8);
             push(rounds[r].log_leaves);
@@ -540,6 +569,168 @@ std::vector<uint32_t> prove(TwoAdicFriPcs& pcs, const AirProgram& air, BfChallen
     }
     push_n(final_poly.c, 4);
     push(pow_witness);
+}
+
+// ------------------------------------------------------------------ Pcs::open, any shape
+// two_adic_pcs.rs:260-419.  Opened values come back in (round, matrix, point, column) order.
+std::vector<uint32_t> TwoAdicFriPcs::open(const std::vector<OpenRound>& rounds, BfChallenger& challenger,
+                                          std::vector<Ef>& opened_values) {
+    TS_REQUIRE(!rounds.empty(), TS_ERR_INVALID, "open: no rounds");
+    const Ef alpha = challenger.sample();  // :312
+    const Ef am = ef_to_mont(alpha);
+    uint32_t max_w = 1;
+    unsigned log_global_max = 0;
+    for (auto& r : rounds) {
+        TS_REQUIRE(r.data && r.points.size() == r.data->ldes.size(), TS_ERR_INVALID,
+                   "open: one point list per committed matrix");
+        for (auto& m : r.data->ldes) max_w = std::max(max_w, m.width);
+        log_global_max = std::max(log_global_max, r.data->log_height);  // :319-326
+    }
+    ctx_.ensure_twiddles(std::max(1u, log_global_max));
+    std::vector<uint32_t> apow(4 * (size_t)max_w);
+    {
+        Ef cur = ef_one_mont();
+        for (uint32_t i = 0; i < max_w; i++) {
+            memcpy(&apow[4 * (size_t)i], cur.c, 16);
+            cur = ef_mul(cur, am);
+        }
+    }
+    DevBuf<uint32_t> d_apow(&ctx_, apow.size());
+    h2d(ctx_, d_apow.p, apow.data(), apow.size() * 4);
+
+    opened_values.clear();
+    DevBuf<Ef> ro[32];            // :331 reduced_openings by log_height
+    uint64_t num_reduced[32] = {0};  // :332
+    const uint32_t gen_inv = inv_canon(GENERATOR);
+    for (auto& r : rounds) {
+        for (size_t mi = 0; mi < r.data->ldes.size(); mi++) {
+            const ColMat& m = r.data->ldes[mi];
+            const unsigned log_h = log2_strict(m.height);
+            TS_REQUIRE(log_h >= fri_.log_blowup, TS_ERR_INVALID, "open: matrix shorter than the blowup");
+            const unsigned log_n = log_h - fri_.log_blowup;
+            const uint64_t n = 1ull << log_n;
+            const uint32_t w = m.width;
+            const uint32_t n_inv = inv_canon((uint32_t)(n % P));
+            const auto& pts = r.points[mi];
+            for (size_t p0 = 0; p0 < pts.size(); p0 += 2) {
+                const uint32_t np = (uint32_t)std::min<size_t>(2, pts.size() - p0);
+                Ef pts_mont[2] = {ef_to_mont(pts[p0]), ef_to_mont(pts[p0 + np - 1])};
+                // :358-369 interpolate_coset on the low coset (first n bit-reversed rows)
+                std::vector<Ef> raw((size_t)w * np);
+                {
+                    StageTimer t(&ctx_, "compute opened values with Lagrange interpolation");
+                    DevBuf<Ef> weights(&ctx_, (size_t)np * n);
+                    launch_bary_weights(ctx_, log_n, pts_mont, np, weights.p);
+                    DevBuf<Ef> sums(&ctx_, raw.size());
+                    launch_bary_dots(ctx_, m, log_n, weights.p, np, sums.p);  // [col][point]
+                    d2h_sync(ctx_, raw.data(), sums.p, raw.size() * sizeof(Ef));
+                }
+                StageTimer t(&ctx_, "reduce rows");
+                ReduceArgs a;
+                memset(&a, 0, sizeof a);
+                a.n_points = np;
+                for (uint32_t p = 0; p < np; p++) {
+                    // p(z) = ((z/31)^n - 1)/n * sum_i p_i x_i/(z - x_i)
+                    Ef un = efc_pow(efc_mul_base(pts[p0 + p], gen_inv), n);
+                    un.c[0] = sub(un.c[0], 1);
+                    const Ef scale = efc_mul_base(un, n_inv);
+                    Ef rys = ef_zero();  // :372 dot_product(alpha.powers(), ys)
+                    for (uint32_t c = 0; c < w; c++) {
+                        const Ef y = efc_mul(raw[(size_t)c * np + p], scale);
+                        opened_values.push_back(y);
+                        Ef ap;
+                        memcpy(ap.c, &apow[4 * (size_t)c], 16);
+                        rys = ef_add(rys, ef_mul(y, ap));
+                    }
+                    a.z_mont[p] = pts_mont[p];
+                    a.off_mont[p] = ef_pow(am, num_reduced[log_h]);  // :371
+                    a.rys[p] = rys;
+                    num_reduced[log_h] += w;  // :383
+                }
+                if (!ro[log_h].p) {
+                    ro[log_h] = DevBuf<Ef>(&ctx_, m.height);
+                    a.accumulate = 0;
+                } else {
+                    a.accumulate = 1;
+                }
+                launch_reduce(ctx_, m, log_h, d_apow.p, a, ro[log_h].p);  // :375-381
+            }
+        }
+    }
+    ctx_.sync();  // pageable apow must outlive its async copy
+
+    // :389-393 fri_input: the reduced openings by descending height
+    std::vector<DevBuf<Ef>> inputs;
+    std::vector<unsigned> log_lens;
+    for (int lh = 31; lh >= 0; lh--)
+        if (ro[lh].p) {
+            inputs.push_back(std::move(ro[lh]));
+            log_lens.push_back((unsigned)lh);
+        }
+    TS_REQUIRE(!inputs.empty(), TS_ERR_INVALID, "open: nothing to open");
+    TS_REQUIRE(log_lens[0] == log_global_max, TS_ERR_UNSUPPORTED,
+               "open: the tallest committed matrix must be opened at one point at least");
+    std::vector<const PcsData*> datas;
+    for (auto& r : rounds) datas.push_back(r.data);
+    std::vector<uint32_t> pf;
+    fri_prove(inputs, log_lens, challenger, datas, pf);
+    return pf;
+}
+
+// ------------------------------------------------------------------ prove
+std::vector<uint32_t> prove(TwoAdicFriPcs& pcs, const AirProgram& air, BfChallenger& challenger,
+                            DeviceMatrix trace, const std::vector<uint32_t>& public_values) {
+    Context& ctx = pcs.ctx();
+    const FriConfig& fri = pcs.fri();
+    TS_REQUIRE(trace.width == air.width, TS_ERR_INVALID, "prove: trace width != AIR width");
+    TS_REQUIRE(public_values.size() == air.n_public, TS_ERR_INVALID,
+               "prove: wrong number of public values");
+    const uint64_t degree = trace.height;  // prover.rs:43-44
+    const unsigned log_degree = log2_strict(degree);
+    const unsigned lqd = air.log_quotient_degree;  // :46
+    const uint32_t qd = 1u << lqd;
+    const unsigned log_N = log_degree + fri.log_blowup;
+    const uint32_t w = air.width;
+    TS_REQUIRE(lqd <= fri.log_blowup, TS_ERR_INVARIANT,
+               "quotient domain larger than the committed LDE (log_quotient_degree > log_blowup)");
+    ctx.ensure_twiddles(std::max(1u, log_N));
+
+    // :50-53 commit to trace data (natural domain: shift 1)
+    std::vector<DeviceMatrix> tv;
+    tv.push_back(std::move(trace));
+    std::unique_ptr<PcsData> trace_data = pcs.commit(tv, {1u});
+    challenger.observe_commitment(trace_data->root);  // :60
+    const Ef alpha = challenger.sample();              // :63
+
+    // :65-80 quotient on the disjoint domain, flattened and split into qd chunks
+    std::vector<DeviceMatrix> chunks = pcs.quotient_chunks(*trace_data, air, public_values, alpha);
+    // split_domains (:80): chunk c lives on {log_n, shift = 31 * omega_{n*qd}^c}
+    std::vector<uint32_t> qshifts(qd);
+    const uint32_t gq = two_adic_generator(log_degree + lqd);
+    for (uint32_t c = 0; c < qd; c++) qshifts[c] = mul(GENERATOR, pow_canon(gq, c));
+    std::unique_ptr<PcsData> quotient_data = pcs.commit(chunks, qshifts);  // :82-83
+    challenger.observe_commitment(quotient_data->root);                    // :84
+    const Ef zeta = challenger.sample();                                   // :91
+
+    // :94-104 open; two_adic_pcs.rs:312 batch-combination challenge first.  Same result as
+    // pcs.open({trace: [zeta, zeta_next]}, {chunks: [zeta]}), through the one-pass reduce kernel.
+    const Ef batch_alpha = challenger.sample();
+    std::vector<Ef> opened;
+    std::vector<DevBuf<Ef>> inputs;
+    inputs.push_back(pcs.open_reduce(*trace_data, *quotient_data, zeta, batch_alpha, opened));
+
+    // ---- Proof (prover.rs:105-118) in TSPF v1 order
+    std::vector<uint32_t> pf;
+    pf.reserve(64 + opened.size() * 4);
+    pf.push_back(TSPF_MAGIC);
+    pf.push_back(1);
+    pf.push_back(log_degree);
+    pf.push_back(w);
+    pf.push_back(qd);
+    pf.insert(pf.end(), trace_data->root, trace_data->root + 8);
+    pf.insert(pf.end(), quotient_data->root, quotient_data->root + 8);
+    for (auto& e : opened) pf.insert(pf.end(), e.c, e.c + 4);
+    pcs.fri_prove(inputs, {log_N}, challenger, {trace_data.get(), quotient_data.get()}, pf);
     return pf;
 }
 

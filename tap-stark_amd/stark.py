@@ -196,9 +196,14 @@ class PcsData:
         n, lh = C.c_uint32(), C.c_uint32()
         ctx.check(ctx._l.ts_pcs_data_info(handle, C.byref(n), C.byref(lh)))
         self.n_mats, self.log_height = int(n.value), int(lh.value)
+        self.dims = []  # (LDE height, width) per committed matrix
+        for i in range(self.n_mats):
+            hh, ww = C.c_uint64(), C.c_uint32()
+            ctx.check(ctx._l.ts_pcs_data_matrix_info(handle, i, C.byref(hh), C.byref(ww)))
+            self.dims.append((int(hh.value), int(ww.value)))
 
-    def lde(self, idx: int, width: int) -> np.ndarray:
-        out = np.zeros((1 << self.log_height, width), dtype=np.uint32)
+    def lde(self, idx: int, width: int | None = None) -> np.ndarray:
+        out = np.zeros(self.dims[idx], dtype=np.uint32)
         self.ctx.check(self.ctx._l.ts_pcs_data_lde(self.ctx.h, self.h, idx, _p(out)))
         return out
 
@@ -207,7 +212,9 @@ class PcsData:
         self.ctx.check(self.ctx._l.ts_pcs_data_digests(self.ctx.h, self.h, level, _p(out)))
         return out
 
-    def open_batch(self, index: int, total_width: int):
+    def open_batch(self, index: int, total_width: int | None = None):
+        if total_width is None:
+            total_width = sum(w for _, w in self.dims)
         rows = np.zeros(max(total_width, 1), dtype=np.uint32)
         path = np.zeros((max(self.log_height, 1), 8), dtype=np.uint32)
         self.ctx.check(self.ctx._l.ts_pcs_open_batch(self.ctx.h, self.h, index, _p(rows), _p(path)))
@@ -268,6 +275,47 @@ class TwoAdicFriPcs:
                                                       quotient_data.h, _p(_u32(zeta)),
                                                       _p(_u32(batch_alpha)), _p(opened), _p(ro)))
         return opened, ro
+
+    def open(self, rounds, challenger: "BfChallenger"):
+        """``Pcs::open`` (two_adic_pcs.rs:260-419).  ``rounds``: list of (PcsData, points) with
+        ``points[m]`` the list of EF4 opening points of matrix m.  Returns (opened, fri_proof):
+        ``opened[r][m][p]`` is a (width, 4) array, ``fri_proof`` the FriProof words (TSPF v1)."""
+        n_pts, pts, total = [], [], 0
+        for data, points in rounds:
+            assert len(points) == data.n_mats
+            for (_, w), pl in zip(data.dims, points):
+                n_pts.append(len(pl))
+                pts.extend(_u32(z).reshape(4) for z in pl)
+                total += w * len(pl)
+        handles = (C.c_void_p * len(rounds))(*[d.h for d, _ in rounds])
+        n_pts_a = _u32(n_pts)
+        pts_a = _u32(np.concatenate(pts)) if pts else np.zeros(4, dtype=np.uint32)
+        opened = np.zeros((max(total, 1), 4), dtype=np.uint32)
+        # exact FriProof size (DESIGN.md "Proof format")
+        log_max = max(d.log_height for d, _ in rounds)
+        R, Q = max(log_max - self.fri.log_blowup, 0), self.fri.num_queries
+        per_q = 1 + sum(2 + d.n_mats + sum(w for _, w in d.dims) + 8 * d.log_height for d, _ in rounds)
+        per_q += sum(9 + 8 * (log_max - 1 - i) for i in range(R))
+        cap = 2 + 8 * R + Q * per_q + 5
+        cfg = self.fri._c()
+        proof = np.zeros(cap, dtype=np.uint32)
+        n_o, n_p = C.c_size_t(), C.c_size_t()
+        self.ctx.check(self.ctx._l.ts_pcs_open(self.ctx.h, C.byref(cfg), challenger.h, len(rounds),
+                                               handles, _p(n_pts_a), _p(pts_a), _p(opened),
+                                               opened.size, C.byref(n_o), _p(proof), cap,
+                                               C.byref(n_p)))
+        assert n_o.value == 4 * total
+        out, k = [], 0
+        for data, points in rounds:
+            r_out = []
+            for (_, w), pl in zip(data.dims, points):
+                m_out = []
+                for _ in pl:
+                    m_out.append(opened[k:k + w].copy())
+                    k += w
+                r_out.append(m_out)
+            out.append(r_out)
+        return out, proof[: n_p.value].copy()
 
     def fold_matrix(self, vec, beta) -> np.ndarray:
         vec = _u32(vec)

@@ -317,3 +317,91 @@ def test_config5_shape(ctx, orc):
     bad = proof.words.copy()
     bad[40] = (int(bad[40]) + 1) % P
     assert orc.verify(orc.FriConfig(*cfg), tape, bad, []) != 0
+
+
+# ------------------------------------------------------------------ general PCS (fri/tests/pcs.rs)
+def test_commit_mixed_heights(ctx, orc):
+    # one batch, matrices of different heights (bf_mmcs.rs:22-42): shorter matrices are injected
+    # into the level with as many nodes as they have rows
+    b = 1
+    pcs = ts.TwoAdicFriPcs(ts.FriConfig(b, 2, 8), ctx)
+    shapes = [(9, 3), (6, 5), (9, 2), (3, 70), (6, 1), (0, 2)]
+    mats = [rand_mat(70 + i, 1 << lg, w) for i, (lg, w) in enumerate(shapes)]
+    root, data = pcs.commit([((lg, 1), m.copy()) for (lg, _), m in zip(shapes, mats)])
+    ldes = [orc.commit_lde(m, 1, b) for m in mats]
+    for i in range(len(mats)):
+        assert (data.lde(i) == ldes[i]).all()
+    om = orc.OracleMmcs(ldes)
+    for lvl in range(data.log_height + 1):
+        assert (data.digests(lvl) == om.layer(lvl)).all(), f"digest level {lvl} differs"
+    assert (root == om.root).all()
+    for idx in (0, 1, 513, 1023):
+        rows, path = data.open_batch(idx)
+        orows, opath = om.open(idx)
+        assert (rows == orows).all() and (path == opath).all()
+        assert om.verify(idx, rows, path, root)
+
+
+PCS_SHAPES = (
+    [[[i]] for i in range(3, 6)]            # single (pcs.rs:135-142)
+    + [[[2, 1]]]                            # small
+    + [[[2] * 5]]                           # many_equal
+    + [[list(range(3, 3 + i))[::-1]] for i in range(1, 3)]  # many_different_rev
+    + [[[3]], [[3], [3]], [[3], [2]], [[2], [3]], [[4, 2], [4, 2]], [[2, 2], [3, 3]],
+       [[3, 3], [2, 2]], [[2], [3, 3]]]     # multiple_rounds
+    + [[[12, 9, 12], [11, 5]], [[0, 1], [2]], [[14], [10, 12]]]  # beyond the one-workgroup tail
+)
+
+
+@pytest.mark.parametrize("log_blowup", [1, 2])
+@pytest.mark.parametrize("shape", PCS_SHAPES, ids=[str(s) for s in PCS_SHAPES])
+def test_pcs_open_bit_identical_to_oracle(ctx, orc, log_blowup, shape):
+    # fri/tests/pcs.rs:62-90: commit every round, observe, sample zeta, open everything at zeta;
+    # roots, opened values and the whole FriProof must equal the oracle's
+    cfg = ts.FriConfig(log_blowup, 2, 8)
+    ocfg = orc.FriConfig(log_blowup, 2, 8)
+    pcs = ts.TwoAdicFriPcs(cfg, ctx)
+    seed, evals = 1000, []
+    for logs in shape:
+        evs = []
+        for lg in logs:
+            seed += 1
+            evs.append(rand_mat(seed, 1 << lg, 2 + seed % 3))
+        evals.append(evs)
+    oroots, ozeta, oopened, oproof = orc.pcs_commit_open(ocfg, shape, evals)
+
+    ch = ts.BfChallenger()
+    datas = []
+    for logs, evs in zip(shape, evals):
+        root, data = pcs.commit([((lg, 1), e.copy()) for lg, e in zip(logs, evs)])
+        datas.append(data)
+    for r, data in enumerate(datas):
+        assert (data.root == oroots[r]).all(), f"round {r} root differs"
+        ch.observe_commitment(data.root)
+    zeta = ch.sample()
+    assert (zeta == ozeta).all()
+    opened, proof = pcs.open([(d, [[zeta]] * d.n_mats) for d in datas], ch)
+    flat = np.concatenate([p for r in opened for m in r for p in m])
+    assert (flat == oopened).all(), "opened values differ"
+    assert len(proof) == len(oproof) and (proof == oproof).all(), "FriProof differs"
+
+
+def test_pcs_open_two_points_matches_prove_shape(ctx, orc):
+    # the general open on the prove() shape (trace at {zeta, zeta*w}, chunks at {zeta}) must give
+    # the fused path's opened values
+    log_n, w, b = 8, 6, 2
+    pcs = ts.TwoAdicFriPcs(ts.FriConfig(b, 3, 4), ctx)
+    tr = rand_mat(5, 1 << log_n, w)
+    chunks = [rand_mat(6 + c, 1 << log_n, 4) for c in range(2)]
+    g = pow(0x1A427A41, 1 << (27 - (log_n + 1)), P)
+    _, td = pcs.commit([((log_n, 1), tr.copy())])
+    _, qd = pcs.commit([((log_n, 31 * pow(g, c, P) % P), m.copy()) for c, m in enumerate(chunks)])
+    zeta = np.array([5, 6, 7, 8], dtype=np.uint32)
+    wn = pow(0x1A427A41, 1 << (27 - log_n), P)
+    zeta_next = (zeta.astype(np.uint64) * wn % P).astype(np.uint32)
+    ch = ts.BfChallenger()
+    alpha = ch.clone().sample()
+    opened, proof = pcs.open([(td, [[zeta, zeta_next]]), (qd, [[zeta]] * 2)], ch)
+    want, _ = pcs.open_reduce(td, qd, w, zeta, alpha)
+    flat = np.concatenate([p for r in opened for m in r for p in m])
+    assert (flat == want).all()

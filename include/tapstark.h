@@ -32,7 +32,8 @@ enum {
     TS_ERR_OOM = 3,
     TS_ERR_UNSUPPORTED = 4,
     TS_ERR_INVARIANT = 5,
-    TS_ERR_BUFFER = 6
+    TS_ERR_BUFFER = 6,
+    TS_ERR_COMM = 7 /* a ts_comm callback reported failure */
 };
 
 typedef struct ts_ctx ts_ctx;               /* one per GPU */
@@ -181,6 +182,33 @@ void ts_chal_state(const ts_challenger* c, uint32_t out[34]);
 ts_status ts_prove(ts_ctx* ctx, const ts_fri_config* cfg, const ts_air* air, ts_challenger* chal,
                    ts_matrix* trace, const uint32_t* public_values, uint32_t n_public,
                    uint32_t* proof_out, size_t cap_words, size_t* n_words_out);
+
+/* ---- one proof over the GPUs of a node (BASELINE config 4) ----
+ * The library does no networking of its own: the host hands it the collectives (RCCL through
+ * torch.distributed in tap-stark_amd/dist.py; any MPI-like layer can stand in).  Buffers are DEVICE
+ * pointers of the calling rank's GPU.  A callback is ordered on `hip_stream` (the context's
+ * stream): it either enqueues its work there or synchronises the stream first, and when it returns
+ * later work on that stream sees the result.  Return 0 on success. */
+typedef struct {
+    int rank, world;
+    void* user;
+    /* recv_dev receives world * bytes_per_rank bytes, the contributions in rank order */
+    int (*all_gather)(void* user, const void* send_dev, void* recv_dev, size_t bytes_per_rank,
+                      void* hip_stream);
+    int (*broadcast)(void* user, void* buf_dev, size_t bytes, int root, void* hip_stream);
+} ts_comm;
+
+/* prove() with the work of ONE proof split over comm->world ranks, one GPU each: rank g owns the
+ * bit-reversed LDE rows [g N/G, (g+1) N/G) -- whole cosets, so world must be a power of two
+ * <= 2^log_blowup (TS_ERR_UNSUPPORTED otherwise) -- with their Merkle sub-trees, FRI slabs and
+ * queries.  `trace_rows` holds natural rows [g n/G, (g+1) n/G) of the trace and is consumed.
+ * Every rank must pass a challenger in the same state; every rank receives the whole proof, which
+ * is bit-identical to ts_prove's on the whole trace.  FRI rounds stay sharded while a rank holds
+ * >= 2^min_local_log values (0 = default 12). */
+ts_status ts_prove_sharded(ts_ctx* ctx, const ts_fri_config* cfg, const ts_comm* comm,
+                           const ts_air* air, ts_challenger* chal, ts_matrix* trace_rows,
+                           const uint32_t* public_values, uint32_t n_public, uint32_t min_local_log,
+                           uint32_t* proof_out, size_t cap_words, size_t* n_words_out);
 
 /* check_constraints (uni-stark/src/check_constraints.rs:11-39; what a debug build of prove() runs
  * first, prover.rs:40-41) on the GPU.  `trace` is NOT consumed.  *first_violation = -1 if every

@@ -24,11 +24,11 @@ ABI_SYMBOLS = [
     "ts_pcs_data_info", "ts_pcs_data_matrix_info", "ts_pcs_data_digests", "ts_pcs_open_batch", "ts_pcs_data_free",
     "ts_quotient_chunks", "ts_pcs_open_reduce", "ts_pcs_open", "ts_fri_fold", "ts_chal_new", "ts_chal_clone",
     "ts_chal_free", "ts_chal_observe", "ts_chal_observe_commitment", "ts_chal_sample",
-    "ts_chal_sample_bits", "ts_chal_check_witness", "ts_chal_grind", "ts_chal_state", "ts_prove", "ts_verify", "ts_check_constraints",
+    "ts_chal_sample_bits", "ts_chal_check_witness", "ts_chal_grind", "ts_chal_state", "ts_prove", "ts_prove_sharded", "ts_verify", "ts_check_constraints",
 ]
 
 STATUS = {0: "TS_OK", 1: "TS_ERR_INVALID", 2: "TS_ERR_HIP", 3: "TS_ERR_OOM",
-          4: "TS_ERR_UNSUPPORTED", 5: "TS_ERR_INVARIANT", 6: "TS_ERR_BUFFER"}
+          4: "TS_ERR_UNSUPPORTED", 5: "TS_ERR_INVARIANT", 6: "TS_ERR_BUFFER", 7: "TS_ERR_COMM"}
 
 
 class TsError(RuntimeError):
@@ -40,6 +40,16 @@ class TsError(RuntimeError):
 class FriConfigC(C.Structure):
     _fields_ = [("log_blowup", C.c_uint32), ("num_queries", C.c_uint32),
                 ("proof_of_work_bits", C.c_uint32)]
+
+
+ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+BROADCAST_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
+
+
+class CommC(C.Structure):
+    """``ts_comm`` (include/tapstark.h)."""
+    _fields_ = [("rank", C.c_int), ("world", C.c_int), ("user", C.c_void_p),
+                ("all_gather", ALL_GATHER_FN), ("broadcast", BROADCAST_FN)]
 
 
 _lib = None
@@ -107,6 +117,9 @@ def lib() -> C.CDLL:
         l.ts_fri_fold.argtypes = [C.c_void_p, u32p, C.c_uint64, u32p, u32p]
         l.ts_prove.argtypes = [C.c_void_p, C.POINTER(FriConfigC), C.c_void_p, C.c_void_p, C.c_void_p,
                                u32p, C.c_uint32, u32p, C.c_size_t, C.POINTER(C.c_size_t)]
+        l.ts_prove_sharded.argtypes = [C.c_void_p, C.POINTER(FriConfigC), C.POINTER(CommC), C.c_void_p,
+                                       C.c_void_p, C.c_void_p, u32p, C.c_uint32, C.c_uint32, u32p,
+                                       C.c_size_t, C.POINTER(C.c_size_t)]
         l.ts_check_constraints.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, u32p, C.c_uint32,
                                            C.POINTER(C.c_int64)]
         l.ts_verify.argtypes = [C.POINTER(FriConfigC), C.c_void_p, C.c_void_p, u32p, C.c_size_t, u32p,

@@ -474,6 +474,45 @@ ts_status ts_prove(ts_ctx* ctx, const ts_fri_config* cfg, const ts_air* air, ts_
     });
 }
 
+ts_status ts_prove_sharded(ts_ctx* ctx, const ts_fri_config* cfg, const ts_comm* comm,
+                           const ts_air* air, ts_challenger* chal, ts_matrix* trace_rows,
+                           const uint32_t* public_values, uint32_t n_public, uint32_t min_local_log,
+                           uint32_t* proof_out, size_t cap_words, size_t* n_words_out) {
+    if (!ctx || !comm || !air || !chal || !trace_rows || !proof_out || !n_words_out ||
+        !comm->all_gather || !comm->broadcast)
+        return TS_ERR_INVALID;
+    *n_words_out = 0;
+    return guard(ctx, [&] {
+        ts::TwoAdicFriPcs pcs(ctx->ctx, load_cfg(cfg));
+        TS_REQUIRE(trace_rows->m.buf.p, ts::TS_ERR_INVALID, "prove: trace matrix was already consumed");
+        std::vector<uint32_t> pis;
+        if (n_public) {
+            TS_REQUIRE(public_values, ts::TS_ERR_INVALID, "null public values");
+            pis.assign(public_values, public_values + n_public);
+        }
+        ts::Comm c;
+        c.rank = comm->rank;
+        c.world = comm->world;
+        const ts_comm cb = *comm;
+        c.all_gather = [cb](const void* send, void* recv, size_t bytes, hipStream_t stream) {
+            if (cb.all_gather(cb.user, send, recv, bytes, (void*)stream) != 0)
+                throw ts::Error(ts::TS_ERR_COMM, "all_gather callback failed");
+        };
+        c.broadcast = [cb](void* buf, size_t bytes, int root, hipStream_t stream) {
+            if (cb.broadcast(cb.user, buf, bytes, root, (void*)stream) != 0)
+                throw ts::Error(ts::TS_ERR_COMM, "broadcast callback failed");
+        };
+        ts::ShardOptions opt;
+        if (min_local_log) opt.min_local_log = min_local_log;
+        ts::StageTimer t(&ctx->ctx, "prove");
+        std::vector<uint32_t> proof =
+            ts::prove_sharded(pcs, c, air->prog, chal->c, std::move(trace_rows->m), pis, opt);
+        *n_words_out = proof.size();
+        TS_REQUIRE(proof.size() <= cap_words, ts::TS_ERR_BUFFER, "proof buffer too small");
+        memcpy(proof_out, proof.data(), proof.size() * 4);
+    });
+}
+
 // ------------------------------------------------------------------ check_constraints
 ts_status ts_check_constraints(ts_ctx* ctx, const ts_air* air, const ts_matrix* trace,
                                const uint32_t* public_values, uint32_t n_public,

@@ -27,6 +27,7 @@ enum : int {
     TS_ERR_UNSUPPORTED = 4,
     TS_ERR_INVARIANT = 5,  // the reference would have panicked (assert/expect)
     TS_ERR_BUFFER = 6,     // output buffer too small
+    TS_ERR_COMM = 7,       // a communicator callback failed
 };
 
 #define TS_HIP(expr)                                                                        \

@@ -69,18 +69,23 @@ __global__ void k_fri_fold_single(const Ef* __restrict__ in, uint64_t h,
 }
 
 void launch_fri_fold_dev(Context& ctx, const Ef* in, uint64_t h, const Ef* d_beta, Ef* out,
-                         uint32_t* next_digests) {
+                         uint32_t* next_digests, uint64_t h_global, uint64_t row0) {
+    if (h_global == 0) h_global = h;
     unsigned log_h = 0;
-    while ((1ull << log_h) < h) log_h++;
-    TS_REQUIRE((1ull << log_h) == h, TS_ERR_INVALID, "fri_fold: length not a power of two");
+    while ((1ull << log_h) < h_global) log_h++;
+    TS_REQUIRE((1ull << log_h) == h_global && row0 + h <= h_global, TS_ERR_INVALID,
+               "fri_fold: length not a power of two");
     ctx.ensure_twiddles(log_h + 1);
+    // the kernels read Winv[h + i] for local i: shift the table so that this is the twiddle of
+    // global row row0 + i, Winv[h_global + row0 + i]
+    const uint32_t* tw = ctx.d_twiddle_inv + (h_global - h) + row0;
     if (h >= 2) {
         const uint64_t pairs = h / 2;
         TS_LAUNCH(ctx, k_fri_fold_pairs, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, in, h,
-                  ctx.d_twiddle_inv, d_beta, out, next_digests);
+                  tw, d_beta, out, next_digests);
     } else {
         TS_REQUIRE(next_digests == nullptr, TS_ERR_INVALID, "fri_fold: no next round at h = 1");
-        TS_LAUNCH(ctx, k_fri_fold_single, dim3(1), dim3(64), 0, in, h, ctx.d_twiddle_inv, d_beta, out);
+        TS_LAUNCH(ctx, k_fri_fold_single, dim3(1), dim3(64), 0, in, h, tw, d_beta, out);
     }
     TS_HIP(hipGetLastError());
 }

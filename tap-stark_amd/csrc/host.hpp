@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <functional>
 #include <memory>
 #include <vector>
 
@@ -101,6 +102,18 @@ public:
     DevBuf<Ef> open_reduce(const PcsData& trace_data, const PcsData& quotient_data, Ef zeta,
                            Ef batch_alpha, std::vector<Ef>& opened_values);
 
+    // The same two steps on a slab of the LDE: global rows [row0, row0 + rows) = whole cosets
+    // beta0, beta0+1, ... (bit-reversed coset order), as held by one rank of the sharded prover.
+    struct Slab {
+        uint64_t row0 = 0, rows = 0;  // rows = 0: the whole LDE
+        uint32_t beta0 = 0;
+    };
+    std::vector<DeviceMatrix> quotient_chunks_slab(const ColMat& lde_slab, unsigned log_n, const Slab& slab,
+                                                   const AirProgram& air,
+                                                   const std::vector<uint32_t>& public_values, Ef alpha);
+    DevBuf<Ef> open_reduce_slab(const PcsData& trace_data, const PcsData& quotient_data, unsigned log_N,
+                                const Slab& slab, Ef zeta, Ef batch_alpha, std::vector<Ef>& opened_values);
+
     // two_adic_pcs.rs:260-419 for any rounds x matrices x points: samples the batch challenge,
     // computes the opened values ((round, matrix, point, column) order) and returns the FriProof
     // (TSPF v1 words from the commit-phase round count on).
@@ -130,6 +143,28 @@ private:
 // uni-stark/src/prover.rs:25-119.  Returns the proof in TSPF v1 words.
 std::vector<uint32_t> prove(TwoAdicFriPcs& pcs, const AirProgram& air, BfChallenger& challenger,
                             DeviceMatrix trace, const std::vector<uint32_t>& public_values);
+
+// ------------------------------------------------------------------ prove, one proof over G GPUs
+// Collectives the sharded prover needs, supplied by the host (torch.distributed over RCCL in
+// tap-stark_amd/dist.py).  Buffers are device memory; the call is ordered on `stream`: the callee
+// either enqueues on it or synchronises it, and on return later work on `stream` sees the result.
+struct Comm {
+    int rank = 0, world = 1;
+    std::function<void(const void* send, void* recv, size_t bytes_per_rank, hipStream_t stream)> all_gather;
+    std::function<void(void* buf, size_t bytes, int root, hipStream_t stream)> broadcast;
+};
+struct ShardOptions {
+    // FRI rounds stay sharded while a rank's slab holds at least 2^min_local_log values; the
+    // remaining rounds run replicated on the gathered vector
+    unsigned min_local_log = 12;
+};
+// rank g owns the bit-reversed LDE rows [g N/G, (g+1) N/G) (whole cosets,
+// G <= 2^log_blowup) of every committed matrix and the matching Merkle sub-trees, FRI slabs and
+// queries.  `trace_rows`: natural rows [g n/G, (g+1) n/G) of the trace.  Every rank passes a
+// challenger in the same state and gets the whole proof, bit-identical to prove()'s.
+std::vector<uint32_t> prove_sharded(TwoAdicFriPcs& pcs, const Comm& comm, const AirProgram& air,
+                                    BfChallenger& challenger, DeviceMatrix trace_rows,
+                                    const std::vector<uint32_t>& public_values, const ShardOptions& opt);
 
 // ------------------------------------------------------------------ verify (host only)
 // uni-stark/src/verifier.rs:19-161.  0 = accept; 1 InvalidProofShape, 2 InvalidOpeningArgument

@@ -78,11 +78,12 @@ struct QO { u32* chunk[16]; };
 extern "C" __global__ void __launch_bounds__(256)
 k_quotient_jit(const u32* __restrict__ lde, u64 col_stride, unsigned log_n, unsigned log_qd,
                const u32* __restrict__ C, const u32* __restrict__ AP, const u32* __restrict__ isf,
-               const u32* __restrict__ isl, const u32* __restrict__ ist, QC qc, QO out) {
+               const u32* __restrict__ isl, const u32* __restrict__ ist, QC qc, QO out,
+               u32 row_begin, u32 row_end) {
     const unsigned L = log_n + log_qd;
     const u32 total = 1u << L;
-    const u32 r = blockIdx.x * 256u + threadIdx.x;
-    if (r >= total) return;
+    const u32 r = row_begin + blockIdx.x * 256u + threadIdx.x;
+    if (r >= row_end) return;
     const u32 i = L ? (__brev(r) >> (32 - L)) : 0u;
     const u32 i_next = (i + (1u << log_qd)) & (total - 1u);
     const u32 r_next = L ? (__brev(i_next) >> (32 - L)) : 0u;

@@ -30,8 +30,11 @@ void launch_transpose_to_row_major(Context& ctx, const uint32_t* src, uint64_t c
 // Coset low-degree extension of `ncols` columns (reference fri/src/two_adic_pcs.rs:233-241):
 //   in : evals[c][p] = column value at subgroup index bitrev(p)   (n per column, DESTROYED)
 //   out: out[c][beta*n + t] = p_c(shift * w_N^bitrev(beta*n+t)),  N = n << log_blowup
+// With a coset range (beta0, n_beta > 0) only the row blocks beta0 .. beta0+n_beta-1 are produced,
+// at out[c][(beta - beta0)*n + t]: the slab of a rank that owns those cosets (sharded prover).
 void coset_lde(Context& ctx, uint32_t* evals, uint64_t in_col_stride, uint32_t ncols, unsigned log_n,
-               unsigned log_blowup, uint32_t shift, uint32_t* out, uint64_t out_col_stride);
+               unsigned log_blowup, uint32_t shift, uint32_t* out, uint64_t out_col_stride,
+               uint32_t beta0 = 0, uint32_t n_beta = 0);
 
 // ---- merkle.hip ------------------------------------------------------------------------------
 constexpr int MAX_BATCH_MATS = 16;
@@ -62,6 +65,11 @@ bool launch_merkle_levels(Context& ctx, uint32_t* tree, unsigned log_leaves,
                           Ef* beta_out = nullptr);
 // mixed-height batches: one level at a time, with the digests of the rows of the matrices whose
 // height equals the level's node count compressed into the nodes (node = Blake3(node || inj))
+// sharded trees: the G sub-tree roots (gathered, rank order) -> the log2(G) top levels.  `top`
+// receives 2G-1 digests (the G roots first, the tree root last).  With `ch` the root is observed
+// and the next challenge sampled, as in launch_merkle_levels.
+void launch_shard_top(Context& ctx, const uint32_t* subroots, uint32_t G, uint32_t* top,
+                      DevChallenger* ch, uint32_t* root_out, Ef* beta_out);
 void launch_merkle_one_level(Context& ctx, const uint32_t* children, uint32_t* parents,
                              uint64_t n_parents);
 void launch_merkle_inject(Context& ctx, uint32_t* nodes, const uint32_t* inj, uint64_t n);
@@ -82,10 +90,13 @@ void launch_selectors(Context& ctx, unsigned log_n, unsigned log_qd, uint32_t* i
 struct QuotOut {
     uint32_t* chunk[16];
 };
+// Rows [row_begin, row_end) of the quotient domain only (row_end = 0: all); trace_lde.d must then
+// be such that d[c * col_stride + r] is valid for those rows r and their `next` rows (a sharded
+// prover passes its slab pointer minus the slab's first row; whole cosets keep `next` local).
 void launch_quotient(Context& ctx, const AirProgram& air, const ColMat& trace_lde, unsigned log_n,
                      unsigned log_qd, const uint32_t* d_consts_mont, const uint32_t* d_alpha_pows_mont,
                      const uint32_t* is_first, const uint32_t* is_last, const uint32_t* is_transition,
-                     const QuotOut& out);
+                     const QuotOut& out, uint64_t row_begin = 0, uint64_t row_end = 0);
 
 // check_constraints.rs:11-39 on the row-major trace; *d_violation (preset to ~0) receives
 // row * 2^16 + constraint index of the first violated constraint
@@ -96,8 +107,10 @@ void launch_check_constraints(Context& ctx, const AirProgram& air, const uint32_
 // ---- open.hip --------------------------------------------------------------------------------
 // d[p][i] = x_i / (z_p - x_i) (Montgomery EF4) for the low coset 31*H_n in bit-reversed order,
 // for up to 2 points; out layout [point][n] of Ef
+// coset_gen (canonical, 0 = 31): the weights of the coset coset_gen * H_n instead (any coset of
+// the LDE determines the polynomial, so a sharded prover interpolates on one it owns)
 void launch_bary_weights(Context& ctx, unsigned log_n, const Ef* points_mont, uint32_t n_points,
-                         Ef* out);
+                         Ef* out, uint32_t coset_gen = 0);
 // out[col][p] = sum_i m[col][i] * d[p][i]   (canonical EF4), i over the first n rows
 void launch_bary_dots(Context& ctx, const ColMat& m, unsigned log_n, const Ef* weights,
                       uint32_t n_points, Ef* out /* width * n_points */);
@@ -121,6 +134,9 @@ struct FusedReduceArgs {
     const uint32_t* chunk[16];
     uint64_t chunk_stride;
     uint32_t n_chunks;
+    // slab of a sharded prover: global rows [row0, row0 + rows) live at local rows [0, rows) of
+    // every matrix and of `ro` (rows = 0: the whole domain)
+    uint64_t row0, rows;
 };
 void launch_reduce_fused(Context& ctx, const ColMat& trace, unsigned log_h,
                          const uint32_t* d_alpha_pows_mont, const FusedReduceArgs& args, Ef* ro);
@@ -131,8 +147,10 @@ void launch_reduce_fused(Context& ctx, const ColMat& trace, unsigned log_h,
 void launch_fri_fold(Context& ctx, const Ef* in, uint64_t h, Ef beta_canonical, Ef* out,
                      uint32_t* next_digests);
 // same with beta read from device memory (written by launch_chal_round)
+// slab form: `in`/`out` hold global outputs [row0, row0 + h) of a fold whose output has h_global
+// rows (h_global = 0: the whole vector, h_global = h, row0 = 0)
 void launch_fri_fold_dev(Context& ctx, const Ef* in, uint64_t h, const Ef* d_beta, Ef* out,
-                         uint32_t* next_digests);
+                         uint32_t* next_digests, uint64_t h_global = 0, uint64_t row0 = 0);
 // device-resident transcript (chal_dev.hpp): observe the root at `root`, sample beta
 struct DevChallenger;
 void launch_chal_round(Context& ctx, DevChallenger* ch, const uint32_t* root, uint32_t* root_out,

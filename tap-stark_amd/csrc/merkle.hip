@@ -105,31 +105,42 @@ void launch_merkle_inject(Context& ctx, uint32_t* nodes, const uint32_t* inj, ui
     TS_HIP(hipGetLastError());
 }
 
-// the top of the tree (<= 512 children) in one workgroup: avoids ~9 tiny launches per tree
-__global__ void __launch_bounds__(256)
-k_merkle_top(uint32_t* __restrict__ tree, unsigned log_leaves, unsigned first_level) {
-    // level `first_level` (already computed) has 2^(log_leaves - first_level) <= 512 nodes
-    uint64_t off = 0;
-    for (unsigned l = 0; l < first_level; l++) off += (uint64_t)1 << (log_leaves - l);
-    for (unsigned l = first_level; l < log_leaves; l++) {
-        const uint64_t n_children = (uint64_t)1 << (log_leaves - l);
-        const uint4* children = reinterpret_cast<const uint4*>(tree + 8 * off);
-        uint4* parents = reinterpret_cast<uint4*>(tree + 8 * (off + n_children));
-        uint32_t i = threadIdx.x;
-        if (i < n_children / 2) {
-            uint4 a = children[4 * i], b = children[4 * i + 1], c = children[4 * i + 2],
-                  d = children[4 * i + 3];
-            uint32_t m[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w,
-                              c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
-            uint32_t cv[8];
+// Top of a sharded tree: level 0 = the G gathered sub-tree roots, then log2(G) levels; G is small
+// (<= 64), so one wavefront does a level at a time.
+__global__ void __launch_bounds__(64)
+k_shard_top(const uint32_t* __restrict__ subroots, uint32_t G, uint32_t* __restrict__ top,
+            DevChallenger* __restrict__ ch, uint32_t* __restrict__ root_out, Ef* __restrict__ beta_out) {
+    for (uint32_t i = threadIdx.x; i < 8 * G; i += 64) top[i] = subroots[i];
+    __threadfence_block();
+    __syncthreads();
+    uint32_t off = 0;
+    for (uint32_t cnt = G; cnt > 1; cnt >>= 1) {
+        const uint32_t i = threadIdx.x;
+        if (i < cnt / 2) {
+            uint32_t m[16], cv[8];
+            for (int k = 0; k < 16; k++) m[k] = top[8 * (off + 2 * i) + k];
             b3::hash64(m, cv);
-            parents[2 * i] = make_uint4(cv[0], cv[1], cv[2], cv[3]);
-            parents[2 * i + 1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
+            for (int k = 0; k < 8; k++) top[8 * (off + cnt + i) + k] = cv[k];
         }
-        off += n_children;
+        off += cnt;
         __threadfence_block();
         __syncthreads();
     }
+    if (ch != nullptr && threadIdx.x == 0) {
+        uint32_t root[8];
+        for (int k = 0; k < 8; k++) {
+            root[k] = top[8 * off + k];
+            root_out[k] = root[k];
+        }
+        const Ef beta = dc_observe_root_and_sample(ch, root);
+        *reinterpret_cast<uint4*>(beta_out) = make_uint4(beta.c[0], beta.c[1], beta.c[2], beta.c[3]);
+    }
+}
+void launch_shard_top(Context& ctx, const uint32_t* subroots, uint32_t G, uint32_t* top,
+                      DevChallenger* ch, uint32_t* root_out, Ef* beta_out) {
+    TS_REQUIRE(G >= 1 && G <= 64 && (G & (G - 1)) == 0, TS_ERR_INVALID, "shard_top: G must be 2^k <= 64");
+    TS_LAUNCH(ctx, k_shard_top, dim3(1), dim3(64), 0, subroots, G, top, ch, root_out, beta_out);
+    TS_HIP(hipGetLastError());
 }
 
 // A workgroup reduces a subtree of S = 2^log_s consecutive nodes of level `first_level` to its

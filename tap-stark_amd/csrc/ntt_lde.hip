@@ -205,7 +205,7 @@ template <int PLAN>
 __global__ void __launch_bounds__(NT_MID)
 k_lde_mid(const uint32_t* __restrict__ evals, uint64_t in_col_stride, uint32_t* __restrict__ out,
           uint64_t out_col_stride, unsigned log_n, unsigned log_len, unsigned log_T,
-          unsigned row_shift, unsigned n_cosets, const uint32_t* __restrict__ W,
+          unsigned row_shift, unsigned beta0, unsigned n_cosets, const uint32_t* __restrict__ W,
           const uint32_t* __restrict__ Winv, const uint32_t* __restrict__ lo,
           const uint32_t* __restrict__ hi, uint32_t n_hi) {
     __shared__ uint32_t s[padded(TILE_ELEMS)];
@@ -234,7 +234,10 @@ k_lde_mid(const uint32_t* __restrict__ evals, uint64_t in_col_stride, uint32_t* 
         const uint32_t i = threadIdx.x + (uint32_t)k * NT_MID;
         coef[k] = i < total ? s[pad(i)] : 0u;
     }
-    for (uint32_t beta = 0; beta < n_cosets; beta++) {
+    // cosets beta0 .. beta0 + n_cosets - 1 go to blocks 0 .. n_cosets - 1 of `out` (a rank of a
+    // sharded prover owns a contiguous range of cosets)
+    for (uint32_t bl = 0; bl < n_cosets; bl++) {
+        const uint32_t beta = beta0 + bl;
         const uint32_t* lo_b = lo + ((uint64_t)beta << SHIFT_LO_BITS);
         const uint32_t* hi_b = hi + (uint64_t)beta * n_hi;
         __syncthreads();
@@ -255,7 +258,7 @@ k_lde_mid(const uint32_t* __restrict__ evals, uint64_t in_col_stride, uint32_t* 
         } else {
             tile_forward_rt<NT_MID>(s, log_len, log_T, 0, 0, W);
         }
-        uint32_t* o = out + (uint64_t)blockIdx.y * out_col_stride + ((uint64_t)beta << log_n) + j2_0;
+        uint32_t* o = out + (uint64_t)blockIdx.y * out_col_stride + ((uint64_t)bl << log_n) + j2_0;
         for (uint32_t i = threadIdx.x; i < total; i += NT_MID)
             o[((uint64_t)(i >> log_T) << row_shift) + (i & tmask)] = s[pad(i)];
     }
@@ -263,7 +266,8 @@ k_lde_mid(const uint32_t* __restrict__ evals, uint64_t in_col_stride, uint32_t* 
 
 // ------------------------------------------------------------------ host driver
 void coset_lde(Context& ctx, uint32_t* evals, uint64_t in_col_stride, uint32_t ncols, unsigned log_n,
-               unsigned log_blowup, uint32_t shift, uint32_t* out, uint64_t out_col_stride) {
+               unsigned log_blowup, uint32_t shift, uint32_t* out, uint64_t out_col_stride,
+               uint32_t beta0, uint32_t n_beta) {
     TS_REQUIRE(log_n + log_blowup <= 27, TS_ERR_INVALID, "coset_lde: log_n + log_blowup > 27");
     TS_REQUIRE(ncols >= 1 && ncols <= 65535, TS_ERR_INVALID, "coset_lde: bad column count");
     const bool two_pass = log_n > (unsigned)LOG_M;
@@ -282,6 +286,8 @@ void coset_lde(Context& ctx, uint32_t* evals, uint64_t in_col_stride, uint32_t n
 
     // per-coset scale tables s_beta^k / n
     const uint32_t n_cosets = 1u << log_blowup;
+    if (n_beta == 0) n_beta = n_cosets - beta0;
+    TS_REQUIRE(beta0 < n_cosets && n_beta <= n_cosets - beta0, TS_ERR_INVALID, "coset_lde: coset range");
     const uint32_t n_lo = 1u << SHIFT_LO_BITS;
     const uint32_t n_hi = log_n > (unsigned)SHIFT_LO_BITS ? 1u << (log_n - SHIFT_LO_BITS) : 1u;
     DevBuf<uint32_t> lo(&ctx, (size_t)n_cosets * n_lo), hi(&ctx, (size_t)n_cosets * n_hi);
@@ -297,17 +303,17 @@ void coset_lde(Context& ctx, uint32_t* evals, uint64_t in_col_stride, uint32_t n
         const dim3 grid(1u << (LOG_M - log_T), ncols);
         if (sA == 8 && log_T == 5)
             TS_LAUNCH(ctx, k_lde_mid<1>, grid, dim3(NT_MID), 0, (const uint32_t*)evals, in_col_stride,
-                      out, out_col_stride, log_n, sA, log_T, (unsigned)LOG_M, n_cosets, W, Winv,
+                      out, out_col_stride, log_n, sA, log_T, (unsigned)LOG_M, beta0, n_beta, W, Winv,
                       (const uint32_t*)lo.p, (const uint32_t*)hi.p, n_hi);
         else
             TS_LAUNCH(ctx, k_lde_mid<0>, grid, dim3(NT_MID), 0, (const uint32_t*)evals, in_col_stride,
-                      out, out_col_stride, log_n, sA, log_T, (unsigned)LOG_M, n_cosets, W, Winv,
+                      out, out_col_stride, log_n, sA, log_T, (unsigned)LOG_M, beta0, n_beta, W, Winv,
                       (const uint32_t*)lo.p, (const uint32_t*)hi.p, n_hi);
-        TS_LAUNCH(ctx, k_lde_fwd_contig, dim3(1u << sA, ncols, n_cosets), dim3(NT), 0, out,
+        TS_LAUNCH(ctx, k_lde_fwd_contig, dim3(1u << sA, ncols, n_beta), dim3(NT), 0, out,
                   out_col_stride, log_n, W);
     } else {
         TS_LAUNCH(ctx, k_lde_mid<0>, dim3(1, ncols), dim3(NT_MID), 0, (const uint32_t*)evals,
-                  in_col_stride, out, out_col_stride, log_n, log_n, 0u, 0u, n_cosets, W, Winv,
+                  in_col_stride, out, out_col_stride, log_n, log_n, 0u, 0u, beta0, n_beta, W, Winv,
                   (const uint32_t*)lo.p, (const uint32_t*)hi.p, n_hi);
     }
     TS_HIP(hipGetLastError());

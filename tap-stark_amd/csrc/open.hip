@@ -78,13 +78,13 @@ k_bary_weights(unsigned log_n, const uint32_t* __restrict__ W, uint32_t gen_mont
 }
 
 void launch_bary_weights(Context& ctx, unsigned log_n, const Ef* points_mont, uint32_t n_points,
-                         Ef* out) {
+                         Ef* out, uint32_t coset_gen) {
     TS_REQUIRE(n_points >= 1 && n_points <= 2, TS_ERR_INVALID, "bary_weights: 1 or 2 points");
     ctx.ensure_twiddles(log_n == 0 ? 1 : log_n);
     const uint64_t threads = (((uint64_t)1 << log_n) + BW_ROWS - 1) / BW_ROWS;
     Ef z0 = points_mont[0], z1 = n_points > 1 ? points_mont[1] : points_mont[0];
     TS_LAUNCH(ctx, k_bary_weights, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, log_n,
-              ctx.d_twiddle_fwd, to_mont(GENERATOR), z0, z1, n_points, out);
+              ctx.d_twiddle_fwd, to_mont(coset_gen ? coset_gen : GENERATOR), z0, z1, n_points, out);
     TS_HIP(hipGetLastError());
 }
 
@@ -314,11 +314,10 @@ __global__ void __launch_bounds__(256)
 k_reduce_fused(const uint32_t* __restrict__ trace, uint64_t trace_stride, uint32_t width,
                unsigned log_h, const uint32_t* __restrict__ W, uint32_t gen_mont,
                const uint32_t* __restrict__ alpha_pows, FusedReduceArgs a, Ef* __restrict__ ro) {
-    const uint64_t h = 1ull << log_h;
-    const uint64_t X = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (X >= h) return;
+    const uint64_t X = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;  // local row
+    if (X >= a.rows) return;
     const Ef St = row_dot_alpha(trace, trace_stride, width, X, alpha_pows);
-    const uint32_t x = mont_mul(gen_mont, root_bitrev(W, log_h, X));
+    const uint32_t x = mont_mul(gen_mont, root_bitrev(W, log_h, a.row0 + X));
     Ef inv_d[2];
     inv_denoms<2>(x, a.z_mont, inv_d);
     Ef g0 = ef_mul(ef_sub(St, a.rys_t[0]), a.off_t[0]);
@@ -335,10 +334,15 @@ void launch_reduce_fused(Context& ctx, const ColMat& trace, unsigned log_h,
                          const uint32_t* d_alpha_pows_mont, const FusedReduceArgs& args, Ef* ro) {
     TS_REQUIRE(args.n_chunks <= 16, TS_ERR_INVALID, "reduce_fused: too many chunks");
     ctx.ensure_twiddles(log_h == 0 ? 1 : log_h);
-    const uint64_t h = 1ull << log_h;
-    TS_LAUNCH(ctx, k_reduce_fused, dim3((unsigned)((h + 255) / 256)), dim3(256), 0,
+    FusedReduceArgs a = args;
+    if (a.rows == 0) {
+        a.row0 = 0;
+        a.rows = 1ull << log_h;
+    }
+    TS_REQUIRE(a.row0 + a.rows <= (1ull << log_h), TS_ERR_INVALID, "reduce_fused: row range");
+    TS_LAUNCH(ctx, k_reduce_fused, dim3((unsigned)((a.rows + 255) / 256)), dim3(256), 0,
               (const uint32_t*)trace.d, trace.col_stride, trace.width, log_h,
-              (const uint32_t*)ctx.d_twiddle_fwd, to_mont(GENERATOR), d_alpha_pows_mont, args, ro);
+              (const uint32_t*)ctx.d_twiddle_fwd, to_mont(GENERATOR), d_alpha_pows_mont, a, ro);
     TS_HIP(hipGetLastError());
 }
 

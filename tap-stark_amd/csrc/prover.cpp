@@ -11,11 +11,9 @@
 
 #include <algorithm>
 
-#include "host.hpp"
+#include "fri_internal.hpp"
 
 namespace ts {
-
-namespace {
 
 void h2d(Context& ctx, void* dst, const void* src, size_t bytes) {
     if (bytes) TS_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx.stream));
@@ -37,10 +35,6 @@ Ef efc_mul(Ef a, Ef b) { return ef_mul(a, ef_to_mont(b)); }
 Ef efc_mul_base(Ef a, uint32_t b) { return ef_mul_base(a, to_mont(b)); }
 Ef efc_pow(Ef a, uint64_t e) { return ef_from_mont(ef_pow(ef_to_mont(a), e)); }
 Ef efc_one() { return Ef{{1, 0, 0, 0}}; }
-
-constexpr uint32_t TSPF_MAGIC = 0x46505354u;
-
-}  // namespace
 
 LeafMats PcsData::leaf_mats() const {
     LeafMats lm;
@@ -162,19 +156,30 @@ std::unique_ptr<PcsData> TwoAdicFriPcs::commit(std::vector<DeviceMatrix>& evals,
 std::vector<DeviceMatrix> TwoAdicFriPcs::quotient_chunks(const PcsData& trace_data,
                                                          const AirProgram& air,
                                                          const std::vector<uint32_t>& pis, Ef alpha) {
-    StageTimer t(&ctx_, "compute quotient polynomial");
     TS_REQUIRE(trace_data.ldes.size() >= 1, TS_ERR_INVALID, "quotient: no trace matrix");
-    const ColMat& lde = trace_data.ldes[0];
-    TS_REQUIRE(lde.width == air.width, TS_ERR_INVALID, "quotient: trace width != AIR width");
+    TS_REQUIRE(trace_data.log_height >= fri_.log_blowup, TS_ERR_INVALID, "quotient: bad trace data");
+    return quotient_chunks_slab(trace_data.ldes[0], trace_data.log_height - fri_.log_blowup, Slab{}, air,
+                                pis, alpha);
+}
+
+std::vector<DeviceMatrix> TwoAdicFriPcs::quotient_chunks_slab(const ColMat& lde_slab, unsigned log_n,
+                                                              const Slab& slab, const AirProgram& air,
+                                                              const std::vector<uint32_t>& pis, Ef alpha) {
+    StageTimer t(&ctx_, "compute quotient polynomial");
+    TS_REQUIRE(lde_slab.width == air.width, TS_ERR_INVALID, "quotient: trace width != AIR width");
     TS_REQUIRE(pis.size() == air.n_public, TS_ERR_INVALID, "quotient: wrong number of public values");
     const unsigned lqd = air.log_quotient_degree;
     // two_adic_pcs.rs:256: assert!(lde.height() >= domain.size())
     TS_REQUIRE(lqd <= fri_.log_blowup, TS_ERR_INVARIANT,
                "quotient domain larger than the committed LDE (log_quotient_degree > log_blowup)");
-    TS_REQUIRE(trace_data.log_height >= fri_.log_blowup, TS_ERR_INVALID, "quotient: bad trace data");
-    const unsigned log_n = trace_data.log_height - fri_.log_blowup;
     const uint64_t n = 1ull << log_n, qn = n << lqd;
     const uint32_t qd = 1u << lqd;
+    // rows of the quotient domain (the first qn bit-reversed rows of the LDE) inside the slab
+    const uint64_t slab_rows = slab.rows ? slab.rows : lde_slab.height;
+    const uint64_t row_begin = std::min<uint64_t>(slab.row0, qn);
+    const uint64_t row_end = std::min<uint64_t>(slab.row0 + slab_rows, qn);
+    // whole cosets only: `next` (natural index + qd) stays inside a coset of H_n
+    TS_REQUIRE(row_begin % n == 0 && row_end % n == 0, TS_ERR_INVALID, "quotient: slab must hold whole cosets");
 
     DevBuf<uint32_t> sel(&ctx_, 3 * qn);
     launch_selectors(ctx_, log_n, lqd, sel.p, sel.p + qn, sel.p + 2 * qn);
@@ -210,7 +215,12 @@ std::vector<DeviceMatrix> TwoAdicFriPcs::quotient_chunks(const PcsData& trace_da
         chunks[c].layout = DeviceMatrix::COL_MAJOR_BITREV;
         qo.chunk[c] = chunks[c].buf.p;
     }
-    launch_quotient(ctx_, air, lde, log_n, lqd, d_consts.p, d_apow.p, sel.p, sel.p + qn, sel.p + 2 * qn, qo);
+    if (row_begin < row_end) {
+        ColMat lde = lde_slab;
+        lde.d = lde_slab.d - slab.row0;  // global row r of the slab's range lives at d[r]
+        launch_quotient(ctx_, air, lde, log_n, lqd, d_consts.p, d_apow.p, sel.p, sel.p + qn, sel.p + 2 * qn,
+                        qo, row_begin, row_end);
+    }
     // the pageable staging vectors must outlive the async copies
     ctx_.sync();
     return chunks;
@@ -219,12 +229,26 @@ std::vector<DeviceMatrix> TwoAdicFriPcs::quotient_chunks(const PcsData& trace_da
 // ------------------------------------------------------------------ open
 DevBuf<Ef> TwoAdicFriPcs::open_reduce(const PcsData& trace_data, const PcsData& quotient_data, Ef zeta,
                                       Ef alpha, std::vector<Ef>& opened_values) {
-    TS_REQUIRE(trace_data.ldes.size() == 1, TS_ERR_UNSUPPORTED, "open: one trace matrix expected");
     TS_REQUIRE(trace_data.log_height == quotient_data.log_height, TS_ERR_INVALID,
                "open: trace and quotient LDE heights differ");
-    const unsigned log_N = trace_data.log_height;
+    return open_reduce_slab(trace_data, quotient_data, trace_data.log_height, Slab{}, zeta, alpha,
+                            opened_values);
+}
+
+// `slab` (rows != 0): the two PcsData hold only global rows [row0, row0 + rows) of the LDEs, which
+// start with the whole coset beta0 (sharded prover).  The opened values are interpolated on that
+// coset -- any coset of the LDE determines the polynomials, so every rank gets the same values.
+DevBuf<Ef> TwoAdicFriPcs::open_reduce_slab(const PcsData& trace_data, const PcsData& quotient_data,
+                                           unsigned log_N, const Slab& slab, Ef zeta, Ef alpha,
+                                           std::vector<Ef>& opened_values) {
+    TS_REQUIRE(trace_data.ldes.size() == 1, TS_ERR_UNSUPPORTED, "open: one trace matrix expected");
     const unsigned log_n = log_N - fri_.log_blowup;
-    const uint64_t n = 1ull << log_n, N = 1ull << log_N;
+    const uint64_t n = 1ull << log_n;
+    const uint64_t N = slab.rows ? slab.rows : 1ull << log_N;  // rows held here
+    TS_REQUIRE(N >= n && trace_data.ldes[0].height == N, TS_ERR_INVALID, "open: slab shape");
+    // x of local row t < n: coset_gen * omega_n^bitrev(t), coset_gen = 31 * omega_N^bitrev_b(beta0)
+    const uint32_t coset_gen =
+        mul(GENERATOR, pow_canon(two_adic_generator(log_N), bitrev32(slab.beta0, fri_.log_blowup)));
     const ColMat& tr = trace_data.ldes[0];
     const uint32_t w = tr.width;
     const uint32_t qd = (uint32_t)quotient_data.ldes.size();
@@ -241,15 +265,15 @@ DevBuf<Ef> TwoAdicFriPcs::open_reduce(const PcsData& trace_data, const PcsData& 
     {
         StageTimer t(&ctx_, "compute opened values with Lagrange interpolation");
         DevBuf<Ef> weights(&ctx_, 2 * n);
-        launch_bary_weights(ctx_, log_n, pts_mont, 2, weights.p);
+        launch_bary_weights(ctx_, log_n, pts_mont, 2, weights.p, coset_gen);
         DevBuf<Ef> sums(&ctx_, raw.size());
         launch_bary_dots(ctx_, tr, log_n, weights.p, 2, sums.p);  // [col][point]
         for (uint32_t c = 0; c < qd; c++)
             launch_bary_dots(ctx_, quotient_data.ldes[c], log_n, weights.p, 1, sums.p + 2 * w + 4 * c);
         d2h_sync(ctx_, raw.data(), sums.p, raw.size() * sizeof(Ef));
     }
-    // p(z) = ((z/31)^n - 1)/n * sum_i p_i x_i/(z - x_i)
-    const uint32_t gen_inv = inv_canon(GENERATOR);
+    // p(z) = ((z/s)^n - 1)/n * sum_i p_i x_i/(z - x_i) on the coset s*H_n (s = 31 unless sharded)
+    const uint32_t gen_inv = inv_canon(coset_gen);
     const uint32_t n_inv = inv_canon((uint32_t)(n % P));
     Ef scale[2];
     for (int p = 0; p < 2; p++) {
@@ -306,6 +330,8 @@ DevBuf<Ef> TwoAdicFriPcs::open_reduce(const PcsData& trace_data, const PcsData& 
         num_reduced += w;
         a.n_chunks = qd;
         a.chunk_stride = N;
+        a.row0 = slab.row0;
+        a.rows = N;
         for (uint32_t c = 0; c < qd; c++) {
             TS_REQUIRE(quotient_data.ldes[c].col_stride == N, TS_ERR_INVALID, "open: chunk stride");
             a.chunk[c] = quotient_data.ldes[c].d;
@@ -337,18 +363,130 @@ void TwoAdicFriPcs::open_batch(const PcsData& d, uint64_t index, std::vector<uin
     ctx_.sync();
 }
 
+// ------------------------------------------------------------------ bf_commit_phase
+// fri/src/prover.rs:93-141.  The transcript moves to the device for the whole phase: per round the
+// kernel that makes the root observes it and samples beta, the fold reads beta from device memory,
+// and once the vector is short (and no further input is waiting to be added) the remaining rounds
+// run inside one workgroup (launch_fri_tail).  One D2H at the end brings back roots, the final
+// values and the challenger state.
+void fri_commit_begin(Context& ctx, const FriConfig& fri, unsigned log_max_height,
+                      const BfChallenger& challenger, FriCommit& st) {
+    TS_REQUIRE(log_max_height >= fri.log_blowup, TS_ERR_INVALID, "FRI: vector shorter than the blowup");
+    st.R_total = log_max_height - fri.log_blowup;
+    DevChallenger hc;
+    challenger.export_dev(hc);
+    st.d_chal = DevBuf<uint32_t>(&ctx, sizeof(DevChallenger) / 4);
+    h2d(ctx, st.d_chal.p, &hc, sizeof hc);
+    ctx.sync();  // `hc` is a stack temporary
+    st.d_roots = DevBuf<uint32_t>(&ctx, std::max<size_t>(8 * (size_t)st.R_total, 8));
+    st.d_betas = DevBuf<Ef>(&ctx, std::max<size_t>(st.R_total, 1));
+    st.d_final = DevBuf<Ef>(&ctx, fri.blowup());
+}
+
+void fri_commit_rounds(Context& ctx, const FriConfig& fri, DevBuf<Ef> folded, uint64_t len,
+                       std::vector<DevBuf<Ef>>& inputs, const std::vector<unsigned>& log_lens,
+                       size_t next_in, FriCommit& st) {
+    DevChallenger* dch = st.dch();
+    DevBuf<uint32_t> next_tree;
+    bool leaves_ready = false;
+    // rounds done with one launch set each; the rest goes to the tail kernel
+    auto big = [&](uint64_t l) {
+        return l > fri.blowup() && (l > (1ull << FRI_TAIL_LOG) || next_in < inputs.size());
+    };
+    while (big(len)) {  // :111
+        FriRound r;
+        const uint64_t h = len / 2;
+        r.log_leaves = log2_strict(h);
+        DevBuf<uint32_t> tree;
+        if (leaves_ready) {
+            tree = std::move(next_tree);  // leaves were hashed by the previous fold
+        } else {
+            tree = DevBuf<uint32_t>(&ctx, merkle_total_digests(r.log_leaves) * 8);
+            launch_leaf_hash_ef_pairs(ctx, reinterpret_cast<const uint32_t*>(folded.p), h, tree.p);
+        }
+        const size_t ri = st.rounds.size();
+        // :113 commit_matrix, :114-116 observe + sample (in the kernel that makes the root)
+        if (!launch_merkle_levels(ctx, tree.p, r.log_leaves, dch, st.d_roots.p + 8 * ri, st.d_betas.p + ri))
+            launch_chal_round(ctx, dch, tree.p + 8 * (merkle_total_digests(r.log_leaves) - 1),
+                              st.d_roots.p + 8 * ri, st.d_betas.p + ri);
+        DevBuf<Ef> out(&ctx, h);
+        const bool add_pending = next_in < inputs.size() && (1ull << log_lens[next_in]) == h;
+        uint32_t* nd = nullptr;
+        leaves_ready = false;
+        if (!add_pending && big(h)) {  // the next round's leaves can be hashed by this fold
+            next_tree = DevBuf<uint32_t>(&ctx, merkle_total_digests(r.log_leaves - 1) * 8);
+            nd = next_tree.p;
+            leaves_ready = true;
+        }
+        launch_fri_fold_dev(ctx, folded.p, h, st.d_betas.p + ri, out.p, nd);  // :119 fold_matrix
+        if (add_pending) {  // :124-126 izip!(&mut folded, v).for_each(|(c, x)| *c += x)
+            launch_vec_add(ctx, out.p, inputs[next_in].p, h);
+            st.keep_vecs.push_back(std::move(inputs[next_in]));
+            next_in++;
+        }
+        r.vec = folded.p;
+        r.tree = tree.p;
+        st.keep_vecs.push_back(std::move(folded));
+        st.keep_trees.push_back(std::move(tree));
+        folded = std::move(out);
+        st.rounds.push_back(r);
+        len = h;
+    }
+    TS_REQUIRE(next_in == inputs.size(), TS_ERR_INVARIANT, "FRI: an input was never folded in");
+    if (len > fri.blowup()) {  // tail rounds in one workgroup
+        const uint32_t L0 = (uint32_t)len;
+        DevBuf<Ef> tail_vecs(&ctx, 2 * (size_t)L0);
+        DevBuf<uint32_t> tail_trees(&ctx, 8 * 2 * (size_t)L0);
+        const size_t ri = st.rounds.size();
+        launch_fri_tail(ctx, folded.p, L0, fri.blowup(), dch, tail_vecs.p, tail_trees.p,
+                        st.d_roots.p + 8 * ri, st.d_betas.p + ri, st.d_final.p);
+        uint32_t L = L0;
+        size_t voff = 0, toff = 0;
+        while (L > fri.blowup()) {
+            FriRound r;
+            r.log_leaves = log2_strict(L / 2);
+            r.vec = tail_vecs.p + voff;
+            r.tree = tail_trees.p + 8 * toff;
+            st.rounds.push_back(r);
+            voff += L;
+            toff += L - 1;
+            L >>= 1;
+        }
+        len = L;
+        st.keep_vecs.push_back(std::move(tail_vecs));
+        st.keep_trees.push_back(std::move(tail_trees));
+    } else {
+        TS_HIP(hipMemcpyAsync(st.d_final.p, folded.p, len * sizeof(Ef), hipMemcpyDeviceToDevice,
+                              ctx.stream));
+    }
+    st.keep_vecs.push_back(std::move(folded));
+    st.final_len = len;
+}
+
+Ef fri_commit_finish(Context& ctx, const FriConfig& fri, BfChallenger& challenger, FriCommit& st) {
+    // :129-134 `blowup` evaluations of a constant polynomial
+    TS_REQUIRE(st.final_len == fri.blowup(), TS_ERR_INVARIANT, "FRI: folded length != blowup");
+    TS_REQUIRE(st.rounds.size() == st.R_total, TS_ERR_INVARIANT, "FRI: round count");
+    const uint32_t R_total = st.R_total;
+    std::vector<Ef> fin(st.final_len);
+    std::vector<uint32_t> roots(std::max<size_t>(8 * (size_t)R_total, 8));
+    DevChallenger hc;
+    TS_HIP(hipMemcpyAsync(fin.data(), st.d_final.p, fin.size() * sizeof(Ef), hipMemcpyDeviceToHost,
+                          ctx.stream));
+    if (R_total)
+        TS_HIP(hipMemcpyAsync(roots.data(), st.d_roots.p, 32 * (size_t)R_total, hipMemcpyDeviceToHost,
+                              ctx.stream));
+    d2h_sync(ctx, &hc, st.d_chal.p, sizeof hc);
+    challenger.import_dev(hc);
+    for (uint32_t r = 0; r < R_total; r++) memcpy(st.rounds[r].root, &roots[8 * (size_t)r], 32);
+    const Ef final_poly = fin[0];
+    for (auto& x : fin)
+        TS_REQUIRE(ef_eq(x, final_poly), TS_ERR_INVARIANT,
+                   "FRI: final polynomial is not constant (assert_eq!(x, final_poly))");
+    return final_poly;
+}
+
 // ------------------------------------------------------------------ bf_prove
-namespace {
-
-struct FriRound {
-    const Ef* vec = nullptr;        // committed vector (rows of two): length 2 * 2^log_leaves
-    const uint32_t* tree = nullptr;
-    unsigned log_leaves = 0;
-    uint32_t root[8];
-};
-
-}  // namespace
-
 // fri/src/prover.rs:19-141 (bf_prove, bf_commit_phase, bf_answer_query) with the open_input closure
 // of two_adic_pcs.rs:399-414.  `inputs` are the reduced openings by strictly descending height.
 // Appends the FriProof to `pf`.
@@ -367,120 +505,16 @@ void TwoAdicFriPcs::fri_prove(std::vector<DevBuf<Ef>>& inputs, const std::vector
         TS_REQUIRE(d->log_height <= log_max_height, TS_ERR_INVALID,
                    "FRI: a committed batch is taller than every opened matrix");
 
-    // ---- bf_commit_phase, prover.rs:93-141.  The transcript moves to the device for the whole
-    // phase: per round the kernel that makes the root observes it and samples beta, the fold reads
-    // beta from device memory, and once the vector is short (and no further input is waiting to be
-    // added) the remaining rounds run inside one workgroup (launch_fri_tail).  One D2H at the end
-    // brings back roots, the final values and the challenger state.
-    std::vector<FriRound> rounds;
-    std::vector<DevBuf<Ef>> keep_vecs;
-    std::vector<DevBuf<uint32_t>> keep_trees;
+    FriCommit st;
     Ef final_poly;
     {
         StageTimer t(&ctx, "FRI commit phase");
-        const uint32_t R_total = log_max_height - fri.log_blowup;
-        DevChallenger hc;
-        challenger.export_dev(hc);
-        DevBuf<uint32_t> d_chal(&ctx, sizeof(DevChallenger) / 4);
-        h2d(ctx, d_chal.p, &hc, sizeof hc);
-        DevBuf<uint32_t> d_roots(&ctx, std::max<size_t>(8 * (size_t)R_total, 8));
-        DevBuf<Ef> d_betas(&ctx, std::max<size_t>(R_total, 1));
-        DevBuf<Ef> d_final(&ctx, fri.blowup());
-        DevChallenger* dch = reinterpret_cast<DevChallenger*>(d_chal.p);
-
-        uint64_t len = 1ull << log_max_height;
-        DevBuf<Ef> folded = std::move(inputs[0]);
-        size_t next_in = 1;
-        DevBuf<uint32_t> next_tree;
-        bool leaves_ready = false;
-        // rounds done with one launch set each; the rest goes to the tail kernel
-        auto big = [&](uint64_t l) {
-            return l > fri.blowup() && (l > (1ull << FRI_TAIL_LOG) || next_in < inputs.size());
-        };
-        while (big(len)) {  // :111
-            FriRound r;
-            const uint64_t h = len / 2;
-            r.log_leaves = log2_strict(h);
-            DevBuf<uint32_t> tree;
-            if (leaves_ready) {
-                tree = std::move(next_tree);  // leaves were hashed by the previous fold
-            } else {
-                tree = DevBuf<uint32_t>(&ctx, merkle_total_digests(r.log_leaves) * 8);
-                launch_leaf_hash_ef_pairs(ctx, reinterpret_cast<const uint32_t*>(folded.p), h, tree.p);
-            }
-            const size_t ri = rounds.size();
-            // :113 commit_matrix, :114-116 observe + sample (in the kernel that makes the root)
-            if (!launch_merkle_levels(ctx, tree.p, r.log_leaves, dch, d_roots.p + 8 * ri, d_betas.p + ri))
-                launch_chal_round(ctx, dch, tree.p + 8 * (merkle_total_digests(r.log_leaves) - 1),
-                                  d_roots.p + 8 * ri, d_betas.p + ri);
-            DevBuf<Ef> out(&ctx, h);
-            const bool add_pending = next_in < inputs.size() && (1ull << log_lens[next_in]) == h;
-            uint32_t* nd = nullptr;
-            leaves_ready = false;
-            if (!add_pending && big(h)) {  // the next round's leaves can be hashed by this fold
-                next_tree = DevBuf<uint32_t>(&ctx, merkle_total_digests(r.log_leaves - 1) * 8);
-                nd = next_tree.p;
-                leaves_ready = true;
-            }
-            launch_fri_fold_dev(ctx, folded.p, h, d_betas.p + ri, out.p, nd);  // :119 fold_matrix
-            if (add_pending) {  // :124-126 izip!(&mut folded, v).for_each(|(c, x)| *c += x)
-                launch_vec_add(ctx, out.p, inputs[next_in].p, h);
-                keep_vecs.push_back(std::move(inputs[next_in]));
-                next_in++;
-            }
-            r.vec = folded.p;
-            r.tree = tree.p;
-            keep_vecs.push_back(std::move(folded));
-            keep_trees.push_back(std::move(tree));
-            folded = std::move(out);
-            rounds.push_back(r);
-            len = h;
-        }
-        TS_REQUIRE(next_in == inputs.size(), TS_ERR_INVARIANT, "FRI: an input was never folded in");
-        if (len > fri.blowup()) {  // tail rounds in one workgroup
-            const uint32_t L0 = (uint32_t)len;
-            DevBuf<Ef> tail_vecs(&ctx, 2 * (size_t)L0);
-            DevBuf<uint32_t> tail_trees(&ctx, 8 * 2 * (size_t)L0);
-            const size_t ri = rounds.size();
-            launch_fri_tail(ctx, folded.p, L0, fri.blowup(), dch, tail_vecs.p, tail_trees.p,
-                            d_roots.p + 8 * ri, d_betas.p + ri, d_final.p);
-            uint32_t L = L0;
-            size_t voff = 0, toff = 0;
-            while (L > fri.blowup()) {
-                FriRound r;
-                r.log_leaves = log2_strict(L / 2);
-                r.vec = tail_vecs.p + voff;
-                r.tree = tail_trees.p + 8 * toff;
-                rounds.push_back(r);
-                voff += L;
-                toff += L - 1;
-                L >>= 1;
-            }
-            len = L;
-            keep_vecs.push_back(std::move(tail_vecs));
-            keep_trees.push_back(std::move(tail_trees));
-        } else {
-            TS_HIP(hipMemcpyAsync(d_final.p, folded.p, len * sizeof(Ef), hipMemcpyDeviceToDevice,
-                                  ctx.stream));
-        }
-        keep_vecs.push_back(std::move(folded));
-        // :129-134 `blowup` evaluations of a constant polynomial
-        TS_REQUIRE(len == fri.blowup(), TS_ERR_INVARIANT, "FRI: folded length != blowup");
-        TS_REQUIRE(rounds.size() == R_total, TS_ERR_INVARIANT, "FRI: round count");
-        std::vector<Ef> fin(len);
-        std::vector<uint32_t> roots(std::max<size_t>(8 * (size_t)R_total, 8));
-        TS_HIP(hipMemcpyAsync(fin.data(), d_final.p, len * sizeof(Ef), hipMemcpyDeviceToHost, ctx.stream));
-        if (R_total)
-            TS_HIP(hipMemcpyAsync(roots.data(), d_roots.p, 32 * (size_t)R_total, hipMemcpyDeviceToHost,
-                                  ctx.stream));
-        d2h_sync(ctx, &hc, d_chal.p, sizeof hc);
-        challenger.import_dev(hc);
-        for (uint32_t r = 0; r < R_total; r++) memcpy(rounds[r].root, &roots[8 * (size_t)r], 32);
-        final_poly = fin[0];
-        for (auto& x : fin)
-            TS_REQUIRE(ef_eq(x, final_poly), TS_ERR_INVARIANT,
-                       "FRI: final polynomial is not constant (assert_eq!(x, final_poly))");
+        fri_commit_begin(ctx, fri, log_max_height, challenger, st);
+        DevBuf<Ef> first = std::move(inputs[0]);
+        fri_commit_rounds(ctx, fri, std::move(first), 1ull << log_max_height, inputs, log_lens, 1, st);
+        final_poly = fri_commit_finish(ctx, fri, challenger, st);
     }
+    std::vector<FriRound>& rounds = st.rounds;
     const uint32_t R = (uint32_t)rounds.size();
 
     // :43 proof of work

@@ -99,13 +99,14 @@ k_quotient(const uint32_t* __restrict__ code, uint32_t n_instr, uint32_t n_regs,
            const uint32_t* __restrict__ lde, uint64_t col_stride, unsigned log_n, unsigned log_qd,
            const uint32_t* __restrict__ consts_mont, const uint32_t* __restrict__ alpha_pows,
            const uint32_t* __restrict__ is_first, const uint32_t* __restrict__ is_last,
-           const uint32_t* __restrict__ is_transition, QuotConsts qc, QuotOut out) {
+           const uint32_t* __restrict__ is_transition, QuotConsts qc, QuotOut out,
+           uint32_t row_begin, uint32_t row_end) {
     extern __shared__ uint32_t regs[];  // [n_regs][NTHREADS]
     const unsigned L = log_n + log_qd;
-    const uint32_t r = blockIdx.x * NTHREADS + threadIdx.x;  // grid covers exactly 2^L rows
+    const uint32_t r = row_begin + blockIdx.x * NTHREADS + threadIdx.x;
     const uint32_t total = 1u << L;
-    const bool active = r < total;
-    const uint32_t rr = active ? r : 0;
+    const bool active = r < row_end;
+    const uint32_t rr = active ? r : row_begin;
     const uint32_t i = bitrev32(rr, L);
     const uint32_t i_next = (i + (1u << log_qd)) & (total - 1);  // prover.rs:139-140,165
     const uint32_t r_next = bitrev32(i_next, L);
@@ -160,7 +161,7 @@ k_quotient(const uint32_t* __restrict__ code, uint32_t n_instr, uint32_t n_regs,
 void launch_quotient(Context& ctx, const AirProgram& air, const ColMat& trace_lde, unsigned log_n,
                      unsigned log_qd, const uint32_t* d_consts_mont, const uint32_t* d_alpha_pows_mont,
                      const uint32_t* is_first, const uint32_t* is_last, const uint32_t* is_transition,
-                     const QuotOut& out) {
+                     const QuotOut& out, uint64_t row_begin, uint64_t row_end) {
     TS_REQUIRE(air.d_code != nullptr, TS_ERR_INVALID, "air program not uploaded");
     TS_REQUIRE(log_n + log_qd <= 31, TS_ERR_INVALID, "quotient domain too large");
     QuotConsts qc;
@@ -169,14 +170,18 @@ void launch_quotient(Context& ctx, const AirProgram& air, const ColMat& trace_ld
     for (uint32_t c = 0; c < (1u << log_qd); c++)
         qc.inv_zh_canonical[c] = inv_canon(sub(mul(s_pow_n, pow_canon(gqd, c)), 1));
     const uint32_t n_instr = (uint32_t)(air.code.size() / 4);
-    const uint64_t total = 1ull << (log_n + log_qd);
+    if (row_end == 0) row_end = 1ull << (log_n + log_qd);
+    TS_REQUIRE(row_begin < row_end && row_end <= (1ull << (log_n + log_qd)), TS_ERR_INVALID,
+               "quotient: row range");
+    const uint64_t total = row_end - row_begin;  // rows to do
+    uint32_t rb = (uint32_t)row_begin, re = (uint32_t)row_end;
     if (air.jit_fn) {
         // specialised straight-line kernel (jit.cpp); same arguments, same results
         const uint32_t* lde_p = trace_lde.d;
         uint64_t stride = trace_lde.col_stride;
         QuotOut qo = out;
         void* args[] = {&lde_p, &stride, &log_n, &log_qd, &d_consts_mont, &d_alpha_pows_mont,
-                        &is_first, &is_last, &is_transition, &qc, &qo};
+                        &is_first, &is_last, &is_transition, &qc, &qo, &rb, &re};
         KernelTimer kt(&ctx, "k_quotient_jit");
         TS_HIP(hipModuleLaunchKernel((hipFunction_t)air.jit_fn, (unsigned)((total + 255) / 256), 1, 1,
                                      256, 1, 1, 0, ctx.stream, args, nullptr));
@@ -192,7 +197,7 @@ void launch_quotient(Context& ctx, const AirProgram& air, const ColMat& trace_ld
 #define TS_LAUNCH_Q(NTH)                                                                          \
     TS_LAUNCH(ctx, k_quotient<NTH>, dim3(grid), dim3(NTH), lds, air.d_code, n_instr, \
                        air.n_regs, trace_lde.d, trace_lde.col_stride, log_n, log_qd, d_consts_mont, \
-                       d_alpha_pows_mont, is_first, is_last, is_transition, qc, out)
+                       d_alpha_pows_mont, is_first, is_last, is_transition, qc, out, rb, re)
     if (nthreads == 256) TS_LAUNCH_Q(256);
     else if (nthreads == 128) TS_LAUNCH_Q(128);
     else TS_LAUNCH_Q(64);

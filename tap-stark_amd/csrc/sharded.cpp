@@ -1,0 +1,406 @@
+// One proof over G GPUs (BASELINE config 4 "FRI/Merkle sharded over 8 GPUs").
+//
+// Partition: rank g owns the bit-reversed LDE rows [g N/G, (g+1) N/G) of every committed matrix.
+// With G <= 2^log_blowup these are whole cosets of H_n, so that
+//   - the coset NTTs of a rank need only the (replicated) trace: no inter-GPU butterflies,
+//   - a slab is a Merkle sub-tree: only the G sub-roots (32 B each) are exchanged per tree,
+//   - the quotient's `next` row (natural index + qd) stays inside a coset,
+//   - the reduce step is row-local, the opened values are interpolated on an owned coset,
+//   - FRI folds adjacent rows (2i, 2i+1): local while a slab has >= 2 values,
+//   - a query index and all its shifted indices index >> k belong to one rank.
+// Exchange steps (collectives supplied by the host, RCCL over xGMI in production):
+//   1. all-gather of the trace row slices (n w 4 / G bytes per rank) -- the one bulk transfer,
+//   2. broadcast of each quotient chunk from the rank that owns its coset (16 n bytes),
+//   3. all-gather of G sub-roots per tree (2 commits + one per sharded FRI round),
+//   4. all-gather of the FRI vector when the slabs get short (the rest runs replicated),
+//   5. all-gather of the answered queries.
+// The transcript is replicated: every rank observes the same roots and samples the same challenges.
+// Proofs are bit-identical to prove()'s (tests/test_gpu_sharded.py).
+#include <string.h>
+
+#include "fri_internal.hpp"
+
+namespace ts {
+
+namespace {
+
+struct Shard {
+    Context& ctx;
+    const FriConfig& fri;
+    const Comm& comm;
+    uint32_t G, rank, log_G;
+    uint32_t cosets, beta0;  // cosets per rank, first owned coset
+};
+
+// what one rank keeps of a committed batch
+struct ShardedData {
+    PcsData local;              // slab LDEs (height N/G) and the slab's Merkle tree
+    unsigned log_global = 0;    // log2 N
+    std::vector<uint32_t> top;  // (2G-1) x 8 words: the G sub-roots, ..., the root
+    uint32_t root[8];
+};
+
+// sub-root of this rank -> gathered sub-roots -> top levels (+ challenger step) on the device
+void gather_top(Shard& sh, const uint32_t* d_subroot, uint32_t* d_top, DevChallenger* dch,
+                uint32_t* d_root_out, Ef* d_beta_out) {
+    DevBuf<uint32_t> all(&sh.ctx, 8 * (size_t)sh.G);
+    sh.comm.all_gather(d_subroot, all.p, 32, sh.ctx.stream);
+    launch_shard_top(sh.ctx, all.p, sh.G, d_top, dch, d_root_out, d_beta_out);
+}
+
+// two_adic_pcs.rs:227-245 for the owned cosets + the slab's sub-tree; `evals` are whole matrices
+std::unique_ptr<ShardedData> commit_sharded(Shard& sh, std::vector<DeviceMatrix>& evals,
+                                            const std::vector<uint32_t>& domain_shifts) {
+    Context& ctx = sh.ctx;
+    TS_REQUIRE(!evals.empty() && evals.size() <= (size_t)MAX_BATCH_MATS, TS_ERR_INVALID,
+               "commit: between 1 and 16 matrices per batch");
+    const uint64_t n = evals[0].height;
+    const unsigned log_n = log2_strict(n);
+    const unsigned log_N = log_n + sh.fri.log_blowup;
+    TS_REQUIRE(log_N <= 27, TS_ERR_INVALID, "commit: LDE larger than the two-adic subgroup");
+    const uint64_t rows = (uint64_t)sh.cosets << log_n;  // slab height
+    const unsigned log_rows = log2_strict(rows);
+    ctx.ensure_twiddles(std::max(1u, log_N));
+
+    auto data = std::make_unique<ShardedData>();
+    data->log_global = log_N;
+    PcsData& loc = data->local;
+    loc.log_height = log_rows;
+    {
+        StageTimer t(&ctx, "coset_lde");
+        for (size_t i = 0; i < evals.size(); i++) {
+            DeviceMatrix& m = evals[i];
+            TS_REQUIRE(m.height == n && m.width >= 1 && m.buf.p, TS_ERR_INVALID,
+                       "sharded commit: matrices of one height expected");
+            DevBuf<uint32_t> colmajor;
+            uint32_t* ev = m.buf.p;
+            if (m.layout == DeviceMatrix::ROW_MAJOR) {
+                colmajor = DevBuf<uint32_t>(&ctx, (size_t)m.width * n);
+                launch_transpose_bitrev(ctx, m.buf.p, colmajor.p, log_n, m.width, n);
+                ev = colmajor.p;
+            }
+            DevBuf<uint32_t> lde(&ctx, (size_t)m.width * rows);
+            const uint32_t shift = mul(GENERATOR, inv_canon(domain_shifts[i]));  // two_adic_pcs.rs:235
+            coset_lde(ctx, ev, n, m.width, log_n, sh.fri.log_blowup, shift, lde.p, rows, sh.beta0, sh.cosets);
+            ColMat cm;
+            cm.d = lde.p;
+            cm.height = rows;
+            cm.width = m.width;
+            cm.col_stride = rows;
+            loc.ldes.push_back(cm);
+            loc.lde_storage.push_back(std::move(lde));
+            m.buf.reset();  // consumed
+        }
+    }
+    {
+        StageTimer t(&ctx, "merkle_commit");
+        loc.tree = DevBuf<uint32_t>(&ctx, merkle_total_digests(log_rows) * 8);
+        std::vector<const uint32_t*> cols;
+        for (auto& cm : loc.ldes)
+            for (uint32_t c = 0; c < cm.width; c++) cols.push_back(cm.d + (uint64_t)c * cm.col_stride);
+        loc.col_table = DevBuf<const uint32_t*>(&ctx, cols.size());
+        h2d(ctx, loc.col_table.p, cols.data(), cols.size() * sizeof(const uint32_t*));
+        launch_leaf_hash(ctx, loc.leaf_mats(), rows, loc.tree.p);
+        launch_merkle_levels(ctx, loc.tree.p, log_rows);
+        DevBuf<uint32_t> d_top(&ctx, 8 * (size_t)(2 * sh.G - 1));
+        gather_top(sh, loc.tree.p + 8 * (merkle_total_digests(log_rows) - 1), d_top.p, nullptr, nullptr,
+                   nullptr);
+        data->top.resize(8 * (size_t)(2 * sh.G - 1));
+        d2h_sync(ctx, data->top.data(), d_top.p, data->top.size() * 4);  // also covers `cols`
+        memcpy(data->root, &data->top[8 * (size_t)(2 * sh.G - 2)], 32);
+        memcpy(loc.root, &data->top[8 * (size_t)sh.rank], 32);
+    }
+    return data;
+}
+
+// siblings of sub-tree `rank` in the top levels, leaf-most first
+void push_top_path(std::vector<uint32_t>& out, const uint32_t* top, uint32_t G, uint32_t rank) {
+    uint32_t off = 0;
+    for (uint32_t cnt = G, l = 0; cnt > 1; cnt >>= 1, l++) {
+        const uint32_t* node = top + 8 * (size_t)(off + ((rank >> l) ^ 1));
+        out.insert(out.end(), node, node + 8);
+        off += cnt;
+    }
+}
+
+}  // namespace
+
+std::vector<uint32_t> prove_sharded(TwoAdicFriPcs& pcs, const Comm& comm, const AirProgram& air,
+                                    BfChallenger& challenger, DeviceMatrix trace_rows,
+                                    const std::vector<uint32_t>& public_values, const ShardOptions& opt) {
+    Context& ctx = pcs.ctx();
+    const FriConfig& fri = pcs.fri();
+    TS_REQUIRE(comm.world >= 1 && comm.rank >= 0 && comm.rank < comm.world && comm.all_gather &&
+                   comm.broadcast,
+               TS_ERR_INVALID, "prove_sharded: bad communicator");
+    const uint32_t G = (uint32_t)comm.world;
+    TS_REQUIRE((G & (G - 1)) == 0 && G <= fri.blowup(), TS_ERR_UNSUPPORTED,
+               "prove_sharded: the number of ranks must be a power of two <= 2^log_blowup (whole "
+               "cosets per rank); run independent proofs per GPU otherwise");
+    Shard sh{ctx, fri, comm, G, (uint32_t)comm.rank, log2_strict(G), fri.blowup() / G,
+             (uint32_t)comm.rank * (fri.blowup() / G)};
+    TS_REQUIRE(trace_rows.width == air.width, TS_ERR_INVALID, "prove: trace width != AIR width");
+    TS_REQUIRE(trace_rows.layout == DeviceMatrix::ROW_MAJOR && trace_rows.buf.p, TS_ERR_INVALID,
+               "prove_sharded: the trace slice must be an uploaded row-major matrix");
+    TS_REQUIRE(public_values.size() == air.n_public, TS_ERR_INVALID,
+               "prove: wrong number of public values");
+    const uint32_t w = air.width;
+    const uint64_t degree = trace_rows.height * G;  // prover.rs:43-44
+    const unsigned log_degree = log2_strict(degree);
+    const unsigned lqd = air.log_quotient_degree;
+    const uint32_t qd = 1u << lqd;
+    const unsigned log_N = log_degree + fri.log_blowup;
+    const uint64_t N = 1ull << log_N, n = degree;
+    const uint64_t loc0 = N / G;  // slab height
+    TS_REQUIRE(lqd <= fri.log_blowup, TS_ERR_INVARIANT,
+               "quotient domain larger than the committed LDE (log_quotient_degree > log_blowup)");
+    ctx.ensure_twiddles(std::max(1u, log_N));
+    TwoAdicFriPcs::Slab slab;
+    slab.row0 = (uint64_t)sh.rank * loc0;
+    slab.rows = loc0;
+    slab.beta0 = sh.beta0;
+
+    // ---- exchange 1: every rank gets the whole trace (row slices in rank order = natural order)
+    DeviceMatrix trace;
+    {
+        StageTimer t(&ctx, "all-gather trace");
+        trace.buf = DevBuf<uint32_t>(&ctx, (size_t)n * w);
+        trace.height = n;
+        trace.width = w;
+        trace.layout = DeviceMatrix::ROW_MAJOR;
+        comm.all_gather(trace_rows.buf.p, trace.buf.p, (size_t)trace_rows.height * w * 4, ctx.stream);
+        trace_rows.buf.reset();
+    }
+
+    // prover.rs:50-63
+    std::vector<DeviceMatrix> tv;
+    tv.push_back(std::move(trace));
+    std::unique_ptr<ShardedData> trace_data = commit_sharded(sh, tv, {1u});
+    challenger.observe_commitment(trace_data->root);
+    const Ef alpha = challenger.sample();
+
+    // :65-80 the quotient domain is the first qd cosets: chunk c = coset bitrev(c), computed by the
+    // rank that owns that coset, then broadcast (exchange 2)
+    std::vector<DeviceMatrix> chunks =
+        pcs.quotient_chunks_slab(trace_data->local.ldes[0], log_degree, slab, air, public_values, alpha);
+    {
+        StageTimer t(&ctx, "broadcast quotient chunks");
+        for (uint32_t c = 0; c < qd; c++) {
+            const uint32_t owner = bitrev32(c, lqd) / sh.cosets;
+            comm.broadcast(chunks[c].buf.p, (size_t)n * 16, (int)owner, ctx.stream);
+        }
+    }
+    std::vector<uint32_t> qshifts(qd);
+    const uint32_t gq = two_adic_generator(log_degree + lqd);
+    for (uint32_t c = 0; c < qd; c++) qshifts[c] = mul(GENERATOR, pow_canon(gq, c));
+    std::unique_ptr<ShardedData> quotient_data = commit_sharded(sh, chunks, qshifts);  // :82-83
+    challenger.observe_commitment(quotient_data->root);                                 // :84
+    const Ef zeta = challenger.sample();                                                // :91
+
+    // :94-104 open: values from an owned coset, reduce on the slab
+    const Ef batch_alpha = challenger.sample();
+    std::vector<Ef> opened;
+    DevBuf<Ef> folded =
+        pcs.open_reduce_slab(trace_data->local, quotient_data->local, log_N, slab, zeta, batch_alpha, opened);
+
+    // ---- bf_commit_phase (fri/src/prover.rs:93-141): sharded rounds, then replicated rounds
+    FriCommit st;
+    Ef final_poly;
+    uint32_t R_sh = 0;                // sharded rounds: st.rounds[0..R_sh) describe slabs
+    DevBuf<uint32_t> d_tops;          // [R_sh][2G-1][8]
+    std::vector<uint32_t> tops;
+    const size_t top_words = 8 * (size_t)(2 * G - 1);
+    {
+        StageTimer t(&ctx, "FRI commit phase");
+        fri_commit_begin(ctx, fri, log_N, challenger, st);
+        d_tops = DevBuf<uint32_t>(&ctx, std::max<size_t>(top_words * st.R_total, 8));
+        uint64_t len = N, loc = loc0;
+        const uint64_t min_loc = std::max<uint64_t>(2, 1ull << opt.min_local_log);
+        auto sharded_round = [&](uint64_t l_glob, uint64_t l_loc) {
+            return l_glob > fri.blowup() && l_loc >= min_loc;
+        };
+        DevBuf<uint32_t> next_tree;
+        bool leaves_ready = false;
+        while (sharded_round(len, loc)) {
+            FriRound r;
+            const uint64_t h_loc = loc / 2, h_glob = len / 2;
+            r.log_leaves = log2_strict(h_loc);
+            DevBuf<uint32_t> tree;
+            if (leaves_ready) {
+                tree = std::move(next_tree);
+            } else {
+                tree = DevBuf<uint32_t>(&ctx, merkle_total_digests(r.log_leaves) * 8);
+                launch_leaf_hash_ef_pairs(ctx, reinterpret_cast<const uint32_t*>(folded.p), h_loc, tree.p);
+            }
+            const size_t ri = st.rounds.size();
+            launch_merkle_levels(ctx, tree.p, r.log_leaves);  // the slab's sub-tree
+            // exchange 3; the top kernel observes the root and samples beta on every rank alike
+            gather_top(sh, tree.p + 8 * (merkle_total_digests(r.log_leaves) - 1), d_tops.p + top_words * ri,
+                       st.dch(), st.d_roots.p + 8 * ri, st.d_betas.p + ri);
+            DevBuf<Ef> out(&ctx, h_loc);
+            uint32_t* nd = nullptr;
+            leaves_ready = false;
+            if (sharded_round(h_glob, h_loc)) {
+                next_tree = DevBuf<uint32_t>(&ctx, merkle_total_digests(r.log_leaves - 1) * 8);
+                nd = next_tree.p;
+                leaves_ready = true;
+            }
+            launch_fri_fold_dev(ctx, folded.p, h_loc, st.d_betas.p + ri, out.p, nd, h_glob,
+                                (uint64_t)sh.rank * h_loc);
+            r.vec = folded.p;
+            r.tree = tree.p;
+            st.keep_vecs.push_back(std::move(folded));
+            st.keep_trees.push_back(std::move(tree));
+            folded = std::move(out);
+            st.rounds.push_back(r);
+            len = h_glob;
+            loc = h_loc;
+            R_sh++;
+        }
+        // exchange 4: the rest is short; every rank folds the whole vector
+        DevBuf<Ef> full(&ctx, len);
+        comm.all_gather(folded.p, full.p, (size_t)loc * sizeof(Ef), ctx.stream);
+        st.keep_vecs.push_back(std::move(folded));
+        std::vector<DevBuf<Ef>> no_inputs;
+        fri_commit_rounds(ctx, fri, std::move(full), len, no_inputs, {}, 0, st);
+        tops.resize(std::max<size_t>(top_words * R_sh, 8));
+        if (R_sh)
+            TS_HIP(hipMemcpyAsync(tops.data(), d_tops.p, top_words * R_sh * 4, hipMemcpyDeviceToHost,
+                                  ctx.stream));
+        final_poly = fri_commit_finish(ctx, fri, challenger, st);
+    }
+    const uint32_t R = (uint32_t)st.rounds.size();
+
+    uint32_t pow_witness;
+    {
+        StageTimer t(&ctx, "grind for proof-of-work witness");
+        pow_witness = challenger.grind(fri.proof_of_work_bits);  // prover.rs:43
+    }
+
+    // ---- query phase (prover.rs:45-59): a rank answers the queries that fall into its slab
+    StageTimer tq(&ctx, "query phase");
+    const uint32_t Q = fri.num_queries;
+    std::vector<uint32_t> indices(Q);
+    for (uint32_t q = 0; q < Q; q++) indices[q] = (uint32_t)challenger.sample_bits(log_N);
+    std::vector<uint32_t> own, li, gi;
+    for (uint32_t q = 0; q < Q; q++)
+        if (indices[q] / loc0 == sh.rank) {
+            own.push_back(q);
+            li.push_back((uint32_t)(indices[q] - slab.row0));
+            gi.push_back(indices[q]);
+        }
+    const uint32_t n_own = (uint32_t)own.size();
+    const ShardedData* in_rounds[2] = {trace_data.get(), quotient_data.get()};
+    const unsigned log_loc0 = log2_strict(loc0);
+    // words of one answered query (the same for every query)
+    size_t wpq = 1;
+    for (auto* d : in_rounds) {
+        wpq += 1 + d->local.ldes.size() + 1 + 8 * (size_t)log_N;
+        for (auto& m : d->local.ldes) wpq += m.width;
+    }
+    for (uint32_t r = 0; r < R; r++) wpq += 8 + 1 + 8 * (size_t)(log_N - 1 - r);
+    std::vector<uint32_t> seg((size_t)Q * wpq, 0);
+    if (n_own) {
+        DevBuf<uint32_t> d_li(&ctx, n_own), d_gi(&ctx, n_own);
+        h2d(ctx, d_li.p, li.data(), n_own * 4);
+        h2d(ctx, d_gi.p, gi.data(), n_own * 4);
+        LeafMats lms[2];
+        size_t o_rows[2], o_path[2], off = 0;
+        for (int k = 0; k < 2; k++) {
+            lms[k] = in_rounds[k]->local.leaf_mats();
+            o_rows[k] = off; off += (size_t)n_own * lms[k].total_width;
+            o_path[k] = off; off += (size_t)n_own * 8 * log_loc0;
+        }
+        std::vector<size_t> o_fvals(R), o_fpath(R);
+        for (uint32_t r = 0; r < R; r++) {
+            o_fvals[r] = off; off += (size_t)n_own * 8;
+            o_fpath[r] = off; off += (size_t)n_own * 8 * st.rounds[r].log_leaves;
+        }
+        DevBuf<uint32_t> d_out(&ctx, std::max<size_t>(off, 1));
+        for (int k = 0; k < 2; k++) {
+            launch_gather_rows(ctx, lms[k], d_li.p, n_own, 0, d_out.p + o_rows[k]);
+            launch_gather_paths(ctx, in_rounds[k]->local.tree.p, log_loc0, d_li.p, n_own, 0,
+                                d_out.p + o_path[k]);
+        }
+        // bf_answer_query :69-90: sharded rounds by local index, replicated rounds by global index
+        std::vector<FriGatherDesc> descs(std::max(R, 1u));
+        uint32_t max_sh = 0, max_rep = 0;
+        for (uint32_t r = 0; r < R; r++) {
+            descs[r].vec = reinterpret_cast<const uint32_t*>(st.rounds[r].vec);
+            descs[r].tree = st.rounds[r].tree;
+            descs[r].log_leaves = st.rounds[r].log_leaves;
+            descs[r].shift = r + 1;
+            descs[r].out_vals = o_fvals[r];
+            descs[r].out_path = o_fpath[r];
+            (r < R_sh ? max_sh : max_rep) = std::max(r < R_sh ? max_sh : max_rep, st.rounds[r].log_leaves);
+        }
+        DevBuf<FriGatherDesc> d_descs(&ctx, descs.size());
+        h2d(ctx, d_descs.p, descs.data(), descs.size() * sizeof(FriGatherDesc));
+        launch_gather_fri(ctx, d_descs.p, R_sh, max_sh, d_li.p, n_own, d_out.p);
+        launch_gather_fri(ctx, d_descs.p + R_sh, R - R_sh, max_rep, d_gi.p, n_own, d_out.p);
+        std::vector<uint32_t> g(std::max<size_t>(off, 1));
+        d2h_sync(ctx, g.data(), d_out.p, off * 4);
+
+        std::vector<uint32_t> one;
+        for (uint32_t j = 0; j < n_own; j++) {
+            one.clear();
+            auto push = [&](uint32_t v) { one.push_back(v); };
+            auto push_n = [&](const uint32_t* p, size_t k) { one.insert(one.end(), p, p + k); };
+            push(2);  // input_proof: one BatchOpening per commit round (two_adic_pcs.rs:399-414)
+            for (int k = 0; k < 2; k++) {
+                push(lms[k].n_mats);
+                size_t c = o_rows[k] + (size_t)j * lms[k].total_width;
+                for (uint32_t i = 0; i < lms[k].n_mats; i++) {
+                    push(lms[k].width[i]);
+                    push_n(&g[c], lms[k].width[i]);
+                    c += lms[k].width[i];
+                }
+                push(log_N);
+                push_n(&g[o_path[k] + (size_t)j * 8 * log_loc0], 8 * (size_t)log_loc0);
+                push_top_path(one, in_rounds[k]->top.data(), G, sh.rank);
+            }
+            for (uint32_t r = 0; r < R; r++) {  // commit_phase_openings
+                const unsigned ll = st.rounds[r].log_leaves;
+                push_n(&g[o_fvals[r] + (size_t)j * 8], 8);
+                push(log_N - 1 - r);
+                push_n(&g[o_fpath[r] + (size_t)j * 8 * ll], 8 * (size_t)ll);
+                if (r < R_sh) push_top_path(one, &tops[top_words * r], G, sh.rank);
+            }
+            TS_REQUIRE(one.size() == wpq, TS_ERR_INVARIANT, "sharded query: segment size");
+            memcpy(&seg[(size_t)own[j] * wpq], one.data(), wpq * 4);
+        }
+    }
+    // ---- exchange 5: collect the answers
+    std::vector<uint32_t> all_seg((size_t)G * Q * wpq);
+    if (Q) {
+        DevBuf<uint32_t> d_seg(&ctx, seg.size()), d_all(&ctx, all_seg.size());
+        h2d(ctx, d_seg.p, seg.data(), seg.size() * 4);
+        comm.all_gather(d_seg.p, d_all.p, seg.size() * 4, ctx.stream);
+        d2h_sync(ctx, all_seg.data(), d_all.p, all_seg.size() * 4);
+    }
+
+    // ---- Proof (uni-stark/src/prover.rs:105-118) in TSPF v1 order
+    std::vector<uint32_t> pf;
+    pf.reserve(64 + opened.size() * 4 + 8 * (size_t)R + (size_t)Q * wpq);
+    pf.push_back(TSPF_MAGIC);
+    pf.push_back(1);
+    pf.push_back(log_degree);
+    pf.push_back(w);
+    pf.push_back(qd);
+    pf.insert(pf.end(), trace_data->root, trace_data->root + 8);
+    pf.insert(pf.end(), quotient_data->root, quotient_data->root + 8);
+    for (auto& e : opened) pf.insert(pf.end(), e.c, e.c + 4);
+    pf.push_back(R);
+    for (uint32_t r = 0; r < R; r++) pf.insert(pf.end(), st.rounds[r].root, st.rounds[r].root + 8);
+    pf.push_back(Q);
+    for (uint32_t q = 0; q < Q; q++) {
+        const size_t owner = indices[q] / loc0;
+        const uint32_t* s = &all_seg[(owner * Q + q) * wpq];
+        pf.insert(pf.end(), s, s + wpq);
+    }
+    pf.insert(pf.end(), final_poly.c, final_poly.c + 4);
+    pf.push_back(pow_witness);
+    return pf;
+}
+
+}  // namespace ts

@@ -494,6 +494,42 @@ def prove(config: StarkConfig, air, challenger: BfChallenger, trace, public_valu
     return Proof.parse(out[: n_words.value].copy())
 
 
+def prove_sharded(config: StarkConfig, air, challenger: BfChallenger, trace_rows, public_values,
+                  comm, min_local_log: int = 0) -> Proof:
+    """One proof over ``comm.world`` GPUs (``ts_prove_sharded``).
+
+    Every rank calls this with its own context, a challenger in the same state and its row slice
+    ``trace_rows`` = natural rows [g n/G, (g+1) n/G) of the trace; every rank gets the whole proof,
+    bit-identical to :func:`prove` on the whole trace.  ``comm`` is a ``dist.TorchComm``.
+    """
+    pcs = config.pcs
+    ctx = pcs.ctx
+    pis = _u32(public_values)
+    if isinstance(air, BaseAir):
+        air = CompiledAir(ctx, air_tape(air, len(pis)))
+    if not isinstance(trace_rows, DeviceMatrix):
+        trace_rows = DeviceMatrix.upload(ctx, trace_rows)
+    n_loc, w = trace_rows.dims()
+    n = n_loc * comm.world
+    log_N = n.bit_length() - 1 + pcs.fri.log_blowup
+    qd = 1 << air.log_quotient_degree
+    R = log_N - pcs.fri.log_blowup
+    Q = pcs.fri.num_queries
+    cap = (64 + 8 * w + 16 * qd + 8 * R
+           + Q * (16 + w + 5 * qd + 2 * 8 * log_N + R * (9 + 8 * log_N)))
+    out = np.zeros(cap, dtype=np.uint32)
+    n_words = C.c_size_t()
+    cfg = pcs.fri._c()
+    pis_p = _p(pis) if len(pis) else None
+    rc = ctx._l.ts_prove_sharded(ctx.h, C.byref(cfg), C.byref(comm.c), air.h, challenger.h,
+                                 trace_rows.h, pis_p, len(pis), min_local_log, _p(out), cap,
+                                 C.byref(n_words))
+    if rc == 7 and getattr(comm, "error", None):
+        raise RuntimeError("communicator callback failed:\n" + comm.error)
+    ctx.check(rc)
+    return Proof.parse(out[: n_words.value].copy())
+
+
 VERIFY_ERRORS = {0: "Ok", 1: "InvalidProofShape", 2: "InvalidOpeningArgument(InvalidProofShape)",
                  3: "InvalidOpeningArgument(InvalidPowWitness)", 4: "InvalidOpeningArgument(InputError)",
                  5: "InvalidOpeningArgument(CommitPhaseMmcsError)",

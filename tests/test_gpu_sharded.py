@@ -1,0 +1,140 @@
+"""One proof sharded over several ranks: bit-identical to prove().
+
+The GPU box has ONE card: the ranks of a multi-rank case are separate processes that share it and
+talk over gloo (host-staged collectives, the CPU rehearsal of the RCCL path); the nccl (= RCCL)
+callback path itself -- zero-copy wrapping of the library's device buffers, collectives enqueued
+behind the library's HIP stream -- runs with a world of one rank.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import tapstark_amd as ts
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from _sharded_worker import make_case  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from tapstark_amd.build import build
+
+    build()
+    return ts.default_context()
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def run_ranks(tmp_path, spec):
+    spec = dict(spec, port=free_port(), out=str(tmp_path / "proof"))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = []
+    for r in range(spec["world"]):
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_sharded_worker.py"),
+                                       json.dumps(spec)], env=dict(env, RANK=str(r)),
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out)
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, f"rank {r} failed:\n{outs[r][-3000:]}"
+    proofs = [np.load(f"{spec['out']}.rank{r}.npy") for r in range(spec["world"])]
+    metas = [json.load(open(f"{spec['out']}.rank{r}.json")) for r in range(spec["world"])]
+    return proofs, metas
+
+
+def single_gpu_proof(ctx, spec):
+    air, trace, pis = make_case(spec["air"], spec["log_n"])
+    config = ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(*spec["cfg"]), ctx))
+    ch = ts.BfChallenger()
+    proof = ts.prove(config, air, ch, trace, pis)
+    ts.verify(config, air, ts.BfChallenger(), proof, pis)
+    return proof, ch.sample_bits(20), (air, pis)
+
+
+CASES = [
+    # air, log_n, (log_blowup, queries, pow), world, min_local_log
+    ("fib", 8, (1, 6, 8), 2, 1),
+    ("fib", 10, (2, 9, 8), 2, 3),
+    ("fib", 10, (2, 9, 8), 4, 1),
+    ("mul7", 9, (2, 7, 8), 4, 2),
+    ("mul64", 10, (2, 28, 8), 4, 4),
+    ("mul64", 11, (3, 16, 8), 4, 12),   # two cosets per rank; every FRI round replicated
+    ("mul64", 13, (2, 28, 8), 2, 10),   # two-pass NTT (n > 4096), cosets split 2 + 2
+    ("ext25", 8, (2, 5, 8), 4, 1),
+]
+
+
+@pytest.mark.parametrize("air,log_n,cfg,world,mll", CASES,
+                         ids=[f"{c[0]}-2p{c[1]}-b{c[2][0]}-G{c[3]}-m{c[4]}" for c in CASES])
+def test_sharded_proof_bit_identical(ctx, orc, tmp_path, air, log_n, cfg, world, mll):
+    spec = {"air": air, "log_n": log_n, "cfg": list(cfg), "world": world, "backend": "gloo",
+            "min_local_log": mll}
+    want, want_bits, (air_obj, pis) = single_gpu_proof(ctx, spec)
+    proofs, metas = run_ranks(tmp_path, spec)
+    for r, p in enumerate(proofs):
+        assert len(p) == len(want.words), f"rank {r}: proof length"
+        assert (p == want.words).all(), f"rank {r}: {int((p != want.words).sum())} words differ"
+        # the transcript ends in the same state on every rank (prover.rs takes &mut challenger)
+        assert metas[r]["chal_bits"] == want_bits
+    tape = ts.air_tape(air_obj, len(pis))
+    assert orc.verify(orc.FriConfig(*cfg), tape, proofs[0], pis) == 0
+    # exchange steps: trace all-gather + 2 commits + sharded FRI rounds + FRI vector + answers
+    assert metas[0]["calls"]["all_gather"] >= 5
+    assert metas[0]["calls"]["broadcast"] == 1 << ts.CompiledAir(ctx, tape).log_quotient_degree
+
+
+def test_sharded_world_of_one_over_rccl(ctx, tmp_path):
+    # nccl backend (RCCL): device buffers wrapped in place, collectives ordered on the HIP stream
+    spec = {"air": "mul64", "log_n": 12, "cfg": [2, 28, 8], "world": 1, "backend": "nccl",
+            "min_local_log": 6}
+    want, want_bits, _ = single_gpu_proof(ctx, spec)
+    proofs, metas = run_ranks(tmp_path, spec)
+    assert (proofs[0] == want.words).all()
+    assert metas[0]["chal_bits"] == want_bits
+
+
+def test_sharded_rejects_partial_cosets(ctx, tmp_path):
+    # G > 2^log_blowup would split cosets: TS_ERR_UNSUPPORTED, as documented
+    spec = {"air": "fib", "log_n": 8, "cfg": [1, 4, 8], "world": 4, "backend": "gloo",
+            "min_local_log": 1, "port": free_port(), "out": str(tmp_path / "x")}
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", RANK="0")
+    spec1 = dict(spec, world=1)
+    # a world of one with a communicator that claims four ranks
+    code = (
+        "import sys, json, numpy as np, torch, torch.distributed as dist\n"
+        f"sys.path.insert(0, {os.path.dirname(HERE)!r}); sys.path.insert(0, {HERE!r})\n"
+        "import tapstark_amd as ts\n"
+        "from tapstark_amd.dist import TorchComm\n"
+        "from _sharded_worker import make_case\n"
+        f"spec = json.loads({json.dumps(json.dumps(spec1))})\n"
+        "dist.init_process_group('gloo', init_method=f\"tcp://127.0.0.1:{spec['port']}\", rank=0, world_size=1)\n"
+        "ctx = ts.default_context()\n"
+        "air, trace, pis = make_case('fib', 8)\n"
+        "comm = TorchComm(0); comm.c.world = 4; comm.world = 4\n"
+        "cfg = ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(1, 4, 8), ctx))\n"
+        "try:\n"
+        "    ts.prove_sharded(cfg, air, ts.BfChallenger(), trace[:64], pis, comm)\n"
+        "except Exception as e:\n"
+        "    print('ERR', e); sys.exit(0 if 'TS_ERR_UNSUPPORTED' in str(e) else 3)\n"
+        "sys.exit(4)\n"
+    )
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=240)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]

@@ -7,8 +7,11 @@ One "step" = one complete prove() (commit trace -> quotient -> commit chunks -> 
 queries -> proof on the host) of BASELINE.json configs[2]: the build-defined SynthMulAir-64 trace,
 2^20 rows x 64 columns, log_blowup 2, 28 queries, 8 PoW bits, with the trace already resident in
 HBM when the timed region starts.  N > 1 (launched by torch.distributed.run, one rank per GPU):
-every rank proves its own independent trace -- "replicas only" this round (DESIGN.md section
-"Multi-GPU"), so scaling is weak and `value` is the aggregate over ranks.
+by default every rank proves its own independent traces (proofs are independent objects: no
+data-path collective, weak scaling, `value` is the aggregate over ranks).  `--mode sharded` instead
+splits ONE proof over the ranks (tap-stark_amd/csrc/sharded.cpp; needs N <= 2^log_blowup; RCCL
+all-gathers of the trace, the Merkle sub-roots and the FRI tail) -- strong scaling, the latency mode
+meant for BASELINE config 4 (`--workload config4`).
 
 Prints ONE JSON line on rank 0 with the driver's contract fields plus:
   roofline     -- the dominant kernel's achieved algorithmic-bytes rate from HIP events recorded
@@ -47,6 +50,12 @@ def workload(name: str, log_n: int):
         trace = generate_fibonacci_trace(0, 1, n)
         pis = fibonacci_public_values(trace)
         desc = f"Fibonacci AIR, trace 2^{log_n}x2, log_blowup=2, 28 queries, pow 8"
+    elif name == "config4":
+        air = SynthMulAir(64)
+        trace = generate_synth_mul_trace(n)
+        pis = np.zeros(0, dtype=np.uint32)
+        desc = f"SynthMulAir-64 (build-defined), trace 2^{log_n}x64, log_blowup=4, 16 queries, pow 8"
+        return air, trace, pis, desc, (4, 16, 8)
     else:
         raise SystemExit(f"unknown workload {name}")
     return air, trace, pis, desc, (2, 28, 8)
@@ -120,13 +129,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="config3", choices=["config3", "config2"])
-    ap.add_argument("--log-n", type=int, default=20)
+    ap.add_argument("--workload", default="config3", choices=["config3", "config2", "config4"])
+    ap.add_argument("--log-n", type=int, default=None, help="default 20 (22 for config4)")
+    ap.add_argument("--mode", default="replicas", choices=["replicas", "sharded"],
+                    help="N > 1: independent proofs per GPU (default) or one proof over all GPUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("TS_BENCH_STREAMS", "4")),
                     help="independent proofs in flight per GPU (one context = one HIP stream and one "
                          "host thread each); the K timed steps are shared among them")
     args = ap.parse_args()
+    if args.log_n is None:
+        args.log_n = 22 if args.workload == "config4" else 20
+    sharded = args.mode == "sharded"
 
     from tapstark_amd.benchutil import init_dist, run_timed
 
@@ -152,7 +166,7 @@ def main():
     # Proofs are independent, so S of them are kept in flight per GPU: S contexts (one HIP stream,
     # one device pool and one host thread each).  The serial transcript of one proof leaves the
     # GPU idle at its host round trips; the next proof's kernels fill those gaps.
-    S = max(1, min(args.streams, args.steps))
+    S = 1 if sharded else max(1, min(args.streams, args.steps))
     lanes = [(ctx, config, cair)]
     for _ in range(1, S):
         c2 = ts.Context(dev)
@@ -162,12 +176,29 @@ def main():
     # inputs resident in HBM before the timed region (prove() consumes its trace, like the
     # reference's moved RowMajorMatrix, so one copy per step); step i runs on lane i % S
     total = args.warmup + args.steps
-    mats = [ts.DeviceMatrix.upload(lanes[i % S][0], trace) for i in range(total)]
     last = {}
+    if sharded:
+        # one proof per step over all ranks: rank g is handed natural rows [g n/G, (g+1) n/G)
+        import torch
+        import torch.distributed as dist
+        from tapstark_amd.dist import TorchComm
 
-    def prove_one(i):
-        c, conf, ca = lanes[i % S]
-        last["proof"] = ts.prove(conf, ca, ts.BfChallenger(), mats[i], pis)
+        if env.dist is None:  # a world of one still goes through the RCCL callbacks
+            torch.cuda.set_device(dev)
+            dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29512", rank=0, world_size=1,
+                                    device_id=torch.device("cuda", dev))
+        comm = TorchComm(dev)
+        rows = np.ascontiguousarray(trace[env.rank * n // env.world:(env.rank + 1) * n // env.world])
+        mats = [ts.DeviceMatrix.upload(ctx, rows) for _ in range(total)]
+
+        def prove_one(i):
+            last["proof"] = ts.prove_sharded(config, cair, ts.BfChallenger(), mats[i], pis, comm)
+    else:
+        mats = [ts.DeviceMatrix.upload(lanes[i % S][0], trace) for i in range(total)]
+
+        def prove_one(i):
+            c, conf, ca = lanes[i % S]
+            last["proof"] = ts.prove(conf, ca, ts.BfChallenger(), mats[i], pis)
 
     if S == 1:
         step = prove_one
@@ -191,8 +222,11 @@ def main():
             import torch
             torch.cuda.synchronize()
 
-    res = run_timed(env, step, args.steps, args.warmup, local_sync, units_per_step=float(n * w),
-                    run_steps=run_steps)
+    # sharded: the ranks share each step's n*w cells
+    res = run_timed(env, step, args.steps, args.warmup, local_sync,
+                    units_per_step=float(n * w) / (env.world if sharded else 1), run_steps=run_steps)
+    if sharded:
+        res["steps_per_sec"] = args.steps / res["elapsed_s"]
 
     out = None
     if env.rank == 0:
@@ -230,7 +264,7 @@ def main():
         try:
             import glob
             pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
-            if pmc_files and args.workload == "config3" and args.log_n == 20:
+            if pmc_files and args.workload == "config3" and args.log_n == 20:  # what was profiled
                 pk = json.load(open(pmc_files[-1]))["kernels"].get(dom)
                 if pk:
                     traffic = round((pk["fetch_bytes_per_proof_corrected"] + pk["write_bytes_per_proof"])
@@ -252,12 +286,14 @@ def main():
             "metric": "trace cells/sec (proofs/sec alongside), 2^20x64 BabyBear trace",
             "value": res["value"], "unit": "trace cells/sec", "n_gpus": env.world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
+            "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None,
+            "dtype": "u32",
             "data": "synthetic",
             "config": {"workload": desc, "rows": n, "width": w, "log_blowup": cfg[0],
                        "num_queries": cfg[1], "proof_of_work_bits": cfg[2], "quotient_degree": qd,
-                       "parallelism": ("1 rank per GPU (replicas)" if env.world > 1 else "1 GPU")
-                                      + f", {S} proofs in flight per GPU",
+                       "parallelism": (f"one proof sharded over {env.world} GPU(s), RCCL" if sharded else
+                                       ("1 rank per GPU (replicas)" if env.world > 1 else "1 GPU")
+                                       + f", {S} proofs in flight per GPU"),
                        "quotient_kernel": "hiprtc-specialised" if cair.is_jit else "interpreter",
                        "proof_words": int(len(proof.words))},
             "proofs_per_sec": res["steps_per_sec"],
@@ -265,6 +301,9 @@ def main():
             "stages_ms": stage_sum,
             "kernels": per_kernel,
         }
+    if sharded and env.dist is None:
+        import torch.distributed as dist
+        dist.destroy_process_group()
     env.close()
     if out is not None:
         print(json.dumps(out))

@@ -62,6 +62,15 @@ def lib() -> C.CDLL:
         if not os.path.exists(LIB_PATH):
             raise TsError(2, f"{LIB_PATH} is missing: run __graft_entry__.build() "
                              "(python -m tapstark_amd.build); there is no CPU fallback")
+        # PyTorch-ROCm wheels carry their own libamdhip64; a process that loaded the system copy
+        # first cannot initialise torch's afterwards ("No HIP GPUs are available").  Loading torch's
+        # first makes both sides share one runtime (same SONAME), which the sharded prover needs
+        # (tap-stark_amd/dist.py).  TS_PRELOAD_TORCH=0 skips it for torch-free hosts.
+        if os.environ.get("TS_PRELOAD_TORCH", "1") != "0":
+            try:
+                import torch  # noqa: F401
+            except Exception:
+                pass
         l = C.CDLL(LIB_PATH)
         l.ts_last_error.restype = C.c_char_p
         l.ts_last_error.argtypes = [C.c_void_p]

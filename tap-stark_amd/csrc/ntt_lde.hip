@@ -9,6 +9,8 @@
 //                    transform, writing coset block beta -- the coefficients never touch HBM
 //   k_lde_fwd_contig stages sA .. log_n-1 of the forward transform, in place on 4096-element chunks
 // For n <= 4096 k_lde_mid alone does everything.
+#include <stdlib.h>
+
 #include "kernels.hpp"
 
 namespace ts {
@@ -17,7 +19,7 @@ constexpr int LOG_M = 12;          // contiguous chunk = 4096 elements
 constexpr int CHUNK = 1 << LOG_M;
 constexpr int NT = 256;            // threads per workgroup, contiguous kernels
 constexpr int NT_MID = 512;        // threads per workgroup, middle kernel
-constexpr int TILE_ELEMS = 8192;   // strided tile
+constexpr int TILE_ELEMS = 8192;   // strided tile (generic plan)
 constexpr int SHIFT_LO_BITS = 10;  // coset scale s^k = hi[k >> 10] * lo[k & 1023]
 
 __device__ __forceinline__ uint32_t pad(uint32_t i) { return i + (i >> 4); }
@@ -200,38 +202,53 @@ k_lde_fwd_contig(uint32_t* __restrict__ out, uint64_t out_col_stride, unsigned l
 // the tile is the whole column).  Finishes the inverse transform (stages log_len-1 .. 0), then for
 // each coset: scaled copy -> forward stages 0 .. log_len-1 -> block beta of `out`.
 // PLAN 0: generic (runtime round plan).  PLAN 1: log_len = 8, log_T = 5 (n = 2^20): two radix-16
-// rounds with compile-time distances 2^9 and 2^5.
-template <int PLAN>
-__global__ void __launch_bounds__(NT_MID)
+// rounds with compile-time distances 2^9 and 2^5.  PLAN 2: log_len = 10 (n = 2^22), rounds of 4, 3
+// and 3 stages with compile-time distances; TILE elements per workgroup (log_T = log2(TILE) - 10).
+template <int PLAN, int TILE = TILE_ELEMS, int NTM = NT_MID>
+__global__ void __launch_bounds__(NTM)
 k_lde_mid(const uint32_t* __restrict__ evals, uint64_t in_col_stride, uint32_t* __restrict__ out,
           uint64_t out_col_stride, unsigned log_n, unsigned log_len, unsigned log_T,
           unsigned row_shift, unsigned beta0, unsigned n_cosets, const uint32_t* __restrict__ W,
           const uint32_t* __restrict__ Winv, const uint32_t* __restrict__ lo,
           const uint32_t* __restrict__ hi, uint32_t n_hi) {
-    __shared__ uint32_t s[padded(TILE_ELEMS)];
-    constexpr int PER_THREAD = TILE_ELEMS / NT_MID;
+    __shared__ uint32_t s[padded(TILE)];
+    constexpr int PER_THREAD = TILE / NTM;
+    constexpr int LOG_TILE = TILE == 8192 ? 13 : (TILE == 16384 ? 14 : 15);
     if (PLAN == 1) {
         log_len = 8;
         log_T = 5;
     }
-    const uint32_t j2_0 = blockIdx.x << log_T;
+    if (PLAN == 2) {
+        log_len = 10;
+        log_T = LOG_TILE - 10;
+    }
+    // Tiles narrower than 128 B (log_T < 5) share every cache line they touch with their neighbours:
+    // neighbouring tiles go to workgroups of the same XCD (ids 8 apart), whose L2 then merges the
+    // pieces of a line (measured on 2^22 x 64, log_blowup 4: 19.6 -> 15.7 ms at 32 B, 14.5 -> 13.8 at 64 B)
+    const bool remap = PLAN != 1 && log_T < 5 && gridDim.x >= 8;
+    const uint32_t bx = remap ? (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    const uint32_t j2_0 = bx << log_T;
     const uint32_t* g = evals + (uint64_t)blockIdx.y * in_col_stride + j2_0;
     const uint32_t total = 1u << (log_len + log_T);
     const uint32_t tmask = (1u << log_T) - 1;
-    for (uint32_t i = threadIdx.x; i < total; i += NT_MID)
+    for (uint32_t i = threadIdx.x; i < total; i += NTM)
         s[pad(i)] = g[((uint64_t)(i >> log_T) << row_shift) + (i & tmask)];
     __syncthreads();
     if (PLAN == 1) {
-        radix_round<4, true, 5, NT_MID>(s, 13, 4, 0, 0, Winv);
-        radix_round<4, true, 9, NT_MID>(s, 13, 0, 0, 0, Winv);
+        radix_round<4, true, 5, NTM>(s, 13, 4, 0, 0, Winv);
+        radix_round<4, true, 9, NTM>(s, 13, 0, 0, 0, Winv);
+    } else if (PLAN == 2) {
+        radix_round<3, true, LOG_TILE - 10, NTM>(s, LOG_TILE, 7, 0, 0, Winv);
+        radix_round<3, true, LOG_TILE - 7, NTM>(s, LOG_TILE, 4, 0, 0, Winv);
+        radix_round<4, true, LOG_TILE - 4, NTM>(s, LOG_TILE, 0, 0, 0, Winv);
     } else {
-        tile_inverse_rt<NT_MID>(s, log_len, log_T, 0, 0, Winv);
+        tile_inverse_rt<NTM>(s, log_len, log_T, 0, 0, Winv);
     }
     // natural-order coefficients (times n): keep this thread's share in registers
     uint32_t coef[PER_THREAD];
 #pragma unroll
     for (int k = 0; k < PER_THREAD; k++) {
-        const uint32_t i = threadIdx.x + (uint32_t)k * NT_MID;
+        const uint32_t i = threadIdx.x + (uint32_t)k * NTM;
         coef[k] = i < total ? s[pad(i)] : 0u;
     }
     // cosets beta0 .. beta0 + n_cosets - 1 go to blocks 0 .. n_cosets - 1 of `out` (a rank of a
@@ -243,7 +260,7 @@ k_lde_mid(const uint32_t* __restrict__ evals, uint64_t in_col_stride, uint32_t* 
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < PER_THREAD; k++) {
-            const uint32_t i = threadIdx.x + (uint32_t)k * NT_MID;
+            const uint32_t i = threadIdx.x + (uint32_t)k * NTM;
             if (i < total) {
                 // coefficient index of this slot
                 const uint32_t kk = ((i >> log_T) << row_shift) + (i & tmask) + j2_0;
@@ -253,13 +270,17 @@ k_lde_mid(const uint32_t* __restrict__ evals, uint64_t in_col_stride, uint32_t* 
         }
         __syncthreads();
         if (PLAN == 1) {
-            radix_round<4, false, 9, NT_MID>(s, 13, 0, 0, 0, W);
-            radix_round<4, false, 5, NT_MID>(s, 13, 4, 0, 0, W);
+            radix_round<4, false, 9, NTM>(s, 13, 0, 0, 0, W);
+            radix_round<4, false, 5, NTM>(s, 13, 4, 0, 0, W);
+        } else if (PLAN == 2) {
+            radix_round<4, false, LOG_TILE - 4, NTM>(s, LOG_TILE, 0, 0, 0, W);
+            radix_round<3, false, LOG_TILE - 7, NTM>(s, LOG_TILE, 4, 0, 0, W);
+            radix_round<3, false, LOG_TILE - 10, NTM>(s, LOG_TILE, 7, 0, 0, W);
         } else {
-            tile_forward_rt<NT_MID>(s, log_len, log_T, 0, 0, W);
+            tile_forward_rt<NTM>(s, log_len, log_T, 0, 0, W);
         }
         uint32_t* o = out + (uint64_t)blockIdx.y * out_col_stride + ((uint64_t)bl << log_n) + j2_0;
-        for (uint32_t i = threadIdx.x; i < total; i += NT_MID)
+        for (uint32_t i = threadIdx.x; i < total; i += NTM)
             o[((uint64_t)(i >> log_T) << row_shift) + (i & tmask)] = s[pad(i)];
     }
 }
@@ -280,8 +301,17 @@ void coset_lde(Context& ctx, uint32_t* evals, uint64_t in_col_stride, uint32_t n
     const uint64_t n = 1ull << log_n;
     const uint32_t n_inv_mont = to_mont(inv_canon((uint32_t)(n % P)));
     unsigned log_T = 0;
+    // TS_LDE_TILE (0 = generic plan / 8192 / 16384 / 32768) picks the PLAN 2 tile: a tuning knob.
+    // Measured on 2^22 x 64, log_blowup 4 (ms per launch): generic 19.1, 8192 15.7, 16384 13.8,
+    // 32768 30.3 (one workgroup per CU)
+    static const int plan2_tile = [] {
+        const char* e = getenv("TS_LDE_TILE");
+        return e ? atoi(e) : 16384;
+    }();
+    const bool plan2 = two_pass && sA == 10 && plan2_tile != 0;
     if (two_pass) {
         while ((1u << (sA + log_T + 1)) <= (unsigned)TILE_ELEMS && log_T < 6) log_T++;
+        if (plan2) log_T = plan2_tile == 8192 ? 3 : (plan2_tile == 16384 ? 4 : 5);
     }
 
     // per-coset scale tables s_beta^k / n
@@ -301,7 +331,16 @@ void coset_lde(Context& ctx, uint32_t* evals, uint64_t in_col_stride, uint32_t n
         TS_LAUNCH(ctx, k_intt_contig, dim3(1u << sA, ncols), dim3(NT), 0, evals, in_col_stride, log_n,
                   Winv);
         const dim3 grid(1u << (LOG_M - log_T), ncols);
-        if (sA == 8 && log_T == 5)
+#define TS_MID_ARGS                                                                            \
+    (const uint32_t*)evals, in_col_stride, out, out_col_stride, log_n, sA, log_T, (unsigned)LOG_M, \
+        beta0, n_beta, W, Winv, (const uint32_t*)lo.p, (const uint32_t*)hi.p, n_hi
+        if (plan2 && plan2_tile == 8192)
+            TS_LAUNCH(ctx, (k_lde_mid<2, 8192>), grid, dim3(NT_MID), 0, TS_MID_ARGS);
+        else if (plan2 && plan2_tile == 16384)
+            TS_LAUNCH(ctx, (k_lde_mid<2, 16384>), grid, dim3(NT_MID), 0, TS_MID_ARGS);
+        else if (plan2)
+            TS_LAUNCH(ctx, (k_lde_mid<2, 32768, 1024>), grid, dim3(1024), 0, TS_MID_ARGS);
+        else if (sA == 8 && log_T == 5)
             TS_LAUNCH(ctx, k_lde_mid<1>, grid, dim3(NT_MID), 0, (const uint32_t*)evals, in_col_stride,
                       out, out_col_stride, log_n, sA, log_T, (unsigned)LOG_M, beta0, n_beta, W, Winv,
                       (const uint32_t*)lo.p, (const uint32_t*)hi.p, n_hi);

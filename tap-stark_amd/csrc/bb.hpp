@@ -21,6 +21,7 @@ namespace ts {
 
 constexpr uint32_t P = 0x78000001u;
 constexpr uint32_t P_INV = 0x88000001u;      // p^-1 mod 2^32
+constexpr uint32_t P_NEG_INV = 0x77ffffffu;  // -p^-1 mod 2^32
 constexpr uint32_t R_MOD_P = 0x0ffffffeu;    // 2^32 mod p  (Montgomery form of 1)
 constexpr uint32_t R2_MOD_P = 0x45dddde3u;   // 2^64 mod p  (checked by tests/test_host_field)
 constexpr uint32_t GENERATOR = 31u;
@@ -53,11 +54,14 @@ TS_HD uint32_t mulhi32(uint32_t a, uint32_t b) {
 // v_mul_hi_u32, v_mad_u64_u32, v_lshl_add_u32, v_alignbit_b32 -- costs ~2.5 issue slots against 1
 // for a VOP2 add/sub/min, so one v_mul_lo_u32 beats the two shift-adds that p^-1 = 2^31+2^27+1
 // would allow.)
+// Additive form: m = -t p^-1 mod 2^32 makes t + m p divisible by 2^32; the quotient is < 2p, so one
+// sub + min finishes.  On the device that is v_mul_lo_u32, v_mad_u64_u32 (product and 64-bit add in
+// one instruction), v_sub, v_min: one VOP2 op fewer than the subtractive form (mul_lo, mul_hi, sub,
+// add, min).  t + m p < p 2^32 + 2^32 p < 2^64.
 TS_HD uint32_t mont_reduce(uint64_t t) {
-    uint32_t m = (uint32_t)t * P_INV;
-    uint32_t u = mulhi32(m, P);
-    uint32_t r = (uint32_t)(t >> 32) - u;
-    return umin32(r, r + P);
+    uint32_t m = (uint32_t)t * P_NEG_INV;
+    uint32_t r = (uint32_t)((t + (uint64_t)m * P) >> 32);
+    return umin32(r, r - P);
 }
 // a * b * 2^-32 mod p.  Needs a*b < p*2^32 (true if either operand is < p).
 TS_HD uint32_t mont_mul(uint32_t a, uint32_t b) { return mont_reduce((uint64_t)a * b); }

@@ -295,7 +295,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": desc, "rows": n, "width": w, "log_blowup": cfg[0],
                        "num_queries": cfg[1], "proof_of_work_bits": cfg[2], "quotient_degree": qd,
-                       "parallelism": (f"one proof sharded over {env.world} GPU(s), RCCL" if sharded else
+                       "parallelism": (f"one proof sharded over {env.world} GPU(s), collectives over {comm.backend}" if sharded else
                                        ("1 rank per GPU (replicas)" if env.world > 1 else "1 GPU")
                                        + f", {S} proofs in flight per GPU"),
                        "quotient_kernel": "hiprtc-specialised" if cair.is_jit else "interpreter",

@@ -269,7 +269,9 @@ def main():
             import glob
             pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
             if pmc_files and args.workload == "config3" and args.log_n == 20:  # what was profiled
-                pk = json.load(open(pmc_files[-1]))["kernels"].get(dom)
+                ks = json.load(open(pmc_files[-1]))["kernels"]
+                stem = dom.strip("()").rstrip(">")  # "k_lde_mid<1" matches "k_lde_mid<1, 8192, 512>"
+                pk = ks.get(dom) or next((v for k, v in ks.items() if k.startswith(stem)), None)
                 if pk:
                     traffic = round((pk["fetch_bytes_per_proof_corrected"] + pk["write_bytes_per_proof"])
                                     / pk["launches_per_proof"])

@@ -1,0 +1,57 @@
+"""profiles/*_pmc_traffic.json from two rocprofv3 --pmc runs (FETCH_SIZE, WRITE_SIZE; separate
+passes) of tools/prof_prove.py.
+
+    pmc_summary.py FETCH_counter_collection.csv WRITE_counter_collection.csv N_PROOFS OUT.json
+
+Units and corrections follow /opt/skills/guides/MI355X_MICROARCH.md (HBM / rocprofv3 section): both
+counters are in KiB; on gfx950 FETCH_SIZE reports half of the bytes of wide coalesced streaming reads,
+so it is doubled before comparing with a byte count.
+"""
+import csv
+import json
+import re
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    name = re.sub(r"^void ", "", name)
+    name = re.sub(r"\(.*$", "", name)  # drop the argument list
+    return name.replace("ts::", "")
+
+
+def load(path, counter):
+    tot, cnt = defaultdict(float), defaultdict(int)
+    for row in csv.DictReader(open(path)):
+        if row["Counter_Name"] != counter:
+            continue
+        k = short(row["Kernel_Name"])
+        tot[k] += float(row["Counter_Value"])
+        cnt[k] += 1
+    return tot, cnt
+
+
+def main():
+    f_csv, w_csv, n_proofs, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+    fetch, cnt = load(f_csv, "FETCH_SIZE")
+    write, _ = load(w_csv, "WRITE_SIZE")
+    sys.path.insert(0, ".")
+    from bench import algorithmic_bytes_per_proof
+    alg = algorithmic_bytes_per_proof(1 << 20, 64, 2, 2)
+    kernels = {}
+    for k in sorted(fetch, key=lambda k: -(fetch[k] + write.get(k, 0))):
+        a = alg.get(k) or alg.get(f"({k})") or (alg["k_lde_mid<1>"] if "k_lde_mid" in k else None)
+        kernels[k] = {"launches_per_proof": cnt[k] / n_proofs,
+                      "fetch_bytes_per_proof_corrected": 2 * 1024 * fetch[k] / n_proofs,
+                      "write_bytes_per_proof": 1024 * write.get(k, 0.0) / n_proofs,
+                      "alg_bytes_per_proof": a}
+    json.dump({"_comment": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) on "
+                           f"tools/prof_prove.py, {n_proofs} proofs of C3; KiB units x1024; FETCH_SIZE "
+                           "doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of wide coalesced "
+                           "reads); per proof", "kernels": kernels}, open(out, "w"), indent=1)
+    for k, v in kernels.items():
+        t = v["fetch_bytes_per_proof_corrected"] + v["write_bytes_per_proof"]
+        print(f"{k:40s} traffic {t/1e6:9.1f} MB  alg {(v['alg_bytes_per_proof'] or 0)/1e6:9.1f} MB")
+
+
+main()

@@ -227,6 +227,18 @@ ts_status ts_verify(const ts_fri_config* cfg, const ts_air* air, ts_challenger* 
                     const uint32_t* proof, size_t n_words, const uint32_t* public_values,
                     uint32_t n_public, int* verdict);
 
+/* ------------------------------------------------------------------ proof wire format (host only) */
+/* TSPF v1 words <-> the postcard encoding of the reference's serde proof types
+ * (uni-stark/src/proof.rs:17-38, fri/src/proof.rs:8-33, fri/src/two_adic_pcs.rs:63-68; postcard is
+ * the carrier the reference names: uni-stark/Cargo.toml:44, uni-stark/tests/mul_air.rs:133-137).
+ * Field order and element encodings are the reference's; the commitment (one 32-byte root) and the
+ * MMCS opening proof (sibling path) are this build's Merkle types.
+ * TS_ERR_INVALID for a malformed input, TS_ERR_BUFFER if the output does not fit (size still set). */
+ts_status ts_proof_to_postcard(const uint32_t* proof, size_t n_words, uint8_t* out, size_t cap_bytes,
+                               size_t* n_bytes_out);
+ts_status ts_proof_from_postcard(const uint8_t* bytes, size_t n_bytes, uint32_t* proof_out,
+                                 size_t cap_words, size_t* n_words_out);
+
 /* library/ABI version (bumped on any incompatible change) */
 uint32_t ts_abi_version(void);
 

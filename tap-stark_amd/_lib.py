@@ -25,6 +25,7 @@ ABI_SYMBOLS = [
     "ts_quotient_chunks", "ts_pcs_open_reduce", "ts_pcs_open", "ts_fri_fold", "ts_chal_new", "ts_chal_clone",
     "ts_chal_free", "ts_chal_observe", "ts_chal_observe_commitment", "ts_chal_sample",
     "ts_chal_sample_bits", "ts_chal_check_witness", "ts_chal_grind", "ts_chal_state", "ts_prove", "ts_prove_sharded", "ts_verify", "ts_check_constraints",
+    "ts_proof_to_postcard", "ts_proof_from_postcard",
 ]
 
 STATUS = {0: "TS_OK", 1: "TS_ERR_INVALID", 2: "TS_ERR_HIP", 3: "TS_ERR_OOM",
@@ -129,6 +130,9 @@ def lib() -> C.CDLL:
         l.ts_prove_sharded.argtypes = [C.c_void_p, C.POINTER(FriConfigC), C.POINTER(CommC), C.c_void_p,
                                        C.c_void_p, C.c_void_p, u32p, C.c_uint32, C.c_uint32, u32p,
                                        C.c_size_t, C.POINTER(C.c_size_t)]
+        u8p = C.POINTER(C.c_uint8)
+        l.ts_proof_to_postcard.argtypes = [u32p, C.c_size_t, u8p, C.c_size_t, C.POINTER(C.c_size_t)]
+        l.ts_proof_from_postcard.argtypes = [u8p, C.c_size_t, u32p, C.c_size_t, C.POINTER(C.c_size_t)]
         l.ts_check_constraints.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, u32p, C.c_uint32,
                                            C.POINTER(C.c_int64)]
         l.ts_verify.argtypes = [C.POINTER(FriConfigC), C.c_void_p, C.c_void_p, u32p, C.c_size_t, u32p,

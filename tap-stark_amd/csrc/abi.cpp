@@ -85,6 +85,31 @@ ts::FriConfig load_cfg(const ts_fri_config* cfg) {
 
 extern "C" {
 
+ts_status ts_proof_to_postcard(const uint32_t* proof, size_t n_words, uint8_t* out, size_t cap_bytes,
+                               size_t* n_bytes_out) {
+    if (!proof || !out || !n_bytes_out) return TS_ERR_INVALID;
+    *n_bytes_out = 0;
+    return guard(nullptr, [&] {
+        std::vector<uint8_t> b;
+        TS_REQUIRE(ts::tspf_to_postcard(proof, n_words, b), ts::TS_ERR_INVALID, "not a TSPF v1 proof");
+        *n_bytes_out = b.size();
+        TS_REQUIRE(b.size() <= cap_bytes, ts::TS_ERR_BUFFER, "postcard buffer too small");
+        memcpy(out, b.data(), b.size());
+    });
+}
+ts_status ts_proof_from_postcard(const uint8_t* bytes, size_t n_bytes, uint32_t* proof_out,
+                                 size_t cap_words, size_t* n_words_out) {
+    if (!bytes || !proof_out || !n_words_out) return TS_ERR_INVALID;
+    *n_words_out = 0;
+    return guard(nullptr, [&] {
+        std::vector<uint32_t> w;
+        TS_REQUIRE(ts::postcard_to_tspf(bytes, n_bytes, w), ts::TS_ERR_INVALID, "malformed postcard proof");
+        *n_words_out = w.size();
+        TS_REQUIRE(w.size() <= cap_words, ts::TS_ERR_BUFFER, "proof buffer too small");
+        memcpy(proof_out, w.data(), w.size() * 4);
+    });
+}
+
 uint32_t ts_abi_version(void) { return 1; }
 
 ts_status ts_ctx_create(int device, ts_ctx** out) {

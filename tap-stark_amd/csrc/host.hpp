@@ -173,4 +173,8 @@ std::vector<uint32_t> prove_sharded(TwoAdicFriPcs& pcs, const Comm& comm, const 
 int verify(const FriConfig& fri, const AirProgram& air, BfChallenger& challenger,
            const uint32_t* proof, size_t n_words, const std::vector<uint32_t>& public_values);
 
+// ------------------------------------------------------------------ wire format (wire.cpp)
+bool tspf_to_postcard(const uint32_t* words, size_t n_words, std::vector<uint8_t>& out);
+bool postcard_to_tspf(const uint8_t* bytes, size_t n_bytes, std::vector<uint32_t>& out);
+
 }  // namespace ts

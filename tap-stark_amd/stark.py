@@ -419,6 +419,30 @@ class Proof:
     final_poly: np.ndarray = None
     pow_witness: int = 0
 
+    def to_postcard(self) -> bytes:
+        """postcard bytes of the reference's serde ``Proof`` (``ts_proof_to_postcard``)."""
+        l = _lib.lib()
+        w = _u32(self.words)
+        out = np.zeros(5 * len(w) + 16, dtype=np.uint8)  # a varint takes at most 5 bytes per word
+        n = C.c_size_t()
+        rc = l.ts_proof_to_postcard(_p(w), len(w), out.ctypes.data_as(C.POINTER(C.c_uint8)), len(out),
+                                    C.byref(n))
+        if rc:
+            raise _lib.TsError(rc, "ts_proof_to_postcard")
+        return out[: n.value].tobytes()
+
+    @classmethod
+    def from_postcard(cls, data: bytes) -> "Proof":
+        l = _lib.lib()
+        b = np.frombuffer(data, dtype=np.uint8).copy()
+        out = np.zeros(len(b) + 16, dtype=np.uint32)  # every word takes at least one byte
+        n = C.c_size_t()
+        rc = l.ts_proof_from_postcard(b.ctypes.data_as(C.POINTER(C.c_uint8)), len(b), _p(out), len(out),
+                                      C.byref(n))
+        if rc:
+            raise _lib.TsError(rc, "ts_proof_from_postcard")
+        return cls.parse(out[: n.value].copy())
+
     @classmethod
     def parse(cls, words: np.ndarray) -> "Proof":
         w = np.asarray(words, dtype=np.uint32)

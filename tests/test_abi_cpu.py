@@ -151,3 +151,96 @@ def test_host_only_air_reports_degrees(lib, orc):
         assert cair.log_quotient_degree == orc.log_quotient_degree(tape) == ts.get_log_quotient_degree(air, npub)
         assert cair.max_constraint_degree == orc.max_constraint_degree(tape)
         assert not cair.is_jit
+
+
+# ------------------------------------------------------------------ proof wire format (postcard)
+def _postcard_reference_encoder(proof: "ts.Proof") -> bytes:
+    """postcard 1.0 by the book, written against the reference's struct definitions
+    (uni-stark/src/proof.rs:19-38, fri/src/proof.rs:13-33, fri/src/two_adic_pcs.rs:63-68) from the
+    PARSED proof -- independent of the C++ encoder, which walks the TSPF words."""
+    out = bytearray()
+
+    def varint(v):
+        v = int(v)
+        while v >= 0x80:
+            out.append((v & 0x7F) | 0x80)
+            v >>= 7
+        out.append(v)
+
+    def felts(a):
+        for v in np.asarray(a).reshape(-1):
+            varint(v)
+
+    def digest(d):
+        out.extend(np.asarray(d, dtype="<u4").tobytes())
+
+    def commitment(d):  # Vec<[[u8; 4]; 8]> holding one root
+        varint(1)
+        digest(d)
+
+    def path(p):  # Vec<[u8; 32]>
+        varint(len(p))
+        for d in p:
+            digest(d)
+
+    # Proof.commitments
+    commitment(proof.trace_commit)
+    commitment(proof.quotient_commit)
+    # Proof.opened_values
+    varint(len(proof.trace_local)); felts(proof.trace_local)
+    varint(len(proof.trace_next)); felts(proof.trace_next)
+    varint(len(proof.quotient_chunks))
+    for ch in proof.quotient_chunks:
+        varint(len(ch)); felts(ch)
+    # Proof.opening_proof: FriProof
+    varint(len(proof.commit_phase_commits))
+    for c in proof.commit_phase_commits:
+        commitment(c)
+    varint(len(proof.query_proofs))
+    for qp in proof.query_proofs:
+        varint(len(qp.input_proof))
+        for batch in qp.input_proof:
+            varint(len(batch.opened_values))
+            for row in batch.opened_values:
+                varint(len(row)); felts(row)
+            path(batch.opening_proof)
+        varint(len(qp.commit_phase_openings))
+        for vals, pth in qp.commit_phase_openings:
+            varint(1); varint(2); felts(vals)
+            path(pth)
+    felts(proof.final_poly)
+    varint(proof.pow_witness)
+    # Proof.degree_bits
+    varint(proof.degree_bits)
+    return bytes(out)
+
+
+def test_postcard_wire_format_round_trip(lib, orc):
+    for name, air, trace, pis, cfg in _cases():
+        tape = ts.air_tape(air, len(pis))
+        words = orc.prove(orc.FriConfig(*cfg), tape, trace, pis)
+        proof = ts.Proof.parse(words)
+        data = proof.to_postcard()
+        assert data == _postcard_reference_encoder(proof), name
+        back = ts.Proof.from_postcard(data)
+        assert (back.words == words).all(), name
+        # still a valid proof after the round trip
+        config = ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(*cfg), host_only=True))
+        ts.verify(config, air, ts.BfChallenger(), back, pis)
+        assert len(data) <= 5 * len(words)  # a 31-bit element takes up to 5 varint bytes
+        # malformed inputs are refused, not mis-parsed
+        for bad in (data[:-1], data + b"\x00", data[:40], b""):
+            with pytest.raises(_lib.TsError):
+                ts.Proof.from_postcard(bad)
+        nc = bytearray(data)
+        # first opened value -> a non-canonical element (>= p): 5-byte varint of 0xffffffff
+        off = 2 * 33 + 1
+        v = 0
+        end = off
+        while nc[end] & 0x80:
+            end += 1
+        nc[off:end + 1] = b"\xff\xff\xff\xff\x0f"
+        with pytest.raises(_lib.TsError):
+            ts.Proof.from_postcard(bytes(nc))
+    with pytest.raises(_lib.TsError):
+        ts.Proof(words=words[:10]).to_postcard()

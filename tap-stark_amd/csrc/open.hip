@@ -230,18 +230,50 @@ __device__ __forceinline__ Ef row_dot_alpha(const uint32_t* __restrict__ m, uint
                                             uint32_t width, uint64_t X,
                                             const uint32_t* __restrict__ alpha_pows) {
     uint64_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-    for (uint32_t i = 0; i < width; i++) {
-        const uint32_t v = m[(uint64_t)i * col_stride + X];
-        const uint32_t* ap = alpha_pows + 4 * i;
-        a0 = lazy_mac(a0, v, ap[0]);
-        a1 = lazy_mac(a1, v, ap[1]);
-        a2 = lazy_mac(a2, v, ap[2]);
-        a3 = lazy_mac(a3, v, ap[3]);
-        if (i & 1) {
-            a0 = lazy_fix(a0);
-            a1 = lazy_fix(a1);
-            a2 = lazy_fix(a2);
-            a3 = lazy_fix(a3);
+    // batches of 8 columns: the 8 loads are issued back to back (one load per iteration with a
+    // wait behind it left the kernel latency-bound), then 32 MACs with a range fix every 2 columns
+    constexpr int B = 8;
+    const uint32_t* col = m + X;
+    uint32_t i = 0;
+    for (; i + B <= width; i += B) {
+        uint32_t v[B];
+#pragma unroll
+        for (int k = 0; k < B; k++) v[k] = col[(uint64_t)(i + k) * col_stride];
+#pragma unroll
+        for (int k = 0; k < B; k++) {
+            const uint32_t* ap = alpha_pows + 4 * (i + k);
+            a0 = lazy_mac(a0, v[k], ap[0]);
+            a1 = lazy_mac(a1, v[k], ap[1]);
+            a2 = lazy_mac(a2, v[k], ap[2]);
+            a3 = lazy_mac(a3, v[k], ap[3]);
+            if (k & 1) {
+                a0 = lazy_fix(a0);
+                a1 = lazy_fix(a1);
+                a2 = lazy_fix(a2);
+                a3 = lazy_fix(a3);
+            }
+        }
+    }
+    // tail (< 8 columns): same pattern, predicated loads
+    if (i < width) {
+        uint32_t v[B];
+#pragma unroll
+        for (int k = 0; k < B; k++) v[k] = i + k < width ? col[(uint64_t)(i + k) * col_stride] : 0u;
+#pragma unroll
+        for (int k = 0; k < B; k++) {
+            if (i + k < width) {
+                const uint32_t* ap = alpha_pows + 4 * (i + k);
+                a0 = lazy_mac(a0, v[k], ap[0]);
+                a1 = lazy_mac(a1, v[k], ap[1]);
+                a2 = lazy_mac(a2, v[k], ap[2]);
+                a3 = lazy_mac(a3, v[k], ap[3]);
+            }
+            if (k & 1) {
+                a0 = lazy_fix(a0);
+                a1 = lazy_fix(a1);
+                a2 = lazy_fix(a2);
+                a3 = lazy_fix(a3);
+            }
         }
     }
     return Ef{{lazy_finish(a0), lazy_finish(a1), lazy_finish(a2), lazy_finish(a3)}};

@@ -36,29 +36,33 @@ import numpy as np  # noqa: E402
 HBM_PEAK = 8.0e12  # B/s, /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
 
 
-def workload(name: str, log_n: int):
-    from tapstark_amd.airs import (FibonacciAir, SynthMulAir, fibonacci_public_values,
-                                   generate_fibonacci_trace, generate_synth_mul_trace)
+def workload(name: str, log_n: int, need_host_trace: bool):
+    """(air, host trace or None, public values, description, fri config, device-side generator).
+    The traces are generated ON THE DEVICE (ts_trace_*): inputs are born in HBM; a host copy is only
+    made when a mode needs to slice it."""
+    import tapstark_amd as ts
+    from tapstark_amd.airs import (FibonacciAir, SynthMulAir, generate_fibonacci_trace,
+                                   generate_synth_mul_trace)
     n = 1 << log_n
-    if name == "config3":
+    if name in ("config3", "config4"):
         air = SynthMulAir(64)
-        trace = generate_synth_mul_trace(n)
+        trace = generate_synth_mul_trace(n) if need_host_trace else None
         pis = np.zeros(0, dtype=np.uint32)
-        desc = f"SynthMulAir-64 (build-defined), trace 2^{log_n}x64, log_blowup=2, 28 queries, pow 8"
-    elif name == "config2":
+        cfg = (2, 28, 8) if name == "config3" else (4, 16, 8)
+        desc = (f"SynthMulAir-64 (build-defined), trace 2^{log_n}x64, log_blowup={cfg[0]}, "
+                f"{cfg[1]} queries, pow 8")
+        return air, trace, pis, desc, cfg, (n, 64), lambda c: ts.DeviceMatrix.synth_mul(c, n, 64)
+    if name == "config2":
         air = FibonacciAir()
-        trace = generate_fibonacci_trace(0, 1, n)
-        pis = fibonacci_public_values(trace)
+        trace = generate_fibonacci_trace(0, 1, n) if need_host_trace else None
+
+        def last_right(c):  # pis = [a, b, trace[n-1].right]  (fib_air.rs:133-139)
+            return int(ts.DeviceMatrix.fibonacci(c, 0, 1, n).download()[-1, 1])
+
         desc = f"Fibonacci AIR, trace 2^{log_n}x2, log_blowup=2, 28 queries, pow 8"
-    elif name == "config4":
-        air = SynthMulAir(64)
-        trace = generate_synth_mul_trace(n)
-        pis = np.zeros(0, dtype=np.uint32)
-        desc = f"SynthMulAir-64 (build-defined), trace 2^{log_n}x64, log_blowup=4, 16 queries, pow 8"
-        return air, trace, pis, desc, (4, 16, 8)
-    else:
-        raise SystemExit(f"unknown workload {name}")
-    return air, trace, pis, desc, (2, 28, 8)
+        return (air, trace, last_right, desc, (2, 28, 8), (n, 2),
+                lambda c: ts.DeviceMatrix.fibonacci(c, 0, 1, n))
+    raise SystemExit(f"unknown workload {name}")
 
 
 def algorithmic_bytes_per_proof(n: int, w: int, b: int, qd: int) -> dict:
@@ -127,7 +131,7 @@ def cpu_baseline(target_seconds: float = 15.0) -> dict:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="config3", choices=["config3", "config2", "config4"])
     ap.add_argument("--log-n", type=int, default=None, help="default 20 (22 for config4)")
@@ -157,8 +161,9 @@ def main():
     dev = 0 if os.environ.get("TS_BENCH_SHARE_GPU") else env.local_rank
     ctx = ts.Context(dev)  # raises without a GPU: there is no fallback path
 
-    air, trace, pis, desc, cfg = workload(args.workload, args.log_n)
-    n, w = trace.shape
+    air, trace, pis, desc, cfg, (n, w), make_trace = workload(args.workload, args.log_n, sharded)
+    if callable(pis):
+        pis = np.array([0, 1, pis(ctx)], dtype=np.uint32)
     config = ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(*cfg), ctx))
     cair = ts.CompiledAir(ctx, ts.air_tape(air, len(pis)))
     qd = 1 << cair.log_quotient_degree
@@ -166,7 +171,11 @@ def main():
     # Proofs are independent, so S of them are kept in flight per GPU: S contexts (one HIP stream,
     # one device pool and one host thread each).  The serial transcript of one proof leaves the
     # GPU idle at its host round trips; the next proof's kernels fill those gaps.
+    # The K timed steps are dealt to the lanes in advance, so K should be a multiple of S: if the
+    # requested lane count does not divide K, a neighbouring one that does is used (K = 10 -> 5 lanes).
     S = 1 if sharded else max(1, min(args.streams, args.steps))
+    if S > 1 and args.steps % S:
+        S = next((c for c in (S + 1, S - 1, S + 2, S - 2) if c >= 2 and args.steps % c == 0), S)
     lanes = [(ctx, config, cair)]
     for _ in range(1, S):
         c2 = ts.Context(dev)
@@ -194,7 +203,7 @@ def main():
         def prove_one(i):
             last["proof"] = ts.prove_sharded(config, cair, ts.BfChallenger(), mats[i], pis, comm)
     else:
-        mats = [ts.DeviceMatrix.upload(lanes[i % S][0], trace) for i in range(total)]
+        mats = [make_trace(lanes[i % S][0]) for i in range(total)]
 
         def prove_one(i):
             c, conf, ca = lanes[i % S]
@@ -232,14 +241,14 @@ def main():
     if env.rank == 0:
         # ---- roofline leg: per-kernel HIP-event timings over 3 extra (untimed) proofs
         reps = 3
-        extra = [ts.DeviceMatrix.upload(ctx, trace) for _ in range(reps)]
+        extra = [make_trace(ctx) for _ in range(reps)]
         ctx.set_kernel_timing(True)
         for m in extra:
             ts.prove(config, cair, ts.BfChallenger(), m, pis)
         kt = ctx.take_kernel_timings()
         ctx.set_kernel_timing(False)
         ctx.set_timing(True)
-        ts.prove(config, cair, ts.BfChallenger(), ts.DeviceMatrix.upload(ctx, trace), pis)
+        ts.prove(config, cair, ts.BfChallenger(), make_trace(ctx), pis)
         stages = ctx.take_timings()
         ctx.set_timing(False)
         stage_sum = {}
@@ -293,8 +302,8 @@ def main():
             "value": res["value"], "unit": "trace cells/sec", "n_gpus": env.world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
             "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None,
-            "dtype": "u32",
-            "data": "synthetic",
+            "dtype": "u32",  # BabyBear arithmetic on u32 lanes (64-bit intermediates)
+            "data": "synthetic (trace generated on the device, resident in HBM before the timed region)",
             "config": {"workload": desc, "rows": n, "width": w, "log_blowup": cfg[0],
                        "num_queries": cfg[1], "proof_of_work_bits": cfg[2], "quotient_degree": qd,
                        "parallelism": (f"one proof sharded over {env.world} GPU(s), collectives over {comm.backend}" if sharded else

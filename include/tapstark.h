@@ -75,6 +75,12 @@ ts_status ts_matrix_upload(ts_ctx* ctx, const uint32_t* host_row_major, uint64_t
 /* same from a device pointer (e.g. a torch tensor's data_ptr); the data is copied */
 ts_status ts_matrix_from_device(ts_ctx* ctx, const uint32_t* dev_row_major, uint64_t height,
                                 uint32_t width, ts_matrix** out);
+/* Traces generated on the device (no H2D).  ts_trace_fibonacci = generate_trace_rows(a, b, n) of
+ * uni-stark/tests/fib_air.rs:59-78 (n x 2: row 0 = (a, b), then (l, r) -> (r, l + r));
+ * ts_trace_synth_mul = the build-defined SynthMulAir-`width` trace of BASELINE configs 3/4
+ * (SplitMix64 stream `seed`, tap-stark_amd/airs.py generate_synth_mul_trace). */
+ts_status ts_trace_fibonacci(ts_ctx* ctx, uint32_t a, uint32_t b, uint64_t n, ts_matrix** out);
+ts_status ts_trace_synth_mul(ts_ctx* ctx, uint64_t n, uint32_t width, uint64_t seed, ts_matrix** out);
 ts_status ts_matrix_dims(const ts_matrix* m, uint64_t* height, uint32_t* width);
 /* row-major, natural row order */
 ts_status ts_matrix_download(ts_ctx* ctx, const ts_matrix* m, uint32_t* host_row_major);

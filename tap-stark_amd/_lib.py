@@ -19,7 +19,7 @@ ABI_SYMBOLS = [
     "ts_abi_version", "ts_ctx_create", "ts_ctx_destroy", "ts_last_error", "ts_ctx_synchronize",
     "ts_ctx_stream", "ts_ctx_set_timing", "ts_ctx_take_timings", "ts_ctx_set_kernel_timing",
     "ts_ctx_take_kernel_timings", "ts_matrix_upload",
-    "ts_matrix_from_device", "ts_matrix_dims", "ts_matrix_download", "ts_matrix_free",
+    "ts_matrix_from_device", "ts_trace_fibonacci", "ts_trace_synth_mul", "ts_matrix_dims", "ts_matrix_download", "ts_matrix_free",
     "ts_air_compile", "ts_air_info", "ts_air_is_jit", "ts_air_free", "ts_pcs_commit", "ts_pcs_data_lde",
     "ts_pcs_data_info", "ts_pcs_data_matrix_info", "ts_pcs_data_digests", "ts_pcs_open_batch", "ts_pcs_data_free",
     "ts_quotient_chunks", "ts_pcs_open_reduce", "ts_pcs_open", "ts_fri_fold", "ts_chal_new", "ts_chal_clone",
@@ -105,6 +105,8 @@ def lib() -> C.CDLL:
         l.ts_ctx_take_kernel_timings.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
         l.ts_matrix_upload.argtypes = [C.c_void_p, u32p, C.c_uint64, C.c_uint32, voidpp]
         l.ts_matrix_from_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, voidpp]
+        l.ts_trace_fibonacci.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, voidpp]
+        l.ts_trace_synth_mul.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, voidpp]
         l.ts_matrix_dims.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), u32p]
         l.ts_matrix_download.argtypes = [C.c_void_p, C.c_void_p, u32p]
         l.ts_air_compile.argtypes = [C.c_void_p, u32p, C.c_size_t, voidpp]

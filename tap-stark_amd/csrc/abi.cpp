@@ -195,6 +195,29 @@ ts_status ts_matrix_from_device(ts_ctx* ctx, const uint32_t* dev, uint64_t heigh
                                 ts_matrix** out) {
     return matrix_from(ctx, dev, height, width, hipMemcpyDeviceToDevice, out);
 }
+static ts_status generated_matrix(ts_ctx* ctx, uint64_t height, uint32_t width, ts_matrix** out,
+                                  const std::function<void(uint32_t*)>& fill) {
+    if (!ctx || !out || height == 0 || width == 0) return TS_ERR_INVALID;
+    *out = nullptr;
+    return guard(ctx, [&] {
+        TS_REQUIRE((height & (height - 1)) == 0, ts::TS_ERR_INVALID, "trace height must be a power of two");
+        auto m = std::make_unique<ts_matrix>();
+        m->m.buf = ts::DevBuf<uint32_t>(&ctx->ctx, (size_t)height * width);
+        m->m.height = height;
+        m->m.width = width;
+        m->m.layout = ts::DeviceMatrix::ROW_MAJOR;
+        fill(m->m.buf.p);
+        *out = m.release();
+    });
+}
+ts_status ts_trace_fibonacci(ts_ctx* ctx, uint32_t a, uint32_t b, uint64_t n, ts_matrix** out) {
+    return generated_matrix(ctx, n, 2, out,
+                            [&](uint32_t* p) { ts::launch_trace_fibonacci(ctx->ctx, p, a, b, n); });
+}
+ts_status ts_trace_synth_mul(ts_ctx* ctx, uint64_t n, uint32_t width, uint64_t seed, ts_matrix** out) {
+    return generated_matrix(ctx, n, width, out,
+                            [&](uint32_t* p) { ts::launch_trace_synth_mul(ctx->ctx, p, n, width, seed); });
+}
 ts_status ts_matrix_dims(const ts_matrix* m, uint64_t* height, uint32_t* width) {
     if (!m) return TS_ERR_INVALID;
     if (height) *height = m->m.height;

@@ -182,4 +182,10 @@ void launch_gather_fri(Context& ctx, const FriGatherDesc* d_descs, uint32_t n_ro
                        uint32_t max_log_leaves, const uint32_t* d_indices, uint32_t n_idx,
                        uint32_t* out);
 
+// ---- tracegen.hip ----------------------------------------------------------------------------
+// row-major traces generated in place (no H2D): Fibonacci (uni-stark/tests/fib_air.rs:59-78) and the
+// build-defined SynthMulAir-w trace (airs.py generate_synth_mul_trace)
+void launch_trace_fibonacci(Context& ctx, uint32_t* out, uint32_t a, uint32_t b, uint64_t n);
+void launch_trace_synth_mul(Context& ctx, uint32_t* out, uint64_t n, uint32_t width, uint64_t seed);
+
 }  // namespace ts

@@ -128,6 +128,22 @@ class DeviceMatrix:
         ctx.check(ctx._l.ts_matrix_from_device(ctx.h, C.c_void_p(ptr), height, width, C.byref(h)))
         return cls(ctx, h)
 
+    @classmethod
+    def fibonacci(cls, ctx: Context, a: int, b: int, n: int) -> "DeviceMatrix":
+        """``generate_trace_rows(a, b, n)`` (uni-stark/tests/fib_air.rs:59-78) computed in HBM."""
+        h = C.c_void_p()
+        ctx.check(ctx._l.ts_trace_fibonacci(ctx.h, a, b, n, C.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def synth_mul(cls, ctx: Context, n: int, width: int = 64, seed: int | None = None) -> "DeviceMatrix":
+        """The SynthMulAir-``width`` trace of ``airs.generate_synth_mul_trace``, computed in HBM."""
+        from .airs import SPLITMIX_SEED
+        h = C.c_void_p()
+        ctx.check(ctx._l.ts_trace_synth_mul(ctx.h, n, width, SPLITMIX_SEED if seed is None else seed,
+                                            C.byref(h)))
+        return cls(ctx, h)
+
     def dims(self):
         hh, ww = C.c_uint64(), C.c_uint32()
         self.ctx.check(self.ctx._l.ts_matrix_dims(self.h, C.byref(hh), C.byref(ww)))

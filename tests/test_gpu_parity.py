@@ -405,3 +405,43 @@ def test_pcs_open_two_points_matches_prove_shape(ctx, orc):
     want, _ = pcs.open_reduce(td, qd, w, zeta, alpha)
     flat = np.concatenate([p for r in opened for m in r for p in m])
     assert (flat == want).all()
+
+
+# ------------------------------------------------------------------ trace generation on the device
+@pytest.mark.parametrize("a,b,log_n", [(0, 1, 0), (0, 1, 3), (3, 5, 7), (P - 1, P - 2, 12), (0, 1, 20)])
+def test_trace_fibonacci_on_device(ctx, a, b, log_n):
+    # generate_trace_rows (uni-stark/tests/fib_air.rs:59-78), row by row on the host vs in HBM
+    n = 1 << log_n
+    got = ts.DeviceMatrix.fibonacci(ctx, a, b, n).download()
+    want = generate_fibonacci_trace(a, b, n)
+    assert got.shape == want.shape and (got == want).all()
+    if log_n == 3 and (a, b) == (0, 1):
+        assert got[-1, 1] == 21  # fib_air.rs:143
+
+
+@pytest.mark.parametrize("log_n,w", [(0, 3), (5, 7), (10, 64), (14, 64), (9, 2)])
+def test_trace_synth_mul_on_device(ctx, log_n, w):
+    n = 1 << log_n
+    got = ts.DeviceMatrix.synth_mul(ctx, n, w).download()
+    want = generate_synth_mul_trace(n, w)
+    assert (got == want).all()
+
+
+def test_prove_from_device_generated_trace(ctx, orc):
+    # the whole path without an H2D of the trace: generate, check constraints, prove; same proof
+    # as from the host-generated trace
+    n = 1 << 12
+    cfg = (2, 9, 8)
+    config = ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(*cfg), ctx))
+    air = SynthMulAir(64)
+    dm = ts.DeviceMatrix.synth_mul(ctx, n, 64)
+    assert ts.check_constraints(air, dm, [], ctx) == -1
+    got = ts.prove(config, air, ts.BfChallenger(), dm, [])
+    want = ts.prove(config, air, ts.BfChallenger(), generate_synth_mul_trace(n), [])
+    assert (got.words == want.words).all()
+    fib = ts.DeviceMatrix.fibonacci(ctx, 0, 1, n)
+    host = generate_fibonacci_trace(0, 1, n)
+    pis = fibonacci_public_values(host)
+    got = ts.prove(config, FibonacciAir(), ts.BfChallenger(), fib, pis)
+    want = ts.prove(config, FibonacciAir(), ts.BfChallenger(), host, pis)
+    assert (got.words == want.words).all()

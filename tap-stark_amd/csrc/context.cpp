@@ -22,6 +22,7 @@ Context::~Context() {
     if (stream) hipStreamSynchronize(stream);
     if (d_twiddle_fwd) hipFree(d_twiddle_fwd);
     if (d_twiddle_inv) hipFree(d_twiddle_inv);
+    for (auto& t : scale_tables) hipFree(t.d);
     for (auto& kv : free_blocks) hipFree(kv.second);
     for (auto& kv : live_blocks) hipFree(kv.first);
     if (h_pinned) hipHostFree(h_pinned);

@@ -59,6 +59,18 @@ struct Context {
     uint32_t* d_twiddle_inv = nullptr;
     unsigned twiddle_log = 0;
 
+    // coset scale tables of the LDE (ntt_lde.hip): T[beta][k] = s_beta^k / n for one (log_n,
+    // log_blowup, shift); a trace commit asks for the same one every proof, so a few are kept
+    struct ScaleTable {
+        unsigned log_n, log_blowup;
+        uint32_t shift;
+        uint32_t* d;
+        size_t words;
+        uint64_t last_use;
+    };
+    std::vector<ScaleTable> scale_tables;
+    uint64_t scale_clock = 0;
+
     // pinned host staging
     void* h_pinned = nullptr;
     size_t h_pinned_bytes = 0;

@@ -21,6 +21,9 @@ void launch_build_twiddles(Context& ctx, uint32_t* W, uint32_t* Winv, unsigned l
 void launch_build_shift_tables(Context& ctx, uint32_t* lo, uint32_t* hi, uint32_t n_hi,
                                uint32_t n_cosets, uint32_t shift_mont, unsigned log_N,
                                unsigned log_blowup, uint32_t scale_mont);
+// T[beta][k] = s_beta^k / n (Montgomery), s_beta = shift * w_N^bitrev_b(beta), k < n: the factor the
+// LDE applies to coefficient k before the forward transform of coset beta.  Cached per context.
+const uint32_t* coset_scale_table(Context& ctx, unsigned log_n, unsigned log_blowup, uint32_t shift);
 // src: row-major n x w (natural rows)  ->  dst: column-major, rows in bit-reversed order
 void launch_transpose_bitrev(Context& ctx, const uint32_t* src, uint32_t* dst, unsigned log_n,
                              uint32_t w, uint64_t dst_col_stride);

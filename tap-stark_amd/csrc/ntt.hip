@@ -86,6 +86,54 @@ void launch_build_shift_tables(Context& ctx, uint32_t* lo, uint32_t* hi, uint32_
     TS_HIP(hipGetLastError());
 }
 
+// T[beta][k] = lo[beta][k & 1023] * hi[beta][k >> 10] = s_beta^k * scale   (Montgomery), k < n
+__global__ void __launch_bounds__(256)
+k_build_scale_table(const uint32_t* __restrict__ lo, const uint32_t* __restrict__ hi, uint32_t n_hi,
+                    unsigned log_n, uint32_t* __restrict__ T) {
+    const uint32_t beta = blockIdx.y;
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= (1ull << log_n)) return;
+    const uint32_t n_lo = 1u << SHIFT_LO_BITS;
+    T[((uint64_t)beta << log_n) + k] =
+        mont_mul(lo[beta * n_lo + (k & (n_lo - 1))], hi[(uint64_t)beta * n_hi + (k >> SHIFT_LO_BITS)]);
+}
+
+const uint32_t* coset_scale_table(Context& ctx, unsigned log_n, unsigned log_blowup, uint32_t shift) {
+    for (auto& t : ctx.scale_tables)
+        if (t.log_n == log_n && t.log_blowup == log_blowup && t.shift == shift) {
+            t.last_use = ++ctx.scale_clock;
+            return t.d;
+        }
+    const uint32_t n_cosets = 1u << log_blowup;
+    const size_t words = (size_t)n_cosets << log_n;
+    // keep at most 8 tables / 2 GiB; evicting needs the stream idle (a launch may still read one)
+    size_t total = words * 4;
+    for (auto& t : ctx.scale_tables) total += t.words * 4;
+    while (!ctx.scale_tables.empty() && (ctx.scale_tables.size() >= 8 || total > (2ull << 30))) {
+        size_t victim = 0;
+        for (size_t i = 1; i < ctx.scale_tables.size(); i++)
+            if (ctx.scale_tables[i].last_use < ctx.scale_tables[victim].last_use) victim = i;
+        ctx.sync();
+        total -= ctx.scale_tables[victim].words * 4;
+        (void)hipFree(ctx.scale_tables[victim].d);
+        ctx.scale_tables.erase(ctx.scale_tables.begin() + victim);
+    }
+    uint32_t* d = nullptr;
+    TS_HIP(hipMalloc((void**)&d, words * 4));
+    const uint64_t n = 1ull << log_n;
+    const uint32_t n_lo = 1u << SHIFT_LO_BITS;
+    const uint32_t n_hi = log_n > (unsigned)SHIFT_LO_BITS ? 1u << (log_n - SHIFT_LO_BITS) : 1u;
+    DevBuf<uint32_t> lo(&ctx, (size_t)n_cosets * n_lo), hi(&ctx, (size_t)n_cosets * n_hi);
+    const uint32_t n_inv_mont = to_mont(inv_canon((uint32_t)(n % P)));
+    launch_build_shift_tables(ctx, lo.p, hi.p, n_hi, n_cosets, to_mont(shift), log_n + log_blowup, log_blowup,
+                              n_inv_mont);
+    TS_LAUNCH(ctx, k_build_scale_table, dim3((unsigned)((n + 255) / 256), n_cosets), dim3(256), 0,
+              (const uint32_t*)lo.p, (const uint32_t*)hi.p, n_hi, log_n, d);
+    TS_HIP(hipGetLastError());
+    ctx.scale_tables.push_back(Context::ScaleTable{log_n, log_blowup, shift, d, words, ++ctx.scale_clock});
+    return d;
+}
+
 // ------------------------------------------------------------------ transposes
 // src row-major [n][w] natural  ->  dst[c][p] = src[bitrev(p)][c]
 __global__ void k_transpose_bitrev(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst,

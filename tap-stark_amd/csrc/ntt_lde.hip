@@ -20,7 +20,6 @@ constexpr int CHUNK = 1 << LOG_M;
 constexpr int NT = 256;            // threads per workgroup, contiguous kernels
 constexpr int NT_MID = 512;        // threads per workgroup, middle kernel
 constexpr int TILE_ELEMS = 8192;   // strided tile (generic plan)
-constexpr int SHIFT_LO_BITS = 10;  // coset scale s^k = hi[k >> 10] * lo[k & 1023]
 
 __device__ __forceinline__ uint32_t pad(uint32_t i) { return i + (i >> 4); }
 constexpr int padded(int n) { return n + (n >> 4); }
@@ -34,7 +33,10 @@ constexpr int padded(int n) { return n + (n >> 4); }
 // One round = K consecutive stages u0 .. u0+K-1 on register groups of 2^K elements spaced by the
 // distance 2^log_dl of the round's last stage.  LOG_DL >= 0 fixes that distance at compile time
 // (LDS addresses become base + immediate offsets); LOG_DL = -1 takes it from the arguments.
-template <int K, bool INV, int LOG_DL, int NTH>
+// TOP = true: the round starts at global stage 0 of a whole transform (s_base = u0 = c = 0, one group
+// block): block 0 of every stage has the twiddle w^0 = 1, i.e. butterflies with q < 2^(K-d) at local
+// stage d need no multiplication (all of stage 0, half of stage 1, ...: 47 % of a radix-16 round).
+template <int K, bool INV, int LOG_DL, int NTH, bool TOP = false>
 __device__ __forceinline__ void radix_round(uint32_t* s, unsigned log_total, unsigned u0,
                                             unsigned s_base, uint32_t c,
                                             const uint32_t* __restrict__ W) {
@@ -68,8 +70,9 @@ __device__ __forceinline__ void radix_round(uint32_t* s, unsigned log_total, uns
 #pragma unroll
                 for (int q = 0; q < R; q++) {
                     if ((q & half) == 0) {
-                        const uint32_t w = W[wb + (q >> (K - d))];
-                        const uint32_t a = v[q], t = mont_mul(v[q + half], w);
+                        const uint32_t a = v[q];
+                        uint32_t t = v[q + half];
+                        if (!(TOP && (q >> (K - d)) == 0)) t = mont_mul(t, W[wb + (q >> (K - d))]);
                         v[q] = add(a, t);
                         v[q + half] = sub(a, t);
                     }
@@ -83,10 +86,11 @@ __device__ __forceinline__ void radix_round(uint32_t* s, unsigned log_total, uns
 #pragma unroll
                 for (int q = 0; q < R; q++) {
                     if ((q & half) == 0) {
-                        const uint32_t w = W[wb + (q >> (K - d))];
                         const uint32_t a = v[q], b = v[q + half];
                         v[q] = add(a, b);
-                        v[q + half] = mont_mul(sub(a, b), w);
+                        uint32_t dlt = sub(a, b);
+                        if (!(TOP && (q >> (K - d)) == 0)) dlt = mont_mul(dlt, W[wb + (q >> (K - d))]);
+                        v[q + half] = dlt;
                     }
                 }
             }
@@ -209,8 +213,7 @@ __global__ void __launch_bounds__(NTM)
 k_lde_mid(const uint32_t* __restrict__ evals, uint64_t in_col_stride, uint32_t* __restrict__ out,
           uint64_t out_col_stride, unsigned log_n, unsigned log_len, unsigned log_T,
           unsigned row_shift, unsigned beta0, unsigned n_cosets, const uint32_t* __restrict__ W,
-          const uint32_t* __restrict__ Winv, const uint32_t* __restrict__ lo,
-          const uint32_t* __restrict__ hi, uint32_t n_hi) {
+          const uint32_t* __restrict__ Winv, const uint32_t* __restrict__ scale) {
     __shared__ uint32_t s[padded(TILE)];
     constexpr int PER_THREAD = TILE / NTM;
     constexpr int LOG_TILE = TILE == 8192 ? 13 : (TILE == 16384 ? 14 : 15);
@@ -236,11 +239,11 @@ k_lde_mid(const uint32_t* __restrict__ evals, uint64_t in_col_stride, uint32_t* 
     __syncthreads();
     if (PLAN == 1) {
         radix_round<4, true, 5, NTM>(s, 13, 4, 0, 0, Winv);
-        radix_round<4, true, 9, NTM>(s, 13, 0, 0, 0, Winv);
+        radix_round<4, true, 9, NTM, true>(s, 13, 0, 0, 0, Winv);
     } else if (PLAN == 2) {
         radix_round<3, true, LOG_TILE - 10, NTM>(s, LOG_TILE, 7, 0, 0, Winv);
         radix_round<3, true, LOG_TILE - 7, NTM>(s, LOG_TILE, 4, 0, 0, Winv);
-        radix_round<4, true, LOG_TILE - 4, NTM>(s, LOG_TILE, 0, 0, 0, Winv);
+        radix_round<4, true, LOG_TILE - 4, NTM, true>(s, LOG_TILE, 0, 0, 0, Winv);
     } else {
         tile_inverse_rt<NTM>(s, log_len, log_T, 0, 0, Winv);
     }
@@ -255,8 +258,7 @@ k_lde_mid(const uint32_t* __restrict__ evals, uint64_t in_col_stride, uint32_t* 
     // sharded prover owns a contiguous range of cosets)
     for (uint32_t bl = 0; bl < n_cosets; bl++) {
         const uint32_t beta = beta0 + bl;
-        const uint32_t* lo_b = lo + ((uint64_t)beta << SHIFT_LO_BITS);
-        const uint32_t* hi_b = hi + (uint64_t)beta * n_hi;
+        const uint32_t* sc = scale + ((uint64_t)beta << log_n);  // s_beta^k / n, one entry per coefficient
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < PER_THREAD; k++) {
@@ -264,16 +266,15 @@ k_lde_mid(const uint32_t* __restrict__ evals, uint64_t in_col_stride, uint32_t* 
             if (i < total) {
                 // coefficient index of this slot
                 const uint32_t kk = ((i >> log_T) << row_shift) + (i & tmask) + j2_0;
-                uint32_t v = mont_mul(coef[k], lo_b[kk & ((1u << SHIFT_LO_BITS) - 1)]);
-                s[pad(i)] = mont_mul(v, hi_b[kk >> SHIFT_LO_BITS]);
+                s[pad(i)] = mont_mul(coef[k], sc[kk]);
             }
         }
         __syncthreads();
         if (PLAN == 1) {
-            radix_round<4, false, 9, NTM>(s, 13, 0, 0, 0, W);
+            radix_round<4, false, 9, NTM, true>(s, 13, 0, 0, 0, W);
             radix_round<4, false, 5, NTM>(s, 13, 4, 0, 0, W);
         } else if (PLAN == 2) {
-            radix_round<4, false, LOG_TILE - 4, NTM>(s, LOG_TILE, 0, 0, 0, W);
+            radix_round<4, false, LOG_TILE - 4, NTM, true>(s, LOG_TILE, 0, 0, 0, W);
             radix_round<3, false, LOG_TILE - 7, NTM>(s, LOG_TILE, 4, 0, 0, W);
             radix_round<3, false, LOG_TILE - 10, NTM>(s, LOG_TILE, 7, 0, 0, W);
         } else {
@@ -298,8 +299,6 @@ void coset_lde(Context& ctx, uint32_t* evals, uint64_t in_col_stride, uint32_t n
     ctx.ensure_twiddles(log_n == 0 ? 1 : log_n);
     const uint32_t* W = ctx.d_twiddle_fwd;
     const uint32_t* Winv = ctx.d_twiddle_inv;
-    const uint64_t n = 1ull << log_n;
-    const uint32_t n_inv_mont = to_mont(inv_canon((uint32_t)(n % P)));
     unsigned log_T = 0;
     // TS_LDE_TILE (0 = generic plan / 8192 / 16384 / 32768) picks the PLAN 2 tile: a tuning knob.
     // Measured on 2^22 x 64, log_blowup 4 (ms per launch): generic 19.1, 8192 15.7, 16384 13.8,
@@ -314,15 +313,11 @@ void coset_lde(Context& ctx, uint32_t* evals, uint64_t in_col_stride, uint32_t n
         if (plan2) log_T = plan2_tile == 8192 ? 3 : (plan2_tile == 16384 ? 4 : 5);
     }
 
-    // per-coset scale tables s_beta^k / n
+    // per-coset scale table s_beta^k / n (cached per context: the trace's is the same every proof)
     const uint32_t n_cosets = 1u << log_blowup;
     if (n_beta == 0) n_beta = n_cosets - beta0;
     TS_REQUIRE(beta0 < n_cosets && n_beta <= n_cosets - beta0, TS_ERR_INVALID, "coset_lde: coset range");
-    const uint32_t n_lo = 1u << SHIFT_LO_BITS;
-    const uint32_t n_hi = log_n > (unsigned)SHIFT_LO_BITS ? 1u << (log_n - SHIFT_LO_BITS) : 1u;
-    DevBuf<uint32_t> lo(&ctx, (size_t)n_cosets * n_lo), hi(&ctx, (size_t)n_cosets * n_hi);
-    launch_build_shift_tables(ctx, lo.p, hi.p, n_hi, n_cosets, to_mont(shift), log_n + log_blowup,
-                              log_blowup, n_inv_mont);
+    const uint32_t* scale = coset_scale_table(ctx, log_n, log_blowup, shift);
 
     if (two_pass) {
         // the vectorised chunk loads need 16-byte aligned columns
@@ -333,7 +328,7 @@ void coset_lde(Context& ctx, uint32_t* evals, uint64_t in_col_stride, uint32_t n
         const dim3 grid(1u << (LOG_M - log_T), ncols);
 #define TS_MID_ARGS                                                                            \
     (const uint32_t*)evals, in_col_stride, out, out_col_stride, log_n, sA, log_T, (unsigned)LOG_M, \
-        beta0, n_beta, W, Winv, (const uint32_t*)lo.p, (const uint32_t*)hi.p, n_hi
+        beta0, n_beta, W, Winv, scale
         if (plan2 && plan2_tile == 8192)
             TS_LAUNCH(ctx, (k_lde_mid<2, 8192>), grid, dim3(NT_MID), 0, TS_MID_ARGS);
         else if (plan2 && plan2_tile == 16384)
@@ -343,17 +338,16 @@ void coset_lde(Context& ctx, uint32_t* evals, uint64_t in_col_stride, uint32_t n
         else if (sA == 8 && log_T == 5)
             TS_LAUNCH(ctx, k_lde_mid<1>, grid, dim3(NT_MID), 0, (const uint32_t*)evals, in_col_stride,
                       out, out_col_stride, log_n, sA, log_T, (unsigned)LOG_M, beta0, n_beta, W, Winv,
-                      (const uint32_t*)lo.p, (const uint32_t*)hi.p, n_hi);
+                      scale);
         else
             TS_LAUNCH(ctx, k_lde_mid<0>, grid, dim3(NT_MID), 0, (const uint32_t*)evals, in_col_stride,
                       out, out_col_stride, log_n, sA, log_T, (unsigned)LOG_M, beta0, n_beta, W, Winv,
-                      (const uint32_t*)lo.p, (const uint32_t*)hi.p, n_hi);
+                      scale);
         TS_LAUNCH(ctx, k_lde_fwd_contig, dim3(1u << sA, ncols, n_beta), dim3(NT), 0, out,
                   out_col_stride, log_n, W);
     } else {
         TS_LAUNCH(ctx, k_lde_mid<0>, dim3(1, ncols), dim3(NT_MID), 0, (const uint32_t*)evals,
-                  in_col_stride, out, out_col_stride, log_n, log_n, 0u, 0u, beta0, n_beta, W, Winv,
-                  (const uint32_t*)lo.p, (const uint32_t*)hi.p, n_hi);
+                  in_col_stride, out, out_col_stride, log_n, log_n, 0u, 0u, beta0, n_beta, W, Winv, scale);
     }
     TS_HIP(hipGetLastError());
 }

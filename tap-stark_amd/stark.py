@@ -419,21 +419,24 @@ class QueryProof:
     commit_phase_openings: list
 
 
-@dataclass
 class Proof:
-    """reference uni-stark/src/proof.rs:17-37 (+ FriProof fri/src/proof.rs:13-21), parsed from
-    the TSPF v1 words the library writes; ``words`` keeps the wire form."""
-    words: np.ndarray
-    degree_bits: int = 0
-    trace_commit: np.ndarray = None
-    quotient_commit: np.ndarray = None
-    trace_local: np.ndarray = None
-    trace_next: np.ndarray = None
-    quotient_chunks: np.ndarray = None
-    commit_phase_commits: np.ndarray = None
-    query_proofs: list = field(default_factory=list)
-    final_poly: np.ndarray = None
-    pow_witness: int = 0
+    """reference uni-stark/src/proof.rs:17-37 (+ FriProof fri/src/proof.rs:13-21) over the TSPF v1
+    words the library writes; ``words`` keeps the wire form.  The structured fields (``degree_bits``,
+    ``trace_commit``, ``quotient_commit``, ``trace_local``, ``trace_next``, ``quotient_chunks``,
+    ``commit_phase_commits``, ``query_proofs``, ``final_poly``, ``pow_witness``) are parsed on first
+    access: ``prove()`` hands back the words without spending interpreter time on them."""
+
+    _FIELDS = ("degree_bits", "trace_commit", "quotient_commit", "trace_local", "trace_next",
+               "quotient_chunks", "commit_phase_commits", "query_proofs", "final_poly", "pow_witness")
+
+    def __init__(self, words):
+        self.words = np.asarray(words, dtype=np.uint32)
+
+    def __getattr__(self, name):  # only reached for attributes not set yet
+        if name in Proof._FIELDS:
+            self._parse()
+            return self.__dict__[name]
+        raise AttributeError(name)
 
     def to_postcard(self) -> bytes:
         """postcard bytes of the reference's serde ``Proof`` (``ts_proof_to_postcard``)."""
@@ -461,7 +464,13 @@ class Proof:
 
     @classmethod
     def parse(cls, words: np.ndarray) -> "Proof":
-        w = np.asarray(words, dtype=np.uint32)
+        """Eager form: raises ``ValueError`` on a malformed buffer."""
+        pf = cls(words)
+        pf._parse()
+        return pf
+
+    def _parse(self) -> None:
+        w = self.words
         pos = 0
 
         def take(n):
@@ -475,13 +484,13 @@ class Proof:
         magic, version, degree_bits, width, qd = (int(x) for x in take(5))
         if magic != TSPF_MAGIC or version != 1:
             raise ValueError("not a TSPF v1 proof")
-        pf = cls(words=w, degree_bits=degree_bits)
-        pf.trace_commit, pf.quotient_commit = take(8), take(8)
-        pf.trace_local = take(4 * width).reshape(width, 4)
-        pf.trace_next = take(4 * width).reshape(width, 4)
-        pf.quotient_chunks = take(16 * qd).reshape(qd, 4, 4)
+        d = {"degree_bits": degree_bits, "query_proofs": []}
+        d["trace_commit"], d["quotient_commit"] = take(8), take(8)
+        d["trace_local"] = take(4 * width).reshape(width, 4)
+        d["trace_next"] = take(4 * width).reshape(width, 4)
+        d["quotient_chunks"] = take(16 * qd).reshape(qd, 4, 4)
         R = int(take(1)[0])
-        pf.commit_phase_commits = take(8 * R).reshape(R, 8)
+        d["commit_phase_commits"] = take(8 * R).reshape(R, 8)
         Q = int(take(1)[0])
         for _ in range(Q):
             nb = int(take(1)[0])
@@ -496,12 +505,12 @@ class Proof:
                 vals = take(8).reshape(2, 4)
                 plen = int(take(1)[0])
                 steps.append((vals, take(8 * plen).reshape(plen, 8)))
-            pf.query_proofs.append(QueryProof(batches, steps))
-        pf.final_poly = take(4)
-        pf.pow_witness = int(take(1)[0])
+            d["query_proofs"].append(QueryProof(batches, steps))
+        d["final_poly"] = take(4)
+        d["pow_witness"] = int(take(1)[0])
         if pos != len(w):
             raise ValueError("trailing words in proof")
-        return pf
+        self.__dict__.update(d)
 
 
 def prove(config: StarkConfig, air, challenger: BfChallenger, trace, public_values) -> Proof:
@@ -531,7 +540,7 @@ def prove(config: StarkConfig, air, challenger: BfChallenger, trace, public_valu
     pis_p = _p(pis) if len(pis) else None
     ctx.check(ctx._l.ts_prove(ctx.h, C.byref(cfg), air.h, challenger.h, trace.h, pis_p, len(pis),
                               _p(out), cap, C.byref(n_words)))
-    return Proof.parse(out[: n_words.value].copy())
+    return Proof(out[: n_words.value].copy())
 
 
 def prove_sharded(config: StarkConfig, air, challenger: BfChallenger, trace_rows, public_values,
@@ -567,7 +576,7 @@ def prove_sharded(config: StarkConfig, air, challenger: BfChallenger, trace_rows
     if rc == 7 and getattr(comm, "error", None):
         raise RuntimeError("communicator callback failed:\n" + comm.error)
     ctx.check(rc)
-    return Proof.parse(out[: n_words.value].copy())
+    return Proof(out[: n_words.value].copy())
 
 
 VERIFY_ERRORS = {0: "Ok", 1: "InvalidProofShape", 2: "InvalidOpeningArgument(InvalidProofShape)",

@@ -63,6 +63,15 @@ TS_HD uint32_t mont_reduce(uint64_t t) {
     uint32_t r = (uint32_t)((t + (uint64_t)m * P) >> 32);
     return umin32(r, r - P);
 }
+// [0, 2p) -> [0, p)
+TS_HD uint32_t red2p(uint32_t x) { return umin32(x, x - P); }
+// Montgomery product without the final range correction: a * b * 2^-32 mod p in [0, 2p), for
+// a * b < p * 2^32 (e.g. a < 2p, b < p).  The NTT kernels keep their butterflies in [0, 2p).
+TS_HD uint32_t mont_mul_lazy(uint32_t a, uint32_t b) {
+    const uint64_t t = (uint64_t)a * b;
+    const uint32_t m = (uint32_t)t * P_NEG_INV;
+    return (uint32_t)((t + (uint64_t)m * P) >> 32);
+}
 // a * b * 2^-32 mod p.  Needs a*b < p*2^32 (true if either operand is < p).
 TS_HD uint32_t mont_mul(uint32_t a, uint32_t b) { return mont_reduce((uint64_t)a * b); }
 TS_HD uint32_t to_mont(uint32_t a) { return mont_mul(a, R2_MOD_P); }

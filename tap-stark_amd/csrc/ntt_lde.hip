@@ -70,11 +70,14 @@ __device__ __forceinline__ void radix_round(uint32_t* s, unsigned log_total, uns
 #pragma unroll
                 for (int q = 0; q < R; q++) {
                     if ((q & half) == 0) {
-                        const uint32_t a = v[q];
+                        // lazy range: inputs and outputs in [0, 2p) (2p < 2^32), 10 VALU
+                        // instructions instead of 11: a -> [0, p), t in [0, p), a + t and a - t + p
+                        const uint32_t a = red2p(v[q]);
                         uint32_t t = v[q + half];
-                        if (!(TOP && (q >> (K - d)) == 0)) t = mont_mul(t, W[wb + (q >> (K - d))]);
-                        v[q] = add(a, t);
-                        v[q + half] = sub(a, t);
+                        if (TOP && (q >> (K - d)) == 0) t = red2p(t);
+                        else t = mont_mul(t, W[wb + (q >> (K - d))]);
+                        v[q] = a + t;
+                        v[q + half] = a - t + P;
                     }
                 }
             }
@@ -86,10 +89,11 @@ __device__ __forceinline__ void radix_round(uint32_t* s, unsigned log_total, uns
 #pragma unroll
                 for (int q = 0; q < R; q++) {
                     if ((q & half) == 0) {
-                        const uint32_t a = v[q], b = v[q + half];
-                        v[q] = add(a, b);
-                        uint32_t dlt = sub(a, b);
-                        if (!(TOP && (q >> (K - d)) == 0)) dlt = mont_mul(dlt, W[wb + (q >> (K - d))]);
+                        // lazy range [0, 2p) in and out: the product is left uncorrected
+                        const uint32_t a = red2p(v[q]), b = red2p(v[q + half]);
+                        v[q] = a + b;
+                        uint32_t dlt = a - b + P;
+                        if (!(TOP && (q >> (K - d)) == 0)) dlt = mont_mul_lazy(dlt, W[wb + (q >> (K - d))]);
                         v[q + half] = dlt;
                     }
                 }
@@ -164,7 +168,8 @@ __device__ __forceinline__ void chunk_store(const uint32_t* s, uint32_t* __restr
     for (int k = 0; k < CHUNK / 4 / NT; k++) {
         const uint32_t i4 = threadIdx.x + (uint32_t)k * NT;
         const uint32_t a = 4 * i4 + (i4 >> 2);
-        g4[i4] = make_uint4(s[a], s[a + 1], s[a + 2], s[a + 3]);
+        // the butterflies leave values in [0, 2p): canonical form on the way to HBM
+        g4[i4] = make_uint4(red2p(s[a]), red2p(s[a + 1]), red2p(s[a + 2]), red2p(s[a + 3]));
     }
 }
 
@@ -282,7 +287,7 @@ k_lde_mid(const uint32_t* __restrict__ evals, uint64_t in_col_stride, uint32_t* 
         }
         uint32_t* o = out + (uint64_t)blockIdx.y * out_col_stride + ((uint64_t)bl << log_n) + j2_0;
         for (uint32_t i = threadIdx.x; i < total; i += NTM)
-            o[((uint64_t)(i >> log_T) << row_shift) + (i & tmask)] = s[pad(i)];
+            o[((uint64_t)(i >> log_T) << row_shift) + (i & tmask)] = red2p(s[pad(i)]);
     }
 }
 

@@ -231,6 +231,21 @@ def main():
             import torch
             torch.cuda.synchronize()
 
+    # Prime every lane with one untimed proof of its own (beyond the W warm-up steps, which only
+    # reach the first W lanes): a context builds its twiddle / scale / selector tables and grows its
+    # device pool on first use, and that must not fall into the timed region.
+    if not sharded:
+        prime = [make_trace(lanes[l][0]) for l in range(S)]
+
+        def prime_lane(l):
+            c, conf, ca = lanes[l]
+            ts.prove(conf, ca, ts.BfChallenger(), prime[l], pis)
+        if S == 1:
+            prime_lane(0)
+        else:
+            list(pool.map(prime_lane, range(S)))
+        del prime
+
     # sharded: the ranks share each step's n*w cells
     res = run_timed(env, step, args.steps, args.warmup, local_sync,
                     units_per_step=float(n * w) / (env.world if sharded else 1), run_steps=run_steps)

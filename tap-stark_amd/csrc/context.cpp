@@ -23,6 +23,7 @@ Context::~Context() {
     if (d_twiddle_fwd) hipFree(d_twiddle_fwd);
     if (d_twiddle_inv) hipFree(d_twiddle_inv);
     for (auto& t : scale_tables) hipFree(t.d);
+    if (d_selectors) hipFree(d_selectors);
     for (auto& kv : free_blocks) hipFree(kv.second);
     for (auto& kv : live_blocks) hipFree(kv.first);
     if (h_pinned) hipHostFree(h_pinned);

@@ -70,6 +70,10 @@ struct Context {
     };
     std::vector<ScaleTable> scale_tables;
     uint64_t scale_clock = 0;
+    // the last selector table (is_first | is_last | is_transition on the quotient domain,
+    // quotient.hip): a function of (log_n, log_qd) only, so repeated proofs of one shape reuse it
+    uint32_t* d_selectors = nullptr;
+    unsigned sel_log_n = ~0u, sel_log_qd = ~0u;
 
     // pinned host staging
     void* h_pinned = nullptr;

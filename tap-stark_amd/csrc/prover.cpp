@@ -181,8 +181,18 @@ std::vector<DeviceMatrix> TwoAdicFriPcs::quotient_chunks_slab(const ColMat& lde_
     // whole cosets only: `next` (natural index + qd) stays inside a coset of H_n
     TS_REQUIRE(row_begin % n == 0 && row_end % n == 0, TS_ERR_INVALID, "quotient: slab must hold whole cosets");
 
-    DevBuf<uint32_t> sel(&ctx_, 3 * qn);
-    launch_selectors(ctx_, log_n, lqd, sel.p, sel.p + qn, sel.p + 2 * qn);
+    // selectors depend on the shape only: kept in the context between proofs
+    if (ctx_.sel_log_n != log_n || ctx_.sel_log_qd != lqd) {
+        ctx_.sync();  // an earlier launch may still read the old table
+        if (ctx_.d_selectors) (void)hipFree(ctx_.d_selectors);
+        ctx_.d_selectors = nullptr;
+        ctx_.sel_log_n = ctx_.sel_log_qd = ~0u;
+        TS_HIP(hipMalloc((void**)&ctx_.d_selectors, 3 * qn * sizeof(uint32_t)));
+        launch_selectors(ctx_, log_n, lqd, ctx_.d_selectors, ctx_.d_selectors + qn, ctx_.d_selectors + 2 * qn);
+        ctx_.sel_log_n = log_n;
+        ctx_.sel_log_qd = lqd;
+    }
+    struct { uint32_t* p; } sel{ctx_.d_selectors};
 
     // constants / public values in Montgomery form
     std::vector<uint32_t> consts(std::max<size_t>(air.const_canonical.size(), 1), 0);

@@ -74,17 +74,29 @@ def algorithmic_bytes_per_proof(n: int, w: int, b: int, qd: int) -> dict:
     # Merkle parents (64 B read + 32 B written each): two N-leaf trees + FRI trees (N/2 + N/4 + ..);
     # levels with > 2^16 children go through k_merkle_level, the rest through the subtree kernel
     parents_all = N + N + N // 2
-    small = 14 * (1 << 16)  # <= 2^16 parents per tree in the subtree kernels (14 trees reach it)
+    # per-level launches take the levels with >= 2^16 parents (two parents per thread from 2^18 up)
+    lvl2 = lvl1 = 0
+    for leaves in [N, N] + [N >> r for r in range(1, 40) if (N >> r) > (1 << 16)]:
+        p = leaves // 2
+        while p >= (1 << 16):
+            if p >= (1 << 18):
+                lvl2 += p
+            else:
+                lvl1 += p
+            p //= 2
+    small = max(parents_all - lvl1 - lvl2, 0)
     return {
         "k_transpose_bitrev": 8 * n * w,
         "k_intt_contig": 8 * n * wall,
         "k_lde_mid<1>": 4 * n * wall + 4 * N * wall,
         "k_lde_mid<0>": 4 * n * wall + 4 * N * wall,
         "k_lde_fwd_contig": 8 * N * wall,
-        "k_leaf_hash": 4 * N * wall + 2 * 32 * N,
+        "k_leaf_hash<2>": 4 * N * wall + 2 * 32 * N,
+        "k_leaf_hash<1>": 4 * N * wall + 2 * 32 * N,
         "k_leaf_hash_ef_pairs": 16 * N + 16 * N,
-        "k_merkle_level": 96 * max(parents_all - small, 0),
-        "(k_merkle_subtree<NTH, LOG_S>)": 96 * min(small, parents_all),
+        "k_merkle_level<2>": 96 * lvl2,
+        "k_merkle_level<1>": 96 * lvl1,
+        "(k_merkle_subtree<NTH, LOG_S>)": 96 * small,
         "k_selectors": 12 * n * qd,
         "k_quotient_jit": 4 * n * qd * w + 12 * n * qd + 16 * n * qd,
         "k_quotient<256>": 4 * n * qd * w + 12 * n * qd + 16 * n * qd,
@@ -272,7 +284,11 @@ def main():
         alg = algorithmic_bytes_per_proof(n, w, cfg[0], qd)
 
         def alg_bytes(name):  # every instantiation of the strided NTT pass moves the same bytes
-            return alg["k_lde_mid<1>"] if "k_lde_mid" in name else alg.get(name)
+            if "k_lde_mid" in name:
+                return alg["k_lde_mid<1>"]
+            if name == "k_merkle_level<1>" and "k_merkle_level<2>" not in kt:
+                return alg["k_merkle_level<1>"] + alg["k_merkle_level<2>"]
+            return alg.get(name)
 
         per_kernel = {}
         for name, (cnt, ms) in kt.items():

@@ -4,45 +4,67 @@
 //   node  = Blake3(left || right)
 // Leaves: one thread per row; column-major matrices make every column read a coalesced 256 B
 // per wavefront.  Digests are stored as 8 consecutive words per node, levels back to back.
+#include <stdlib.h>
+
 #include "blake3.hpp"
 #include "chal_dev.hpp"
 #include "kernels.hpp"
 
 namespace ts {
 
+// ROWS rows per thread (r, r + height/ROWS, ...): independent Blake3 chains in one thread give the
+// scheduler something to overlap with each chain's long dependency path
+template <int ROWS>
 __global__ void __launch_bounds__(256)
 k_leaf_hash(const uint32_t* const* __restrict__ cols, uint32_t total, uint64_t height,
             uint32_t* __restrict__ digests) {
-    uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= height) return;
-    uint32_t cv[8];
-    b3::iv(cv);
+    const uint64_t per = height / ROWS;  // host guarantees divisibility for ROWS > 1
+    const uint64_t r0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r0 >= per) return;
+    uint32_t cv[ROWS][8];
+#pragma unroll
+    for (int k = 0; k < ROWS; k++) b3::iv(cv[k]);
     const uint32_t n_blocks = total == 0 ? 1 : (total + 15) / 16;
     // walk the concatenated row 16 words (one Blake3 block) at a time; the 16 loads of a block are
     // independent and issue back to back
     for (uint32_t blk = 0; blk < n_blocks; blk++) {
-        uint32_t m[16];
+        uint32_t m[ROWS][16];
 #pragma unroll
         for (int j = 0; j < 16; j++) {
             const uint32_t c = blk * 16 + j;
-            m[j] = c < total ? cols[c][r] : 0u;
+            const uint32_t* col = c < total ? cols[c] : nullptr;
+#pragma unroll
+            for (int k = 0; k < ROWS; k++) m[k][j] = col ? col[r0 + (uint64_t)k * per] : 0u;
         }
         uint32_t words = total - blk * 16 < 16 ? total - blk * 16 : 16;
         uint32_t flags = (blk == 0 ? b3::CHUNK_START : 0u) |
                          (blk + 1 == n_blocks ? (b3::CHUNK_END | b3::ROOT) : 0u);
-        b3::compress(cv, m, words * 4, flags);
+#pragma unroll
+        for (int k = 0; k < ROWS; k++) b3::compress(cv[k], m[k], words * 4, flags);
     }
-    uint4* o = reinterpret_cast<uint4*>(digests + 8 * r);
-    o[0] = make_uint4(cv[0], cv[1], cv[2], cv[3]);
-    o[1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
+#pragma unroll
+    for (int k = 0; k < ROWS; k++) {
+        uint4* o = reinterpret_cast<uint4*>(digests + 8 * (r0 + (uint64_t)k * per));
+        o[0] = make_uint4(cv[k][0], cv[k][1], cv[k][2], cv[k][3]);
+        o[1] = make_uint4(cv[k][4], cv[k][5], cv[k][6], cv[k][7]);
+    }
 }
 
 void launch_leaf_hash(Context& ctx, const LeafMats& mats, uint64_t height, uint32_t* digests) {
     TS_REQUIRE(mats.total_width <= 256, TS_ERR_UNSUPPORTED,
                "leaf rows wider than 256 field elements (one Blake3 chunk) are not supported");
     TS_REQUIRE(mats.cols != nullptr, TS_ERR_INVALID, "leaf_hash: column pointer table missing");
-    TS_LAUNCH(ctx, k_leaf_hash, dim3((unsigned)((height + 255) / 256)), dim3(256), 0, mats.cols,
-              mats.total_width, height, digests);
+    static const int rows_per_thread = [] {
+        const char* e = getenv("TS_LEAF_ROWS");
+        return e ? atoi(e) : 1;
+    }();
+    if (rows_per_thread == 2 && height % 2 == 0 && height >= (1u << 16)) {
+        TS_LAUNCH(ctx, k_leaf_hash<2>, dim3((unsigned)((height / 2 + 255) / 256)), dim3(256), 0, mats.cols,
+                  mats.total_width, height, digests);
+    } else {
+        TS_LAUNCH(ctx, k_leaf_hash<1>, dim3((unsigned)((height + 255) / 256)), dim3(256), 0, mats.cols,
+                  mats.total_width, height, digests);
+    }
     TS_HIP(hipGetLastError());
 }
 
@@ -67,23 +89,52 @@ void launch_leaf_hash_ef_pairs(Context& ctx, const uint32_t* vec, uint64_t n_row
     TS_HIP(hipGetLastError());
 }
 
-// one level: parents[i] = Blake3(children[2i] || children[2i+1])
+// one level: parents[i] = Blake3(children[2i] || children[2i+1]); PAR parents per thread
+// (i, i + n/PAR, ...: independent chains, as in k_leaf_hash)
+template <int PAR>
 __global__ void __launch_bounds__(256)
 k_merkle_level(const uint4* __restrict__ children, uint4* __restrict__ parents, uint64_t n_parents) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_parents) return;
-    uint4 a = children[4 * i], b = children[4 * i + 1], c = children[4 * i + 2], d = children[4 * i + 3];
-    uint32_t m[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
-    uint32_t cv[8];
-    b3::hash64(m, cv);
-    parents[2 * i] = make_uint4(cv[0], cv[1], cv[2], cv[3]);
-    parents[2 * i + 1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
+    const uint64_t per = n_parents / PAR;
+    const uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i0 >= per) return;
+    uint32_t m[PAR][16], cv[PAR][8];
+#pragma unroll
+    for (int k = 0; k < PAR; k++) {
+        const uint64_t i = i0 + (uint64_t)k * per;
+        const uint4 a = children[4 * i], b = children[4 * i + 1], c = children[4 * i + 2], d = children[4 * i + 3];
+        m[k][0] = a.x; m[k][1] = a.y; m[k][2] = a.z; m[k][3] = a.w;
+        m[k][4] = b.x; m[k][5] = b.y; m[k][6] = b.z; m[k][7] = b.w;
+        m[k][8] = c.x; m[k][9] = c.y; m[k][10] = c.z; m[k][11] = c.w;
+        m[k][12] = d.x; m[k][13] = d.y; m[k][14] = d.z; m[k][15] = d.w;
+    }
+#pragma unroll
+    for (int k = 0; k < PAR; k++) b3::hash64(m[k], cv[k]);
+#pragma unroll
+    for (int k = 0; k < PAR; k++) {
+        const uint64_t i = i0 + (uint64_t)k * per;
+        parents[2 * i] = make_uint4(cv[k][0], cv[k][1], cv[k][2], cv[k][3]);
+        parents[2 * i + 1] = make_uint4(cv[k][4], cv[k][5], cv[k][6], cv[k][7]);
+    }
+}
+
+static void launch_level(Context& ctx, const uint32_t* children, uint32_t* parents, uint64_t n_parents) {
+    static const int par = [] {
+        // two parents per thread measured no better inside whole proofs (3.32 vs 3.27-3.33 ms/step);
+        // like TS_LEAF_ROWS this stays a knob for experiments
+        const char* e = getenv("TS_LEVEL_PAR");
+        return e ? atoi(e) : 1;
+    }();
+    if (par == 2 && n_parents >= (1u << 18) && n_parents % 2 == 0)
+        TS_LAUNCH(ctx, k_merkle_level<2>, dim3((unsigned)((n_parents / 2 + 255) / 256)), dim3(256), 0,
+                  reinterpret_cast<const uint4*>(children), reinterpret_cast<uint4*>(parents), n_parents);
+    else
+        TS_LAUNCH(ctx, k_merkle_level<1>, dim3((unsigned)((n_parents + 255) / 256)), dim3(256), 0,
+                  reinterpret_cast<const uint4*>(children), reinterpret_cast<uint4*>(parents), n_parents);
 }
 
 void launch_merkle_one_level(Context& ctx, const uint32_t* children, uint32_t* parents,
                              uint64_t n_parents) {
-    TS_LAUNCH(ctx, k_merkle_level, dim3((unsigned)((n_parents + 255) / 256)), dim3(256), 0,
-              reinterpret_cast<const uint4*>(children), reinterpret_cast<uint4*>(parents), n_parents);
+    launch_level(ctx, children, parents, n_parents);
     TS_HIP(hipGetLastError());
 }
 
@@ -229,9 +280,7 @@ bool launch_merkle_levels(Context& ctx, uint32_t* tree, unsigned log_leaves, Dev
     while (log_leaves - level > 16) {
         const uint64_t n_children = (uint64_t)1 << (log_leaves - level);
         const uint64_t n_parents = n_children / 2;
-        TS_LAUNCH(ctx, k_merkle_level, dim3((unsigned)((n_parents + 255) / 256)), dim3(256), 0,
-                  reinterpret_cast<const uint4*>(tree + 8 * off),
-                  reinterpret_cast<uint4*>(tree + 8 * (off + n_children)), n_parents);
+        launch_level(ctx, tree + 8 * off, tree + 8 * (off + n_children), n_parents);
         off += n_children;
         level++;
     }

@@ -233,6 +233,21 @@ ts_status ts_verify(const ts_fri_config* cfg, const ts_air* air, ts_challenger* 
                     const uint32_t* proof, size_t n_words, const uint32_t* public_values,
                     uint32_t n_public, int* verdict);
 
+/* Pcs::verify (fri/src/two_adic_pcs.rs:421-534 with fri/src/verifier.rs:20-165) for any rounds x
+ * matrices x points: the counterpart of ts_pcs_open, host only.  Arguments follow ts_pcs_open:
+ *   commitments   n_rounds x 8 words
+ *   mats_per_round[r], then per matrix k in (round, matrix) order: log_degrees[k] (log2 of the
+ *   committed matrix's height), widths[k], n_points[k]; points: 4 words each; opened_values: EF4 in
+ *   (round, matrix, point, column) order; fri_proof: what ts_pcs_open wrote.
+ * The challenger must be in the state the prover's had when ts_pcs_open was called.
+ * *verdict as for ts_verify (0 accept, 1 shape, 2 FRI shape, 3 PoW, 4 input MMCS, 5 commit-phase
+ * MMCS, 6 final poly, 8 folded evaluation, 9 malformed). */
+ts_status ts_pcs_verify(const ts_fri_config* cfg, ts_challenger* chal, uint32_t n_rounds,
+                        const uint32_t* commitments, const uint32_t* mats_per_round,
+                        const uint32_t* log_degrees, const uint32_t* widths, const uint32_t* n_points,
+                        const uint32_t* points, const uint32_t* opened_values,
+                        const uint32_t* fri_proof, size_t n_words, int* verdict);
+
 /* ------------------------------------------------------------------ proof wire format (host only) */
 /* TSPF v1 words <-> the postcard encoding of the reference's serde proof types
  * (uni-stark/src/proof.rs:17-38, fri/src/proof.rs:8-33, fri/src/two_adic_pcs.rs:63-68; postcard is

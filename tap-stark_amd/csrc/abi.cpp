@@ -85,6 +85,45 @@ ts::FriConfig load_cfg(const ts_fri_config* cfg) {
 
 extern "C" {
 
+ts_status ts_pcs_verify(const ts_fri_config* cfg, ts_challenger* chal, uint32_t n_rounds,
+                        const uint32_t* commitments, const uint32_t* mats_per_round,
+                        const uint32_t* log_degrees, const uint32_t* widths, const uint32_t* n_points,
+                        const uint32_t* points, const uint32_t* opened_values,
+                        const uint32_t* fri_proof, size_t n_words, int* verdict) {
+    if (!chal || !commitments || !mats_per_round || !log_degrees || !widths || !n_points || !fri_proof ||
+        !verdict || n_rounds == 0)
+        return TS_ERR_INVALID;
+    *verdict = 9;
+    return guard(nullptr, [&] {
+        const ts::FriConfig fri = load_cfg(cfg);
+        std::vector<ts::PcsRoundClaim> rounds(n_rounds);
+        size_t k = 0, pw = 0, ow = 0;
+        auto load_checked = [&](const uint32_t* p) {
+            for (int j = 0; j < 4; j++) TS_REQUIRE(p[j] < ts::P, ts::TS_ERR_INVALID, "non-canonical element");
+            return load_ef(p);
+        };
+        for (uint32_t r = 0; r < n_rounds; r++) {
+            rounds[r].root = commitments + 8 * (size_t)r;
+            TS_REQUIRE(mats_per_round[r] >= 1 && mats_per_round[r] <= 16, ts::TS_ERR_INVALID, "mats per round");
+            for (uint32_t i = 0; i < mats_per_round[r]; i++, k++) {
+                ts::PcsMatClaim m;
+                TS_REQUIRE(log_degrees[k] + fri.log_blowup <= 27, ts::TS_ERR_INVALID, "matrix too tall");
+                m.log_height = log_degrees[k] + fri.log_blowup;
+                m.width = widths[k];
+                TS_REQUIRE(n_points[k] == 0 || (points && opened_values), ts::TS_ERR_INVALID, "null points");
+                for (uint32_t p = 0; p < n_points[k]; p++, pw += 4) {
+                    m.points.push_back(load_checked(points + pw));
+                    std::vector<ts::Ef> vals(m.width);
+                    for (uint32_t c = 0; c < m.width; c++, ow += 4) vals[c] = load_checked(opened_values + ow);
+                    m.values.push_back(std::move(vals));
+                }
+                rounds[r].mats.push_back(std::move(m));
+            }
+        }
+        *verdict = ts::pcs_verify(fri, chal->c, rounds, fri_proof, n_words);
+    });
+}
+
 ts_status ts_proof_to_postcard(const uint32_t* proof, size_t n_words, uint8_t* out, size_t cap_bytes,
                                size_t* n_bytes_out) {
     if (!proof || !out || !n_bytes_out) return TS_ERR_INVALID;

@@ -173,6 +173,20 @@ std::vector<uint32_t> prove_sharded(TwoAdicFriPcs& pcs, const Comm& comm, const 
 int verify(const FriConfig& fri, const AirProgram& air, BfChallenger& challenger,
            const uint32_t* proof, size_t n_words, const std::vector<uint32_t>& public_values);
 
+// Pcs::verify (fri/src/two_adic_pcs.rs:421-534) for any rounds x matrices x points; same codes.
+struct PcsMatClaim {
+    unsigned log_height;                  // log2 of the LDE height = log_degree + log_blowup
+    uint32_t width;
+    std::vector<Ef> points;               // canonical EF4
+    std::vector<std::vector<Ef>> values;  // values[p][column], the claimed p_column(points[p])
+};
+struct PcsRoundClaim {
+    const uint32_t* root = nullptr;  // the round's commitment
+    std::vector<PcsMatClaim> mats;
+};
+int pcs_verify(const FriConfig& fri, BfChallenger& challenger, const std::vector<PcsRoundClaim>& rounds,
+               const uint32_t* fri_proof, size_t n_words);
+
 // ------------------------------------------------------------------ wire format (wire.cpp)
 bool tspf_to_postcard(const uint32_t* words, size_t n_words, std::vector<uint8_t>& out);
 bool postcard_to_tspf(const uint8_t* bytes, size_t n_bytes, std::vector<uint32_t>& out);

@@ -143,6 +143,149 @@ void eval_tape_ext(const AirProgram& air, const Ef* local, const Ef* next,
 
 }  // namespace
 
+// Pcs::verify, fri/src/two_adic_pcs.rs:421-534, with verify_shape_and_sample_challenges and
+// verify_challenges / verify_query of fri/src/verifier.rs:20-165, for any rounds x matrices x points.
+// `words` = the FriProof (TSPF v1 order, from the commit-phase round count on).  Returns 0 or the
+// error code of include/tapstark.h ts_verify.
+int pcs_verify(const FriConfig& fri, BfChallenger& challenger, const std::vector<PcsRoundClaim>& rounds,
+               const uint32_t* words, size_t n_words) {
+    Reader rb{words, n_words};
+    unsigned log_global_max_height = 0;  // two_adic_pcs.rs:447-455
+    for (auto& r : rounds)
+        for (auto& m : r.mats) {
+            if (m.log_height > 27 || m.log_height < fri.log_blowup || m.points.size() != m.values.size())
+                return 1;
+            for (auto& v : m.values)
+                if (v.size() != m.width) return 1;
+            log_global_max_height = std::max(log_global_max_height, m.log_height);
+        }
+    const Ef batch_alpha = challenger.sample();  // :443
+    const uint32_t R = rb.get();
+    if (rb.bad || R > 31) return 9;
+    const uint32_t* commits = rb.take(8 * (size_t)R);
+    if (rb.bad) return 9;
+    std::vector<Ef> betas(R);
+    for (uint32_t r = 0; r < R; r++) {  // fri/src/verifier.rs:32-39
+        challenger.observe_commitment(commits + 8 * r);
+        betas[r] = challenger.sample();
+    }
+    const uint32_t Q = rb.get();
+    if (rb.bad) return 9;
+    if (Q != fri.num_queries) return 2;  // :39-41 InvalidProofShape
+    const unsigned log_max_height = R + fri.log_blowup;
+    if (log_max_height != log_global_max_height) return 1;
+    // the PoW witness follows the queries in the buffer: locate it with a dry parse
+    const size_t save = rb.pos;
+    for (uint32_t q = 0; q < Q && !rb.bad; q++) {
+        const uint32_t nb = rb.get();
+        for (uint32_t k = 0; k < nb && !rb.bad; k++) {
+            const uint32_t nm = rb.get();
+            for (uint32_t i = 0; i < nm && !rb.bad; i++) rb.take(rb.get());
+            rb.take(8 * (size_t)rb.get());
+        }
+        for (uint32_t r = 0; r < R && !rb.bad; r++) {
+            rb.take(8);
+            rb.take(8 * (size_t)rb.get());
+        }
+    }
+    const uint32_t* tail = rb.take(5);
+    if (rb.bad) return 9;
+    if (rb.pos != rb.len) return 9;
+    for (int k = 0; k < 4; k++)
+        if (tail[k] >= P) return 9;
+    const Ef final_poly = Ef{{tail[0], tail[1], tail[2], tail[3]}};
+    const uint32_t pow_witness = tail[4];
+    rb.pos = save;
+    if (!challenger.check_witness(fri.proof_of_work_bits, pow_witness)) return 3;  // :44-46
+    std::vector<uint64_t> indices(Q);
+    for (uint32_t q = 0; q < Q; q++) indices[q] = challenger.sample_bits(log_max_height);  // :50-52
+
+    for (uint32_t q = 0; q < Q; q++) {  // verify_challenges, fri/src/verifier.rs:62-98
+        const uint64_t index = indices[q];
+        // ---- open_input, two_adic_pcs.rs:457-528: the reduced opening of every height
+        Ef ro[32], alpha_pow[32];
+        bool have[32] = {false};
+        for (int i = 0; i < 32; i++) {
+            ro[i] = ef_zero();
+            alpha_pow[i] = c_one();
+        }
+        if (rb.get() != rounds.size()) return 1;  // one BatchOpening per commit round
+        for (auto& round : rounds) {
+            const uint32_t nm = rb.get();
+            if (rb.bad || nm != round.mats.size()) return 1;
+            std::vector<uint32_t> rows;
+            std::vector<uint64_t> heights;
+            std::vector<uint32_t> widths;
+            unsigned log_batch_max = 0;
+            for (uint32_t i = 0; i < nm; i++) {
+                const uint32_t wd = rb.get();
+                if (rb.bad || wd != round.mats[i].width) return 1;
+                const uint32_t* vals = rb.take(wd);
+                if (rb.bad) return 9;
+                for (uint32_t c = 0; c < wd; c++)
+                    if (vals[c] >= P) return 9;
+                rows.insert(rows.end(), vals, vals + wd);
+                heights.push_back(1ull << round.mats[i].log_height);
+                widths.push_back(wd);
+                log_batch_max = std::max(log_batch_max, round.mats[i].log_height);
+            }
+            const uint32_t plen = rb.get();
+            const uint32_t* path = rb.take(8 * (size_t)plen);
+            if (rb.bad) return 9;
+            // :470-486 reduced_index = index >> (log_global_max_height - log_batch_max_height)
+            const uint64_t reduced_index = index >> (log_global_max_height - log_batch_max);
+            if (!mmcs_verify(heights, widths, reduced_index, rows.data(), path, plen, round.root))
+                return 4;  // InputError
+            size_t off = 0;
+            for (uint32_t i = 0; i < nm; i++) {  // :490-523
+                const PcsMatClaim& m = round.mats[i];
+                const unsigned lh = m.log_height;
+                const uint64_t rev = bitrev32((uint32_t)(index >> (log_global_max_height - lh)), lh);
+                const uint32_t x = mul(GENERATOR, pow_canon(two_adic_generator(lh), rev));
+                have[lh] = true;
+                for (size_t p = 0; p < m.points.size(); p++) {
+                    Ef acc = ef_zero();
+                    for (uint32_t c = 0; c < m.width; c++) {
+                        Ef diff = c_add_base(ef_neg(m.values[p][c]), rows[off + c]);
+                        acc = ef_add(acc, c_mul(alpha_pow[lh], diff));
+                        alpha_pow[lh] = c_mul(alpha_pow[lh], batch_alpha);
+                    }
+                    const Ef den = c_add_base(ef_neg(m.points[p]), x);
+                    ro[lh] = ef_add(ro[lh], c_mul(acc, c_inv(den)));
+                }
+                off += m.width;
+            }
+        }
+        // ---- verify_query, fri/src/verifier.rs:100-165
+        Ef folded_eval = ef_zero();
+        uint64_t query_index = index;
+        for (uint32_t r = 0; r < R; r++) {
+            const unsigned log_folded_height = log_max_height - 1 - r;
+            const uint64_t point_index = query_index & 1;
+            const uint64_t index_pair = query_index >> 1;
+            if (have[log_folded_height + 1]) folded_eval = ef_add(folded_eval, ro[log_folded_height + 1]);  // :127-130
+            const uint32_t* vals = rb.take(8);
+            const uint32_t plen = rb.get();
+            const uint32_t* path = rb.take(8 * (size_t)plen);
+            if (rb.bad) return 9;
+            for (int k = 0; k < 8; k++)
+                if (vals[k] >= P) return 9;
+            const Ef e0 = Ef{{vals[0], vals[1], vals[2], vals[3]}}, e1 = Ef{{vals[4], vals[5], vals[6], vals[7]}};
+            const Ef committed = point_index ? e1 : e0;
+            // :139-141 asserts this from the second round on; checking the first round as well is a
+            // strict superset (the reduced opening must be what was committed)
+            if (!ef_eq(folded_eval, committed)) return 8;
+            std::vector<uint64_t> hh{1ull << log_folded_height};
+            std::vector<uint32_t> ww{8};
+            if (!mmcs_verify(hh, ww, index_pair, vals, path, plen, commits + 8 * r)) return 5;  // :143-146
+            query_index = index_pair;
+            folded_eval = fold_row(query_index, log_folded_height, betas[r], e0, e1);  // :149-154
+        }
+        if (!ef_eq(folded_eval, final_poly)) return 6;  // :92-94 FinalPolyMismatch
+    }
+    return 0;
+}
+
 // 0 = accept; otherwise the reference's error (see include/tapstark.h ts_verify)
 int verify(const FriConfig& fri, const AirProgram& air, BfChallenger& challenger,
            const uint32_t* proof, size_t n_words, const std::vector<uint32_t>& pis) {
@@ -177,123 +320,18 @@ int verify(const FriConfig& fri, const AirProgram& air, BfChallenger& challenger
     const uint32_t gn = two_adic_generator(degree_bits);
     const Ef zeta_next = c_mul_base(zeta, gn);
 
-    // ---- pcs.verify, two_adic_pcs.rs:421-534
-    const Ef batch_alpha = challenger.sample();  // :443
-    const uint32_t R = rb.get();
-    if (rb.bad || R > 31) return 9;
-    const uint32_t* commits = rb.take(8 * (size_t)R);
-    if (rb.bad) return 9;
-    std::vector<Ef> betas(R);
-    for (uint32_t r = 0; r < R; r++) {  // fri/src/verifier.rs:32-39
-        challenger.observe_commitment(commits + 8 * r);
-        betas[r] = challenger.sample();
+    // ---- pcs.verify, two_adic_pcs.rs:421-534 (verifier.rs:77-101 builds these claims)
+    PcsRoundClaim r0, r1;
+    r0.root = trace_root;
+    r0.mats.push_back(PcsMatClaim{degree_bits + fri.log_blowup, w, {zeta, zeta_next}, {tl, tn}});
+    r1.root = quot_root;
+    for (uint32_t c = 0; c < qd; c++) {
+        std::vector<Ef> vals(qc.begin() + 4 * (size_t)c, qc.begin() + 4 * (size_t)c + 4);
+        r1.mats.push_back(PcsMatClaim{degree_bits + fri.log_blowup, 4, {zeta}, {vals}});
     }
-    const uint32_t Q = rb.get();
-    if (rb.bad) return 9;
-    if (Q != fri.num_queries) return 2;  // :39-41 InvalidProofShape
-    const unsigned log_max_height = R + fri.log_blowup;
-    if (log_max_height != degree_bits + fri.log_blowup) return 1;
-    // the PoW witness follows the queries in the buffer: locate it with a dry parse
-    const size_t save = rb.pos;
-    for (uint32_t q = 0; q < Q && !rb.bad; q++) {
-        const uint32_t nb = rb.get();
-        for (uint32_t k = 0; k < nb && !rb.bad; k++) {
-            const uint32_t nm = rb.get();
-            for (uint32_t i = 0; i < nm && !rb.bad; i++) rb.take(rb.get());
-            rb.take(8 * (size_t)rb.get());
-        }
-        for (uint32_t r = 0; r < R && !rb.bad; r++) {
-            rb.take(8);
-            rb.take(8 * (size_t)rb.get());
-        }
-    }
-    const uint32_t* tail = rb.take(5);
-    if (rb.bad) return 9;
-    if (rb.pos != rb.len) return 9;
-    Ef final_poly = Ef{{tail[0], tail[1], tail[2], tail[3]}};
-    const uint32_t pow_witness = tail[4];
-    rb.pos = save;
-    if (!challenger.check_witness(fri.proof_of_work_bits, pow_witness)) return 3;  // :44-46
-    std::vector<uint64_t> indices(Q);
-    for (uint32_t q = 0; q < Q; q++) indices[q] = challenger.sample_bits(log_max_height);  // :50-52
-
-    const unsigned log_N = log_max_height;
-    const uint64_t N = 1ull << log_N;
-    const uint32_t g_N = two_adic_generator(log_N);
-    for (uint32_t q = 0; q < Q; q++) {  // verify_challenges, fri/src/verifier.rs:62-98
-        const uint64_t index = indices[q];
-        if (rb.get() != 2) return 1;  // one BatchOpening per commit round
-        // x = 31 * w_N^bitrev(index): both batches have height N (two_adic_pcs.rs:494-500)
-        const uint32_t x = mul(GENERATOR, pow_canon(g_N, bitrev32((uint32_t)index, log_N)));
-        Ef alpha_pow = c_one(), ro = ef_zero();
-        // batch 0: trace matrix opened at zeta, zeta_next; batch 1: qd chunk matrices at zeta
-        for (int batch = 0; batch < 2; batch++) {
-            const uint32_t nm = rb.get();
-            if (rb.bad || nm != (batch == 0 ? 1u : qd)) return 1;
-            std::vector<uint32_t> rows;
-            std::vector<uint64_t> heights;
-            std::vector<uint32_t> widths;
-            for (uint32_t i = 0; i < nm; i++) {
-                const uint32_t wd = rb.get();
-                if (rb.bad || wd != (batch == 0 ? w : 4u)) return 1;
-                const uint32_t* vals = rb.take(wd);
-                if (rb.bad) return 9;
-                rows.insert(rows.end(), vals, vals + wd);
-                heights.push_back(N);
-                widths.push_back(wd);
-            }
-            const uint32_t plen = rb.get();
-            const uint32_t* path = rb.take(8 * (size_t)plen);
-            if (rb.bad) return 9;
-            if (!mmcs_verify(heights, widths, index, rows.data(), path, plen,
-                             batch == 0 ? trace_root : quot_root))
-                return 4;  // :481-486 InputError
-            size_t off = 0;
-            for (uint32_t i = 0; i < nm; i++) {  // :490-523
-                const int n_points = batch == 0 ? 2 : 1;
-                for (int p = 0; p < n_points; p++) {
-                    const Ef z = p == 0 ? zeta : zeta_next;
-                    const Ef* ps_at_z = batch == 0 ? (p == 0 ? tl.data() : tn.data()) : &qc[4 * (size_t)i];
-                    Ef acc = ef_zero();
-                    for (uint32_t c = 0; c < widths[i]; c++) {
-                        if (rows[off + c] >= P) return 9;
-                        Ef diff = c_add_base(ef_neg(ps_at_z[c]), rows[off + c]);
-                        acc = ef_add(acc, c_mul(alpha_pow, diff));
-                        alpha_pow = c_mul(alpha_pow, batch_alpha);
-                    }
-                    Ef den = c_add_base(ef_neg(z), x);
-                    ro = ef_add(ro, c_mul(acc, c_inv(den)));
-                }
-                off += widths[i];
-            }
-        }
-        // verify_query, fri/src/verifier.rs:100-165
-        Ef folded_eval = ef_zero();
-        uint64_t query_index = index;
-        for (uint32_t r = 0; r < R; r++) {
-            const unsigned log_folded_height = log_max_height - 1 - r;
-            const uint64_t point_index = query_index & 1;
-            const uint64_t index_pair = query_index >> 1;
-            if (r == 0) folded_eval = ef_add(folded_eval, ro);  // :127-130 (single input height)
-            const uint32_t* vals = rb.take(8);
-            const uint32_t plen = rb.get();
-            const uint32_t* path = rb.take(8 * (size_t)plen);
-            if (rb.bad) return 9;
-            for (int k = 0; k < 8; k++)
-                if (vals[k] >= P) return 9;
-            const Ef e0 = Ef{{vals[0], vals[1], vals[2], vals[3]}}, e1 = Ef{{vals[4], vals[5], vals[6], vals[7]}};
-            const Ef committed = point_index ? e1 : e0;
-            // :139-141 asserts this from the second round on; checking the first round as well is a
-            // strict superset (the reduced opening must be what was committed)
-            if (!ef_eq(folded_eval, committed)) return 8;
-            std::vector<uint64_t> hh{1ull << log_folded_height};
-            std::vector<uint32_t> ww{8};
-            if (!mmcs_verify(hh, ww, index_pair, vals, path, plen, commits + 8 * r)) return 5;  // :143-146
-            query_index = index_pair;
-            folded_eval = fold_row(query_index, log_folded_height, betas[r], e0, e1);  // :149-154
-        }
-        if (!ef_eq(folded_eval, final_poly)) return 6;  // :92-94 FinalPolyMismatch
-    }
+    Reader fr{proof + rb.pos, n_words - rb.pos};
+    const int rc = pcs_verify(fri, challenger, {r0, r1}, fr.w, fr.len);
+    if (rc) return rc;
 
     // ---- verifier.rs:103-132 quotient recombination
     std::vector<uint32_t> shifts(qd);

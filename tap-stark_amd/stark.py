@@ -333,6 +333,37 @@ class TwoAdicFriPcs:
             out.append(r_out)
         return out, proof[: n_p.value].copy()
 
+    def verify(self, rounds, fri_proof, challenger: "BfChallenger") -> None:
+        """``Pcs::verify`` (two_adic_pcs.rs:421-534), host only.  ``rounds``: list of
+        (commitment, mats) with ``mats[m] = (log_degree, [(point, values (width, 4)), ...])``.
+        Raises :class:`VerificationError`."""
+        roots, per_round, logs, widths, n_pts, pts, vals = [], [], [], [], [], [], []
+        for root, mats in rounds:
+            roots.append(_u32(root).reshape(8))
+            per_round.append(len(mats))
+            for log_degree, openings in mats:
+                logs.append(log_degree)
+                n_pts.append(len(openings))
+                width = None
+                for z, v in openings:
+                    v = _u32(v).reshape(-1, 4)
+                    width = len(v)
+                    pts.append(_u32(z).reshape(4))
+                    vals.append(v.reshape(-1))
+                widths.append(width or 0)
+        fri_proof = _u32(fri_proof)
+        verdict = C.c_int(9)
+        cfg = self.fri._c()
+        cat = lambda xs: _u32(np.concatenate(xs)) if xs else np.zeros(4, dtype=np.uint32)  # noqa: E731
+        rc = _lib.lib().ts_pcs_verify(C.byref(cfg), challenger.h, len(rounds), _p(cat(roots)),
+                                      _p(_u32(per_round)), _p(_u32(logs)), _p(_u32(widths)),
+                                      _p(_u32(n_pts)), _p(cat(pts)), _p(cat(vals)), _p(fri_proof),
+                                      len(fri_proof), C.byref(verdict))
+        if rc:
+            raise _lib.TsError(rc, "ts_pcs_verify")
+        if verdict.value:
+            raise VerificationError(verdict.value)
+
     def fold_matrix(self, vec, beta) -> np.ndarray:
         vec = _u32(vec)
         h = vec.shape[0] // 2

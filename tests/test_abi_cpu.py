@@ -244,3 +244,69 @@ def test_postcard_wire_format_round_trip(lib, orc):
             ts.Proof.from_postcard(bytes(nc))
     with pytest.raises(_lib.TsError):
         ts.Proof(words=words[:10]).to_postcard()
+
+
+# ------------------------------------------------------------------ Pcs::verify, any shape (host)
+PCS_VERIFY_SHAPES = [[[3]], [[2, 1]], [[2] * 5], [[4, 3]], [[3], [2]], [[2], [3, 3]], [[4, 2], [4, 2]],
+                     [[0, 1], [2]], [[6, 3, 6], [5, 2]]]
+
+
+@pytest.mark.parametrize("log_blowup", [1, 2])
+@pytest.mark.parametrize("shape", PCS_VERIFY_SHAPES, ids=[str(s) for s in PCS_VERIFY_SHAPES])
+def test_native_pcs_verify_on_oracle_openings(lib, orc, log_blowup, shape):
+    # the second half of fri/tests/pcs.rs:62-117: what the (oracle) prover opened, the product's
+    # Pcs::verify accepts from a fresh challenger in the same state -- and nothing else
+    from tapstark_amd.airs import splitmix64_stream
+    cfg = (log_blowup, 3, 8)
+    seed, evals = 500, []
+    for logs in shape:
+        evs = []
+        for lg in logs:
+            seed += 1
+            evs.append(splitmix64_stream(seed, (1 << lg) * (2 + seed % 3)).reshape(1 << lg, 2 + seed % 3))
+        evals.append(evs)
+    roots, zeta, opened, proof = orc.pcs_commit_open(orc.FriConfig(*cfg), shape, evals)
+    pcs = ts.TwoAdicFriPcs(ts.FriConfig(*cfg), host_only=True)
+
+    def claims(opened_vals, roots_=roots):
+        out, k = [], 0
+        for r, (logs, evs) in enumerate(zip(shape, evals)):
+            mats = []
+            for lg, e in zip(logs, evs):
+                w = e.shape[1]
+                mats.append((lg, [(zeta, opened_vals[k:k + w])]))
+                k += w
+            out.append((roots_[r], mats))
+        return out
+
+    def transcript():
+        ch = ts.BfChallenger()
+        for r in roots:
+            ch.observe_commitment(r)
+        assert (ch.sample() == zeta).all()
+        return ch
+
+    pcs.verify(claims(opened), proof, transcript())  # Ok(())
+    # a wrong opened value, a wrong commitment, a corrupted proof word, a wrong transcript
+    # (tampering with the LAST matrix: a height-1 matrix -- shape [0, ...], outside fri/tests/pcs.rs --
+    # has an LDE of exactly `blowup` rows, whose reduced opening no FRI round consumes; the
+    # reference only debug-asserts that case away, fri/src/verifier.rs:158-163)
+    bad = opened.copy()
+    bad[-1, 1] = (int(bad[-1, 1]) + 1) % 0x78000001
+    with pytest.raises(ts.VerificationError):
+        pcs.verify(claims(bad), proof, transcript())
+    bad_roots = roots.copy()
+    bad_roots[-1, 3] ^= 1
+    with pytest.raises(ts.VerificationError) as ei:
+        pcs.verify(claims(opened, bad_roots), proof, transcript())
+    assert ei.value.code == 4
+    for pos in (len(proof) - 1, len(proof) - 3, len(proof) // 2, 9):
+        badp = proof.copy()
+        badp[pos] = (int(badp[pos]) + 1) % 0x78000001
+        with pytest.raises(ts.VerificationError):
+            pcs.verify(claims(opened), badp, transcript())
+    with pytest.raises(ts.VerificationError):
+        pcs.verify(claims(opened), proof, ts.BfChallenger())
+    with pytest.raises(ts.VerificationError) as ei:
+        pcs.verify(claims(opened), proof[:-1], transcript())
+    assert ei.value.code == 9

@@ -384,6 +384,15 @@ def test_pcs_open_bit_identical_to_oracle(ctx, orc, log_blowup, shape):
     flat = np.concatenate([p for r in opened for m in r for p in m])
     assert (flat == oopened).all(), "opened values differ"
     assert len(proof) == len(oproof) and (proof == oproof).all(), "FriProof differs"
+    # pcs.rs:92-117: the verifier side, with the product's own Pcs::verify
+    vch = ts.BfChallenger()
+    for d in datas:
+        vch.observe_commitment(d.root)
+    assert (vch.sample() == zeta).all()
+    claims = [(d.root, [(lg, [(zeta, opened[r][m][0])]) for m, lg in enumerate(logs)])
+              for r, (d, logs) in enumerate(zip(datas, shape))]
+    pcs.verify(claims, proof, vch)
+    assert vch.sample_bits(16) == ch.sample_bits(16)  # prover and verifier transcripts agree
 
 
 def test_pcs_open_two_points_matches_prove_shape(ctx, orc):

@@ -310,3 +310,27 @@ def test_native_pcs_verify_on_oracle_openings(lib, orc, log_blowup, shape):
     with pytest.raises(ts.VerificationError) as ei:
         pcs.verify(claims(opened), proof[:-1], transcript())
     assert ei.value.code == 9
+
+
+# ------------------------------------------------------------------ compiled-language host (C++)
+def _build_example(tmp_path):
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "fib_air")
+    libdir = os.path.join(root, "tap-stark_amd", "lib")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "examples", "fib_air.cpp"), "-L", libdir, "-ltapstark_hip",
+                           f"-Wl,-rpath,{libdir}", "-o", exe])
+    return exe
+
+
+def test_cpp_air_capture_matches_python(lib, tmp_path):
+    """include/tapstark_air.hpp (the C++ SymbolicAirBuilder) captures FibonacciAir::eval into the
+    very tape the Python front-end produces; the example links against the C ABI with plain g++."""
+    import subprocess
+    exe = _build_example(tmp_path)
+    out = subprocess.run([exe, "--tape"], capture_output=True, text=True, check=True).stdout.splitlines()
+    tape = np.array([int(x) for x in out[0].split()], dtype=np.uint32)
+    assert (tape == ts.air_tape(FibonacciAir(), 3)).all()
+    assert out[1].split() == [str(ts.get_max_constraint_degree(FibonacciAir(), 3)),
+                              str(ts.get_log_quotient_degree(FibonacciAir(), 3))]

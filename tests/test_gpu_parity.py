@@ -454,3 +454,26 @@ def test_prove_from_device_generated_trace(ctx, orc):
     got = ts.prove(config, FibonacciAir(), ts.BfChallenger(), fib, pis)
     want = ts.prove(config, FibonacciAir(), ts.BfChallenger(), host, pis)
     assert (got.words == want.words).all()
+
+
+# ------------------------------------------------------------------ compiled-language host (C++)
+def test_cpp_example_runs_the_reference_test_through_the_c_abi(ctx, orc, tmp_path):
+    """examples/fib_air.cpp = uni-stark/tests/fib_air.rs (prove, verify with a fresh challenger) in
+    C++ over include/tapstark.h only; its proof is the one the Python binding and the oracle produce."""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_abi_cpu import _build_example
+    exe = _build_example(tmp_path)
+    for log_n in (3, 10):
+        out_bin = str(tmp_path / f"proof{log_n}.bin")
+        r = subprocess.run([exe, str(log_n), out_bin], capture_output=True, text=True, timeout=240)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "verify -> 0, with a wrong public value -> 7" in r.stdout
+        words = np.fromfile(out_bin, dtype=np.uint32)
+        trace = generate_fibonacci_trace(0, 1, 1 << log_n)
+        pis = fibonacci_public_values(trace)
+        if log_n == 3:
+            assert "public values [0, 1, 21]" in r.stdout  # fib_air.rs:143
+        want = orc.prove(orc.FriConfig(2, 28, 8), ts.air_tape(FibonacciAir(), 3), trace, pis)
+        assert len(words) == len(want) and (words == want).all()

@@ -52,6 +52,14 @@ def workload(name: str, log_n: int, need_host_trace: bool):
         desc = (f"SynthMulAir-64 (build-defined), trace 2^{log_n}x64, log_blowup={cfg[0]}, "
                 f"{cfg[1]} queries, pow 8")
         return air, trace, pis, desc, cfg, (n, 64), lambda c: ts.DeviceMatrix.synth_mul(c, n, 64)
+    if name == "config5":  # build-defined stand-in for the RISC0-recursion-style AIR
+        from tapstark_amd.airs import SynthExtAir, generate_synth_ext_trace
+        air = SynthExtAir(163)
+        host = generate_synth_ext_trace(n, 163)  # no device generator for this one: uploaded
+        pis = np.zeros(0, dtype=np.uint32)
+        desc = (f"SynthExt-163 (build-defined, EF4 multiplication constraints), trace 2^{log_n}x163, "
+                "log_blowup=4, 16 queries, pow 8")
+        return air, host, pis, desc, (4, 16, 8), (n, 163), lambda c: ts.DeviceMatrix.upload(c, host)
     if name == "config2":
         air = FibonacciAir()
         trace = generate_fibonacci_trace(0, 1, n) if need_host_trace else None
@@ -148,7 +156,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="config3", choices=["config3", "config2", "config4"])
+    ap.add_argument("--workload", default="config3", choices=["config3", "config2", "config4", "config5"])
     ap.add_argument("--log-n", type=int, default=None, help="default 20 (22 for config4)")
     ap.add_argument("--mode", default="replicas", choices=["replicas", "sharded"],
                     help="N > 1: independent proofs per GPU (default) or one proof over all GPUs")

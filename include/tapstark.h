@@ -159,6 +159,19 @@ ts_status ts_pcs_open(ts_ctx* ctx, const ts_fri_config* cfg, ts_challenger* chal
                       size_t* n_opened_words, uint32_t* proof_out, size_t proof_cap_words,
                       size_t* n_proof_words);
 
+/* bf_prove (fri/src/prover.rs:19-63) on its own, as fri/tests/fri.rs:51-147 drives it: `n_inputs`
+ * host vectors of EF4 (4 words per element; BabyBear values are embedded as (v, 0, 0, 0)) of
+ * strictly descending power-of-two lengths 2^log_lens[k]; the "input opening proof" of a query is
+ * the literal reduced openings [(log_height, value)] (fri.rs:109-118).  Any challenger kind
+ * (ts_chal_new: Blake3 or the test permutation, EF4 or BabyBear samples).  The proof is the FriProof
+ * in TSPF v1 words with that input-proof shape.  ts_fri_verify = verify_shape_and_sample_challenges
+ * + verify_challenges (fri/src/verifier.rs:20-98) for such a proof; verdict codes as ts_verify. */
+ts_status ts_fri_prove(ts_ctx* ctx, const ts_fri_config* cfg, ts_challenger* chal, uint32_t n_inputs,
+                       const uint32_t* log_lens, const uint32_t* const* inputs, uint32_t* proof_out,
+                       size_t cap_words, size_t* n_words_out);
+ts_status ts_fri_verify(const ts_fri_config* cfg, ts_challenger* chal, const uint32_t* proof,
+                        size_t n_words, int* verdict);
+
 /* FriGenericConfig::fold_matrix, two_adic_pcs.rs:116-147 (host in, host out; 2h EF4 -> h EF4) */
 ts_status ts_fri_fold(ts_ctx* ctx, const uint32_t* in, uint64_t h, const uint32_t beta[4],
                       uint32_t* out);

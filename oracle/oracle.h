@@ -185,6 +185,14 @@ int64_t ts_or_pcs_commit_open(const ts_or_fri_config* cfg, ts_or_challenger* cha
                               uint32_t* roots_out, uint32_t* zeta_out, uint32_t* opened_out,
                               uint32_t* proof_out, size_t cap_words);
 
+/* fri/tests/fri.rs:51-147: bf_prove over given EF4 vectors with pass-through input openings, and
+ * the matching verifier; see stark.c */
+int64_t ts_or_fri_prove(const ts_or_fri_config* cfg, ts_or_challenger* chal, int n_inputs,
+                        const unsigned* log_lens, const uint32_t* const* inputs,
+                        uint32_t* proof_out, size_t cap_words);
+int ts_or_fri_verify(const ts_or_fri_config* cfg, ts_or_challenger* chal, const uint32_t* proof,
+                     size_t n_words);
+
 #ifdef __cplusplus
 }
 #endif

@@ -364,3 +364,23 @@ def pcs_commit_open(cfg: FriConfig, log_degrees_by_round, evals_by_round,
     if n < 0:
         raise RuntimeError(f"oracle pcs_commit_open failed: {n}")
     return roots, zeta, opened, proof[:n].copy()
+
+
+def fri_prove(cfg: FriConfig, inputs, chal: OracleChallenger) -> np.ndarray:
+    """fri/tests/fri.rs: bf_prove over EF4 vectors (descending lengths), pass-through input proof."""
+    inputs = [_u32(v) for v in inputs]
+    k = len(inputs)
+    logs = [(v.shape[0]).bit_length() - 1 for v in inputs]
+    cap = 1 << 22
+    out = np.zeros(cap, dtype=np.uint32)
+    lib().ts_or_fri_prove.restype = C.c_int64
+    n = lib().ts_or_fri_prove(C.byref(cfg), C.byref(chal.c), k, (C.c_uint * k)(*logs),
+                              (u32p * k)(*[_p(v) for v in inputs]), _p(out), C.c_size_t(cap))
+    if n < 0:
+        raise RuntimeError(f"oracle fri_prove failed: {n}")
+    return out[:n].copy()
+
+
+def fri_verify(cfg: FriConfig, proof, chal: OracleChallenger) -> int:
+    proof = _u32(proof)
+    return int(lib().ts_or_fri_verify(C.byref(cfg), C.byref(chal.c), _p(proof), C.c_size_t(len(proof))))

@@ -964,3 +964,25 @@ int64_t ts_or_pcs_commit_open(const ts_or_fri_config* cfg, ts_or_challenger* cha
     if (b.overflow) return -1;
     return (int64_t)b.len;
 }
+
+/* ------------------------------------------------------ bf_prove / FRI verify alone, exported
+ * fri/tests/fri.rs:51-147: FRI over given input vectors (EF4, strictly descending lengths) with the
+ * literal reduced openings as the "input opening proof" (:109-118).  The challenger may be of either
+ * kind (Blake3 or the test's reverse permutation; F = EF4 or BabyBear embedded). */
+int64_t ts_or_fri_prove(const ts_or_fri_config* cfg, ts_or_challenger* chal, int n_inputs,
+                        const unsigned* log_lens, const uint32_t* const* inputs,
+                        uint32_t* proof_out, size_t cap_words) {
+    ts_or_wbuf b;
+    wb_init(&b, proof_out, cap_words);
+    int rc = bf_prove(cfg, n_inputs, (ef4* const*)inputs, log_lens, chal, NULL, 1, &b);
+    if (rc) return rc;
+    if (b.overflow) return -1;
+    return (int64_t)b.len;
+}
+int ts_or_fri_verify(const ts_or_fri_config* cfg, ts_or_challenger* chal, const uint32_t* proof,
+                     size_t n_words) {
+    rbuf rb = {proof, n_words, 0, 0};
+    int rc = fri_verify(cfg, 0, NULL, ef4_one(), chal, &rb, 1);
+    if (rc == 0 && rb.pos != rb.len) rc = 9;
+    return rc;
+}

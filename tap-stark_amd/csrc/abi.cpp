@@ -495,6 +495,43 @@ ts_status ts_pcs_open(ts_ctx* ctx, const ts_fri_config* cfg, ts_challenger* chal
     });
 }
 
+ts_status ts_fri_prove(ts_ctx* ctx, const ts_fri_config* cfg, ts_challenger* chal, uint32_t n_inputs,
+                       const uint32_t* log_lens, const uint32_t* const* inputs, uint32_t* proof_out,
+                       size_t cap_words, size_t* n_words_out) {
+    if (!ctx || !chal || !log_lens || !inputs || !proof_out || !n_words_out || n_inputs == 0 || n_inputs > 32)
+        return TS_ERR_INVALID;
+    *n_words_out = 0;
+    return guard(ctx, [&] {
+        ts::TwoAdicFriPcs pcs(ctx->ctx, load_cfg(cfg));
+        std::vector<ts::DevBuf<ts::Ef>> in;
+        std::vector<unsigned> logs;
+        for (uint32_t k = 0; k < n_inputs; k++) {
+            TS_REQUIRE(inputs[k] && log_lens[k] <= 27, ts::TS_ERR_INVALID, "fri_prove: bad input");
+            const size_t len = (size_t)1 << log_lens[k];
+            for (size_t i = 0; i < 4 * len; i++)
+                TS_REQUIRE(inputs[k][i] < ts::P, ts::TS_ERR_INVALID, "fri_prove: non-canonical element");
+            ts::DevBuf<ts::Ef> d(&ctx->ctx, len);
+            TS_HIP(hipMemcpyAsync(d.p, inputs[k], len * sizeof(ts::Ef), hipMemcpyHostToDevice, ctx->ctx.stream));
+            in.push_back(std::move(d));
+            logs.push_back(log_lens[k]);
+        }
+        ctx->ctx.sync();
+        std::vector<uint32_t> pf;
+        pcs.fri_prove(in, logs, chal->c, {}, pf, /*pass_through=*/true);
+        *n_words_out = pf.size();
+        TS_REQUIRE(pf.size() <= cap_words, ts::TS_ERR_BUFFER, "proof buffer too small");
+        memcpy(proof_out, pf.data(), pf.size() * 4);
+    });
+}
+ts_status ts_fri_verify(const ts_fri_config* cfg, ts_challenger* chal, const uint32_t* proof,
+                        size_t n_words, int* verdict) {
+    if (!chal || !proof || !verdict) return TS_ERR_INVALID;
+    *verdict = 9;
+    return guard(nullptr, [&] {
+        *verdict = ts::fri_verify_pass_through(load_cfg(cfg), chal->c, proof, n_words);
+    });
+}
+
 ts_status ts_fri_fold(ts_ctx* ctx, const uint32_t* in, uint64_t h, const uint32_t beta[4], uint32_t* out) {
     if (!ctx || !in || !beta || !out || h == 0) return TS_ERR_INVALID;
     return guard(ctx, [&] {

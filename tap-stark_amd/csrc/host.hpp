@@ -126,9 +126,11 @@ public:
 
     // fri/src/prover.rs:19-141 bf_prove over the reduced openings (strictly descending heights),
     // with the input openings of two_adic_pcs.rs:399-414; appends the FriProof to `pf`
+    // pass_through: no committed batches; the input proof of a query is the literal reduced
+    // openings [(log_height, value)] as in fri/tests/fri.rs:109-118
     void fri_prove(std::vector<DevBuf<Ef>>& inputs, const std::vector<unsigned>& log_lens,
                    BfChallenger& challenger, const std::vector<const PcsData*>& input_rounds,
-                   std::vector<uint32_t>& pf);
+                   std::vector<uint32_t>& pf, bool pass_through = false);
 
     // BFMmcs::open_batch
     void open_batch(const PcsData& d, uint64_t index, std::vector<uint32_t>& rows,
@@ -186,6 +188,10 @@ struct PcsRoundClaim {
 };
 int pcs_verify(const FriConfig& fri, BfChallenger& challenger, const std::vector<PcsRoundClaim>& rounds,
                const uint32_t* fri_proof, size_t n_words);
+// FRI alone (fri/src/verifier.rs:20-165) on a proof whose input proofs are the literal reduced
+// openings (fri/tests/fri.rs:126-140)
+int fri_verify_pass_through(const FriConfig& fri, BfChallenger& challenger, const uint32_t* fri_proof,
+                            size_t n_words);
 
 // ------------------------------------------------------------------ wire format (wire.cpp)
 bool tspf_to_postcard(const uint32_t* words, size_t n_words, std::vector<uint8_t>& out);

@@ -503,10 +503,17 @@ Ef fri_commit_finish(Context& ctx, const FriConfig& fri, BfChallenger& challenge
 void TwoAdicFriPcs::fri_prove(std::vector<DevBuf<Ef>>& inputs, const std::vector<unsigned>& log_lens,
                               BfChallenger& challenger,
                               const std::vector<const PcsData*>& input_rounds,
-                              std::vector<uint32_t>& pf) {
+                              std::vector<uint32_t>& pf, bool pass_through) {
     Context& ctx = ctx_;
     const FriConfig& fri = fri_;
     TS_REQUIRE(!inputs.empty() && inputs.size() == log_lens.size(), TS_ERR_INVALID, "FRI: no input");
+    // pass-through input proof (fri/tests/fri.rs:109-118): the literal reduced openings; the input
+    // vectors stay alive (and unmodified) in the commit state until the queries are answered
+    std::vector<const Ef*> in_ptr;
+    for (auto& v : inputs) in_ptr.push_back(v.p);
+    if (pass_through)
+        TS_REQUIRE(input_rounds.empty() && log_lens.back() >= 1, TS_ERR_INVALID,
+                   "FRI: pass-through input proof takes no committed batches");
     for (size_t k = 1; k < log_lens.size(); k++)
         TS_REQUIRE(log_lens[k] < log_lens[k - 1], TS_ERR_INVALID, "FRI: inputs must descend in height");
     const unsigned log_max_height = log_lens[0];  // prover.rs:30
@@ -557,7 +564,14 @@ void TwoAdicFriPcs::fri_prove(std::vector<DevBuf<Ef>>& inputs, const std::vector
         o_fvals[r] = off; off += (size_t)Q * 8;
         o_fpath[r] = off; off += (size_t)Q * 8 * rounds[r].log_leaves;
     }
+    std::vector<size_t> o_pass(pass_through ? in_ptr.size() : 0);
+    for (size_t k = 0; k < o_pass.size(); k++) {
+        o_pass[k] = off; off += (size_t)Q * 8;
+    }
     DevBuf<uint32_t> d_out(&ctx, std::max<size_t>(off, 1));
+    for (size_t k = 0; k < o_pass.size(); k++)  // the pair holding element index >> shift
+        launch_gather_ef_pairs(ctx, in_ptr[k], d_idx.p, Q, log_max_height - log_lens[k] + 1,
+                               d_out.p + o_pass[k]);
     for (size_t k = 0; k < n_in_rounds; k++) {
         // two_adic_pcs.rs:403-409: bits_reduced = log_global_max_height - log_max_height(batch)
         const unsigned bits_reduced = log_max_height - input_rounds[k]->log_height;
@@ -591,7 +605,16 @@ void TwoAdicFriPcs::fri_prove(std::vector<DevBuf<Ef>>& inputs, const std::vector
     for (uint32_t r = 0; r < R; r++) push_n(rounds[r].root, 8);
     push(Q);
     for (uint32_t q = 0; q < Q; q++) {
-        push((uint32_t)n_in_rounds);  // input_proof: one BatchOpening per commit round
+        if (pass_through) {  // fri.rs:109-118: [(log_height, value)] by descending height
+            push((uint32_t)in_ptr.size());
+            for (size_t k = 0; k < in_ptr.size(); k++) {
+                push(log_lens[k]);
+                const uint32_t half = (indices[q] >> (log_max_height - log_lens[k])) & 1;
+                push_n(&g[o_pass[k] + (size_t)q * 8 + 4 * half], 4);
+            }
+        } else {
+            push((uint32_t)n_in_rounds);  // input_proof: one BatchOpening per commit round
+        }
         for (size_t k = 0; k < n_in_rounds; k++) {
             const LeafMats& lm = lms[k];
             push(lm.n_mats);

@@ -147,8 +147,22 @@ void eval_tape_ext(const AirProgram& air, const Ef* local, const Ef* next,
 // verify_challenges / verify_query of fri/src/verifier.rs:20-165, for any rounds x matrices x points.
 // `words` = the FriProof (TSPF v1 order, from the commit-phase round count on).  Returns 0 or the
 // error code of include/tapstark.h ts_verify.
+static int fri_verify_impl(const FriConfig& fri, BfChallenger& challenger,
+                           const std::vector<PcsRoundClaim>& rounds, bool pass_through,
+                           const uint32_t* words, size_t n_words);
+
 int pcs_verify(const FriConfig& fri, BfChallenger& challenger, const std::vector<PcsRoundClaim>& rounds,
                const uint32_t* words, size_t n_words) {
+    return fri_verify_impl(fri, challenger, rounds, false, words, n_words);
+}
+int fri_verify_pass_through(const FriConfig& fri, BfChallenger& challenger, const uint32_t* words,
+                            size_t n_words) {
+    return fri_verify_impl(fri, challenger, {}, true, words, n_words);
+}
+
+static int fri_verify_impl(const FriConfig& fri, BfChallenger& challenger,
+                           const std::vector<PcsRoundClaim>& rounds, bool pass_through,
+                           const uint32_t* words, size_t n_words) {
     Reader rb{words, n_words};
     unsigned log_global_max_height = 0;  // two_adic_pcs.rs:447-455
     for (auto& r : rounds)
@@ -159,7 +173,7 @@ int pcs_verify(const FriConfig& fri, BfChallenger& challenger, const std::vector
                 if (v.size() != m.width) return 1;
             log_global_max_height = std::max(log_global_max_height, m.log_height);
         }
-    const Ef batch_alpha = challenger.sample();  // :443
+    const Ef batch_alpha = pass_through ? c_one() : challenger.sample();  // :443
     const uint32_t R = rb.get();
     if (rb.bad || R > 31) return 9;
     const uint32_t* commits = rb.take(8 * (size_t)R);
@@ -173,12 +187,17 @@ int pcs_verify(const FriConfig& fri, BfChallenger& challenger, const std::vector
     if (rb.bad) return 9;
     if (Q != fri.num_queries) return 2;  // :39-41 InvalidProofShape
     const unsigned log_max_height = R + fri.log_blowup;
-    if (log_max_height != log_global_max_height) return 1;
+    if (!pass_through && log_max_height != log_global_max_height) return 1;
+    if (pass_through) log_global_max_height = log_max_height;
     // the PoW witness follows the queries in the buffer: locate it with a dry parse
     const size_t save = rb.pos;
     for (uint32_t q = 0; q < Q && !rb.bad; q++) {
         const uint32_t nb = rb.get();
         for (uint32_t k = 0; k < nb && !rb.bad; k++) {
+            if (pass_through) {  // (log_height, value)
+                rb.take(5);
+                continue;
+            }
             const uint32_t nm = rb.get();
             for (uint32_t i = 0; i < nm && !rb.bad; i++) rb.take(rb.get());
             rb.take(8 * (size_t)rb.get());
@@ -209,7 +228,24 @@ int pcs_verify(const FriConfig& fri, BfChallenger& challenger, const std::vector
             ro[i] = ef_zero();
             alpha_pow[i] = c_one();
         }
-        if (rb.get() != rounds.size()) return 1;  // one BatchOpening per commit round
+        if (pass_through) {  // fri.rs:126-140: the input proof IS the reduced openings
+            const uint32_t n_in = rb.get();
+            if (rb.bad || n_in > 32) return 9;
+            unsigned prev = 32;
+            for (uint32_t k = 0; k < n_in; k++) {
+                const uint32_t* e = rb.take(5);
+                if (rb.bad) return 9;
+                const unsigned lh = e[0];
+                if (lh >= prev || lh > log_max_height) return 1;  // sorted by descending height
+                prev = lh;
+                for (int j = 1; j < 5; j++)
+                    if (e[j] >= P) return 9;
+                ro[lh] = Ef{{e[1], e[2], e[3], e[4]}};
+                have[lh] = true;
+            }
+        } else if (rb.get() != rounds.size()) {
+            return 1;  // one BatchOpening per commit round
+        }
         for (auto& round : rounds) {
             const uint32_t nm = rb.get();
             if (rb.bad || nm != round.mats.size()) return 1;

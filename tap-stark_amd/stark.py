@@ -364,6 +364,34 @@ class TwoAdicFriPcs:
         if verdict.value:
             raise VerificationError(verdict.value)
 
+    def fri_prove(self, inputs, challenger: "BfChallenger") -> np.ndarray:
+        """``bf_prove`` alone (fri/src/prover.rs:19-63) the way fri/tests/fri.rs:100-119 calls it:
+        ``inputs`` are (len, 4) EF4 vectors of strictly descending power-of-two lengths; the input
+        opening proof is the literal reduced openings.  Returns the FriProof words."""
+        ins = [_u32(v).reshape(-1, 4) for v in inputs]
+        logs = _u32([len(v).bit_length() - 1 for v in ins])
+        ptrs = (_lib.u32p * len(ins))(*[_p(v) for v in ins])
+        R = max(int(logs[0]) - self.fri.log_blowup, 0)
+        cap = 16 + 8 * R + self.fri.num_queries * (1 + 5 * len(ins) + sum(9 + 8 * (int(logs[0]) - 1 - i)
+                                                                           for i in range(R)))
+        out = np.zeros(cap, dtype=np.uint32)
+        n = C.c_size_t()
+        cfg = self.fri._c()
+        self.ctx.check(self.ctx._l.ts_fri_prove(self.ctx.h, C.byref(cfg), challenger.h, len(ins),
+                                                _p(logs), ptrs, _p(out), cap, C.byref(n)))
+        return out[: n.value].copy()
+
+    def fri_verify(self, proof, challenger: "BfChallenger") -> None:
+        """fri/src/verifier.rs:20-98 for a proof of :meth:`fri_prove` (host only)."""
+        proof = _u32(proof)
+        verdict = C.c_int(9)
+        cfg = self.fri._c()
+        rc = _lib.lib().ts_fri_verify(C.byref(cfg), challenger.h, _p(proof), len(proof), C.byref(verdict))
+        if rc:
+            raise _lib.TsError(rc, "ts_fri_verify")
+        if verdict.value:
+            raise VerificationError(verdict.value)
+
     def fold_matrix(self, vec, beta) -> np.ndarray:
         vec = _u32(vec)
         h = vec.shape[0] // 2

@@ -334,3 +334,47 @@ def test_cpp_air_capture_matches_python(lib, tmp_path):
     assert (tape == ts.air_tape(FibonacciAir(), 3)).all()
     assert out[1].split() == [str(ts.get_max_constraint_degree(FibonacciAir(), 3)),
                               str(ts.get_log_quotient_degree(FibonacciAir(), 3))]
+
+
+# ------------------------------------------------------------------ FRI alone (fri/tests/fri.rs)
+def _fri_rs_inputs(orc, log_blowup, deg_bits_range, seed=0):
+    """fri.rs:68-97: one random degree-2^k polynomial per k, LDE on the coset 31*H with bit-reversed
+    rows, alpha = 1 and one column per matrix => the reduced opening of a height IS its LDE column;
+    by descending height, embedded in EF4."""
+    from tapstark_amd.airs import splitmix64_stream
+    ins = []
+    for k in deg_bits_range:
+        ev = splitmix64_stream(seed + k, 1 << k).reshape(1 << k, 1)
+        lde = orc.commit_lde(ev, 1, log_blowup)[:, 0]
+        v = np.zeros((len(lde), 4), dtype=np.uint32)
+        v[:, 0] = lde
+        ins.append(v)
+    return ins[::-1]
+
+
+@pytest.mark.parametrize("perm,ext", [(1, False), (0, True)])
+def test_native_fri_verify_on_oracle_fri_proofs(lib, orc, perm, ext):
+    # test_compelte_fri_process (fri.rs:51-147): TestPermutation + BabyBear challenges as there, and
+    # the production challenger; prover = oracle here (the GPU prover is checked in the gpu suite)
+    cfg = (1, 10, 8)
+    ins = _fri_rs_inputs(orc, cfg[0], range(1, 10))
+    pch = orc.OracleChallenger(perm_kind=perm, sample_ext=ext)
+    proof = orc.fri_prove(orc.FriConfig(*cfg), ins, pch)
+    pcs = ts.TwoAdicFriPcs(ts.FriConfig(*cfg), host_only=True)
+    vch = ts.BfChallenger(perm, ext)
+    pcs.fri_verify(proof, vch)
+    # fri.rs:141-146 "prover and verifier transcript have same state after FRI"
+    assert vch.sample_bits(8) == pch.sample_bits(8)
+    rejected = 0
+    for pos in (len(proof) - 1, len(proof) - 2, 3, len(proof) // 2, len(proof) // 3):
+        bad = proof.copy()
+        bad[pos] = (int(bad[pos]) + 1) % 0x78000001
+        want = orc.fri_verify(orc.FriConfig(*cfg), bad, orc.OracleChallenger(perm_kind=perm, sample_ext=ext))
+        try:
+            pcs.fri_verify(bad, ts.BfChallenger(perm, ext))
+            got = 0
+        except ts.VerificationError as e:
+            got = e.code
+        assert got == want, (pos, got, want)
+        rejected = rejected + (want != 0)
+    assert rejected >= 3  # (a changed PoW witness can still be a witness under the test permutation)

@@ -477,3 +477,25 @@ def test_cpp_example_runs_the_reference_test_through_the_c_abi(ctx, orc, tmp_pat
             assert "public values [0, 1, 21]" in r.stdout  # fib_air.rs:143
         want = orc.prove(orc.FriConfig(2, 28, 8), ts.air_tape(FibonacciAir(), 3), trace, pis)
         assert len(words) == len(want) and (words == want).all()
+
+
+# ------------------------------------------------------------------ FRI alone (fri/tests/fri.rs)
+@pytest.mark.parametrize("perm,ext,cfg,degs", [
+    (1, False, (1, 10, 8), range(1, 10)),        # test_compelte_fri_process, fri.rs:51-147
+    (0, True, (1, 10, 8), range(1, 10)),
+    (0, True, (2, 7, 8), [3, 9, 14, 15]),        # beyond the one-workgroup tail; gaps between heights
+])
+def test_fri_prove_alone_matches_oracle(ctx, orc, perm, ext, cfg, degs):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_abi_cpu import _fri_rs_inputs
+    ins = _fri_rs_inputs(orc, cfg[0], degs)
+    pcs = ts.TwoAdicFriPcs(ts.FriConfig(*cfg), ctx)
+    pch = ts.BfChallenger(perm, ext)
+    proof = pcs.fri_prove(ins, pch)
+    och = orc.OracleChallenger(perm_kind=perm, sample_ext=ext)
+    want = orc.fri_prove(orc.FriConfig(*cfg), ins, och)
+    assert len(proof) == len(want) and (proof == want).all()
+    vch = ts.BfChallenger(perm, ext)
+    pcs.fri_verify(proof, vch)
+    assert pch.sample_bits(8) == vch.sample_bits(8) == och.sample_bits(8)  # fri.rs:141-146

@@ -184,7 +184,7 @@ def main():
     dev = 0 if os.environ.get("TS_BENCH_SHARE_GPU") else env.local_rank
     ctx = ts.Context(dev)  # raises without a GPU: there is no fallback path
 
-    air, trace, pis, desc, cfg, (n, w), make_trace = workload(args.workload, args.log_n, sharded)
+    air, trace, pis, desc, cfg, (n, w), make_trace = workload(args.workload, args.log_n, False)
     if callable(pis):
         pis = np.array([0, 1, pis(ctx)], dtype=np.uint32)
     config = ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(*cfg), ctx))
@@ -220,11 +220,19 @@ def main():
             dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29512", rank=0, world_size=1,
                                     device_id=torch.device("cuda", dev))
         comm = TorchComm(dev)
-        rows = np.ascontiguousarray(trace[env.rank * n // env.world:(env.rank + 1) * n // env.world])
-        mats = [ts.DeviceMatrix.upload(ctx, rows) for _ in range(total)]
+        # every rank generates the whole trace on its own device (ts_trace_*): nothing to exchange
+        # for the input; TS_BENCH_SLICED=1 hands out row slices instead (adds the trace all-gather)
+        sliced = bool(os.environ.get("TS_BENCH_SLICED"))
+        if sliced:
+            full = make_trace(ctx).download()
+            rows = np.ascontiguousarray(full[env.rank * n // env.world:(env.rank + 1) * n // env.world])
+            mats = [ts.DeviceMatrix.upload(ctx, rows) for _ in range(total)]
+        else:
+            mats = [make_trace(ctx) for _ in range(total)]
 
         def prove_one(i):
-            last["proof"] = ts.prove_sharded(config, cair, ts.BfChallenger(), mats[i], pis, comm)
+            last["proof"] = ts.prove_sharded(config, cair, ts.BfChallenger(), mats[i], pis, comm,
+                                             trace_replicated=not sliced)
     else:
         mats = [make_trace(lanes[i % S][0]) for i in range(total)]
 

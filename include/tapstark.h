@@ -223,10 +223,16 @@ typedef struct {
  * queries.  `trace_rows` holds natural rows [g n/G, (g+1) n/G) of the trace and is consumed.
  * Every rank must pass a challenger in the same state; every rank receives the whole proof, which
  * is bit-identical to ts_prove's on the whole trace.  FRI rounds stay sharded while a rank holds
- * >= 2^min_local_log values (0 = default 12). */
+ * >= 2^min_local_log values. */
+typedef struct {
+    uint32_t min_local_log;    /* 0 = default (12) */
+    uint32_t trace_replicated; /* 1: `trace_rows` is the WHOLE trace on every rank (e.g. made by
+                                  ts_trace_* on each device); the trace all-gather is skipped */
+} ts_shard_options;
 ts_status ts_prove_sharded(ts_ctx* ctx, const ts_fri_config* cfg, const ts_comm* comm,
                            const ts_air* air, ts_challenger* chal, ts_matrix* trace_rows,
-                           const uint32_t* public_values, uint32_t n_public, uint32_t min_local_log,
+                           const uint32_t* public_values, uint32_t n_public,
+                           const ts_shard_options* options /* NULL = defaults */,
                            uint32_t* proof_out, size_t cap_words, size_t* n_words_out);
 
 /* check_constraints (uni-stark/src/check_constraints.rs:11-39; what a debug build of prove() runs

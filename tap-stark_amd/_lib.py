@@ -53,6 +53,11 @@ class CommC(C.Structure):
                 ("all_gather", ALL_GATHER_FN), ("broadcast", BROADCAST_FN)]
 
 
+class ShardOptionsC(C.Structure):
+    """``ts_shard_options`` (include/tapstark.h)."""
+    _fields_ = [("min_local_log", C.c_uint32), ("trace_replicated", C.c_uint32)]
+
+
 _lib = None
 
 
@@ -136,8 +141,9 @@ def lib() -> C.CDLL:
         l.ts_prove.argtypes = [C.c_void_p, C.POINTER(FriConfigC), C.c_void_p, C.c_void_p, C.c_void_p,
                                u32p, C.c_uint32, u32p, C.c_size_t, C.POINTER(C.c_size_t)]
         l.ts_prove_sharded.argtypes = [C.c_void_p, C.POINTER(FriConfigC), C.POINTER(CommC), C.c_void_p,
-                                       C.c_void_p, C.c_void_p, u32p, C.c_uint32, C.c_uint32, u32p,
-                                       C.c_size_t, C.POINTER(C.c_size_t)]
+                                       C.c_void_p, C.c_void_p, u32p, C.c_uint32,
+                                       C.POINTER(ShardOptionsC), u32p, C.c_size_t,
+                                       C.POINTER(C.c_size_t)]
         u8p = C.POINTER(C.c_uint8)
         l.ts_proof_to_postcard.argtypes = [u32p, C.c_size_t, u8p, C.c_size_t, C.POINTER(C.c_size_t)]
         l.ts_proof_from_postcard.argtypes = [u8p, C.c_size_t, u32p, C.c_size_t, C.POINTER(C.c_size_t)]

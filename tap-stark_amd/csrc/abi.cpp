@@ -600,8 +600,9 @@ ts_status ts_prove(ts_ctx* ctx, const ts_fri_config* cfg, const ts_air* air, ts_
 
 ts_status ts_prove_sharded(ts_ctx* ctx, const ts_fri_config* cfg, const ts_comm* comm,
                            const ts_air* air, ts_challenger* chal, ts_matrix* trace_rows,
-                           const uint32_t* public_values, uint32_t n_public, uint32_t min_local_log,
-                           uint32_t* proof_out, size_t cap_words, size_t* n_words_out) {
+                           const uint32_t* public_values, uint32_t n_public,
+                           const ts_shard_options* options, uint32_t* proof_out, size_t cap_words,
+                           size_t* n_words_out) {
     if (!ctx || !comm || !air || !chal || !trace_rows || !proof_out || !n_words_out ||
         !comm->all_gather || !comm->broadcast)
         return TS_ERR_INVALID;
@@ -627,7 +628,8 @@ ts_status ts_prove_sharded(ts_ctx* ctx, const ts_fri_config* cfg, const ts_comm*
                 throw ts::Error(ts::TS_ERR_COMM, "broadcast callback failed");
         };
         ts::ShardOptions opt;
-        if (min_local_log) opt.min_local_log = min_local_log;
+        if (options && options->min_local_log) opt.min_local_log = options->min_local_log;
+        if (options) opt.trace_replicated = options->trace_replicated != 0;
         ts::StageTimer t(&ctx->ctx, "prove");
         std::vector<uint32_t> proof =
             ts::prove_sharded(pcs, c, air->prog, chal->c, std::move(trace_rows->m), pis, opt);

@@ -159,10 +159,14 @@ struct ShardOptions {
     // FRI rounds stay sharded while a rank's slab holds at least 2^min_local_log values; the
     // remaining rounds run replicated on the gathered vector
     unsigned min_local_log = 12;
+    // true: every rank already holds the WHOLE trace (e.g. generated on each device by
+    // ts_trace_*): the one bulk exchange, the all-gather of the trace rows, is skipped
+    bool trace_replicated = false;
 };
 // rank g owns the bit-reversed LDE rows [g N/G, (g+1) N/G) (whole cosets,
 // G <= 2^log_blowup) of every committed matrix and the matching Merkle sub-trees, FRI slabs and
-// queries.  `trace_rows`: natural rows [g n/G, (g+1) n/G) of the trace.  Every rank passes a
+// queries.  `trace_rows`: natural rows [g n/G, (g+1) n/G) of the trace (or the whole trace with
+// opt.trace_replicated).  Every rank passes a
 // challenger in the same state and gets the whole proof, bit-identical to prove()'s.
 std::vector<uint32_t> prove_sharded(TwoAdicFriPcs& pcs, const Comm& comm, const AirProgram& air,
                                     BfChallenger& challenger, DeviceMatrix trace_rows,

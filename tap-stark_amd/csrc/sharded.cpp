@@ -9,7 +9,8 @@
 //   - FRI folds adjacent rows (2i, 2i+1): local while a slab has >= 2 values,
 //   - a query index and all its shifted indices index >> k belong to one rank.
 // Exchange steps (collectives supplied by the host, RCCL over xGMI in production):
-//   1. all-gather of the trace row slices (n w 4 / G bytes per rank) -- the one bulk transfer,
+//   1. all-gather of the trace row slices (n w 4 / G bytes per rank) -- the one bulk transfer;
+//      skipped when every rank already holds the whole trace (ShardOptions::trace_replicated),
 //   2. broadcast of each quotient chunk from the rank that owns its coset (16 n bytes),
 //   3. all-gather of G sub-roots per tree (2 commits + one per sharded FRI round),
 //   4. all-gather of the FRI vector when the slabs get short (the rest runs replicated),
@@ -145,7 +146,7 @@ std::vector<uint32_t> prove_sharded(TwoAdicFriPcs& pcs, const Comm& comm, const 
     TS_REQUIRE(public_values.size() == air.n_public, TS_ERR_INVALID,
                "prove: wrong number of public values");
     const uint32_t w = air.width;
-    const uint64_t degree = trace_rows.height * G;  // prover.rs:43-44
+    const uint64_t degree = opt.trace_replicated ? trace_rows.height : trace_rows.height * G;  // prover.rs:43-44
     const unsigned log_degree = log2_strict(degree);
     const unsigned lqd = air.log_quotient_degree;
     const uint32_t qd = 1u << lqd;
@@ -162,7 +163,9 @@ std::vector<uint32_t> prove_sharded(TwoAdicFriPcs& pcs, const Comm& comm, const 
 
     // ---- exchange 1: every rank gets the whole trace (row slices in rank order = natural order)
     DeviceMatrix trace;
-    {
+    if (opt.trace_replicated) {
+        trace = std::move(trace_rows);
+    } else {
         StageTimer t(&ctx, "all-gather trace");
         trace.buf = DevBuf<uint32_t>(&ctx, (size_t)n * w);
         trace.height = n;

@@ -603,12 +603,13 @@ def prove(config: StarkConfig, air, challenger: BfChallenger, trace, public_valu
 
 
 def prove_sharded(config: StarkConfig, air, challenger: BfChallenger, trace_rows, public_values,
-                  comm, min_local_log: int = 0) -> Proof:
+                  comm, min_local_log: int = 0, trace_replicated: bool = False) -> Proof:
     """One proof over ``comm.world`` GPUs (``ts_prove_sharded``).
 
     Every rank calls this with its own context, a challenger in the same state and its row slice
     ``trace_rows`` = natural rows [g n/G, (g+1) n/G) of the trace; every rank gets the whole proof,
     bit-identical to :func:`prove` on the whole trace.  ``comm`` is a ``dist.TorchComm``.
+    ``trace_replicated``: ``trace_rows`` is the whole trace on every rank (no all-gather of it).
     """
     pcs = config.pcs
     ctx = pcs.ctx
@@ -618,7 +619,7 @@ def prove_sharded(config: StarkConfig, air, challenger: BfChallenger, trace_rows
     if not isinstance(trace_rows, DeviceMatrix):
         trace_rows = DeviceMatrix.upload(ctx, trace_rows)
     n_loc, w = trace_rows.dims()
-    n = n_loc * comm.world
+    n = n_loc if trace_replicated else n_loc * comm.world
     log_N = n.bit_length() - 1 + pcs.fri.log_blowup
     qd = 1 << air.log_quotient_degree
     R = log_N - pcs.fri.log_blowup
@@ -629,8 +630,9 @@ def prove_sharded(config: StarkConfig, air, challenger: BfChallenger, trace_rows
     n_words = C.c_size_t()
     cfg = pcs.fri._c()
     pis_p = _p(pis) if len(pis) else None
+    opts = _lib.ShardOptionsC(min_local_log, int(trace_replicated))
     rc = ctx._l.ts_prove_sharded(ctx.h, C.byref(cfg), C.byref(comm.c), air.h, challenger.h,
-                                 trace_rows.h, pis_p, len(pis), min_local_log, _p(out), cap,
+                                 trace_rows.h, pis_p, len(pis), C.byref(opts), _p(out), cap,
                                  C.byref(n_words))
     if rc == 7 and getattr(comm, "error", None):
         raise RuntimeError("communicator callback failed:\n" + comm.error)

@@ -46,11 +46,15 @@ def main():
     ctx = ts.default_context()
     air, trace, pis = make_case(spec["air"], spec["log_n"])
     n = trace.shape[0]
-    rows = np.ascontiguousarray(trace[rank * n // world:(rank + 1) * n // world])
+    if spec.get("replicated"):
+        rows = trace  # every rank holds the whole trace: no all-gather of it
+    else:
+        rows = np.ascontiguousarray(trace[rank * n // world:(rank + 1) * n // world])
     config = ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(*spec["cfg"]), ctx))
     comm = TorchComm(0)
     challenger = ts.BfChallenger()
-    proof = ts.prove_sharded(config, air, challenger, rows, pis, comm, spec["min_local_log"])
+    proof = ts.prove_sharded(config, air, challenger, rows, pis, comm, spec["min_local_log"],
+                             trace_replicated=bool(spec.get("replicated")))
     np.save(f"{spec['out']}.rank{rank}.npy", proof.words)
     with open(f"{spec['out']}.rank{rank}.json", "w") as f:
         json.dump({"calls": comm.calls, "chal_bits": challenger.sample_bits(20)}, f)

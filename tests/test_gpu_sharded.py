@@ -101,6 +101,20 @@ def test_sharded_proof_bit_identical(ctx, orc, tmp_path, air, log_n, cfg, world,
     assert metas[0]["calls"]["broadcast"] == 1 << ts.CompiledAir(ctx, tape).log_quotient_degree
 
 
+def test_sharded_with_replicated_trace(ctx, orc, tmp_path):
+    # every rank already holds the whole trace (device-generated in production): one collective
+    # fewer -- the bulk one -- and the same proof
+    spec = {"air": "mul64", "log_n": 10, "cfg": [2, 28, 8], "world": 4, "backend": "gloo",
+            "min_local_log": 4, "replicated": True}
+    want, want_bits, _ = single_gpu_proof(ctx, spec)
+    proofs, metas = run_ranks(tmp_path, spec)
+    sliced, sliced_metas = run_ranks(tmp_path, dict(spec, replicated=False))
+    for r in range(4):
+        assert (proofs[r] == want.words).all() and (sliced[r] == want.words).all()
+    assert metas[0]["calls"]["all_gather"] == sliced_metas[0]["calls"]["all_gather"] - 1
+    assert metas[0]["calls"]["bytes"] < sliced_metas[0]["calls"]["bytes"]
+
+
 def test_sharded_world_of_one_over_rccl(ctx, tmp_path):
     # nccl backend (RCCL): device buffers wrapped in place, collectives ordered on the HIP stream
     spec = {"air": "mul64", "log_n": 12, "cfg": [2, 28, 8], "world": 1, "backend": "nccl",

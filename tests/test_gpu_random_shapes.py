@@ -1,0 +1,68 @@
+"""Seeded sweep of prove() shapes against the oracle, bit for bit: odd widths (leaf rows that are
+not a multiple of a Blake3 block, free columns), every log_blowup / quotient-degree combination the
+AIRs allow, sizes on both sides of the one-kernel / three-kernel NTT split and of the FRI tail."""
+import numpy as np
+import pytest
+
+import tapstark_amd as ts
+from tapstark_amd.airs import (FibonacciAir, SynthExtAir, SynthMulAir, fibonacci_public_values,
+                               generate_fibonacci_trace, generate_synth_ext_trace,
+                               generate_synth_mul_trace)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from tapstark_amd.build import build
+
+    build()
+    return ts.default_context()
+
+
+def _cases():
+    rng = np.random.default_rng(20240607)
+    out = []
+    for i in range(28):
+        kind = ["mul", "fib", "ext"][int(rng.integers(0, 3))]
+        log_n = int(rng.integers(1, 14))
+        b = int(rng.integers(1, 4))
+        q = int(rng.integers(1, 12))
+        pow_bits = int(rng.choice([0, 4, 8]))
+        if kind == "mul":
+            w = int(rng.integers(3, 80))
+        elif kind == "ext":
+            w = int(rng.choice([13, 25, 37, 49]))
+        else:
+            w = 2
+        # quotient degree 2 (mul) needs log_blowup >= 1: always true here
+        out.append((f"{i}-{kind}{w}-2p{log_n}-b{b}-q{q}-p{pow_bits}", kind, w, log_n, (b, q, pow_bits), int(rng.integers(1, 1 << 30))))
+    return out
+
+
+CASES = _cases()
+
+
+@pytest.mark.parametrize("name,kind,w,log_n,cfg,seed", CASES, ids=[c[0] for c in CASES])
+def test_random_shape_bit_identical(ctx, orc, name, kind, w, log_n, cfg, seed):
+    n = 1 << log_n
+    if kind == "mul":
+        air, trace, pis = SynthMulAir(w), generate_synth_mul_trace(n, w, seed), np.zeros(0, dtype=np.uint32)
+    elif kind == "ext":
+        air, trace, pis = SynthExtAir(w), generate_synth_ext_trace(n, w, seed), np.zeros(0, dtype=np.uint32)
+    else:
+        trace = generate_fibonacci_trace(seed % 1000, (seed >> 10) % 1000, n)
+        air, pis = FibonacciAir(), fibonacci_public_values(trace)
+    tape = ts.air_tape(air, len(pis))
+    assert orc.check_constraints(tape, trace, pis) == -1
+    config = ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(*cfg), ctx))
+    ch = ts.BfChallenger()
+    proof = ts.prove(config, air, ch, trace, pis)
+    och = orc.OracleChallenger()
+    want = orc.prove(orc.FriConfig(*cfg), tape, trace, pis, och)
+    assert len(proof.words) == len(want)
+    assert (proof.words == want).all(), f"{int((proof.words != want).sum())} words differ"
+    assert ch.sample_bits(24) == och.sample_bits(24)
+    ts.verify(config, air, ts.BfChallenger(), proof, pis)
+    # and the wire format survives the trip
+    assert (ts.Proof.from_postcard(proof.to_postcard()).words == proof.words).all()

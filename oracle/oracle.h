@@ -185,6 +185,13 @@ int64_t ts_or_pcs_commit_open(const ts_or_fri_config* cfg, ts_or_challenger* cha
                               uint32_t* roots_out, uint32_t* zeta_out, uint32_t* opened_out,
                               uint32_t* proof_out, size_t cap_words);
 
+/* the same with 1 + k % 3 points zeta * 7^j for matrix k (counted over all rounds) */
+int64_t ts_or_pcs_commit_open_multi(const ts_or_fri_config* cfg, ts_or_challenger* chal, int n_rounds,
+                                    const int* mats_per_round, const unsigned* log_degrees,
+                                    const size_t* widths, const uint32_t* const* evals,
+                                    uint32_t* roots_out, uint32_t* zeta_out, uint32_t* opened_out,
+                                    uint32_t* proof_out, size_t cap_words);
+
 /* fri/tests/fri.rs:51-147: bf_prove over given EF4 vectors with pass-through input openings, and
  * the matching verifier; see stark.c */
 int64_t ts_or_fri_prove(const ts_or_fri_config* cfg, ts_or_challenger* chal, int n_inputs,

@@ -339,7 +339,7 @@ def fri_roundtrip(cfg: FriConfig, inputs, sample_ext: bool = True, perm_kind: in
 
 
 def pcs_commit_open(cfg: FriConfig, log_degrees_by_round, evals_by_round,
-                    chal: OracleChallenger | None = None):
+                    chal: OracleChallenger | None = None, multi: bool = False):
     """fri/tests/pcs.rs:62-90 flow on the oracle: returns (roots, zeta, opened (sum_w x 4), proof)."""
     flat_logs, flat_w, flat_e, per_round = [], [], [], []
     for logs, evs in zip(log_degrees_by_round, evals_by_round):
@@ -353,11 +353,13 @@ def pcs_commit_open(cfg: FriConfig, log_degrees_by_round, evals_by_round,
     chal = chal or OracleChallenger()
     roots = np.zeros((len(per_round), 8), dtype=np.uint32)
     zeta = np.zeros(4, dtype=np.uint32)
-    opened = np.zeros((sum(flat_w), 4), dtype=np.uint32)
+    opened = np.zeros((sum(w * (1 + i % 3 if multi else 1) for i, w in enumerate(flat_w)), 4),
+                      dtype=np.uint32)
     cap = 1 << 22
     proof = np.zeros(cap, dtype=np.uint32)
-    lib().ts_or_pcs_commit_open.restype = C.c_int64
-    n = lib().ts_or_pcs_commit_open(
+    fn = lib().ts_or_pcs_commit_open_multi if multi else lib().ts_or_pcs_commit_open
+    fn.restype = C.c_int64
+    n = fn(
         C.byref(cfg), C.byref(chal.c), len(per_round), (C.c_int * len(per_round))(*per_round),
         (C.c_uint * k)(*flat_logs), (C.c_size_t * k)(*flat_w), (u32p * k)(*[_p(e) for e in flat_e]),
         _p(roots), _p(zeta), _p(opened), _p(proof), C.c_size_t(cap))

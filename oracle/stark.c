@@ -919,11 +919,34 @@ int ts_or_fri_roundtrip(const ts_or_fri_config* cfg, int n_inputs, const unsigne
  * compared bit for bit: commit every round, observe the commitments, sample zeta, open every matrix
  * at zeta.  roots_out: n_rounds x 8 words; opened_out: sum(widths) x 4 words in (round, matrix,
  * column) order; proof_out: the FriProof part of the TSPF format.  Returns proof words or < 0. */
+static int64_t pcs_commit_open_impl(const ts_or_fri_config* cfg, ts_or_challenger* chal, int n_rounds,
+                                    const int* mats_per_round, const unsigned* log_degrees,
+                                    const size_t* widths, const uint32_t* const* evals, int multi,
+                                    uint32_t* roots_out, uint32_t* zeta_out, uint32_t* opened_out,
+                                    uint32_t* proof_out, size_t cap_words);
 int64_t ts_or_pcs_commit_open(const ts_or_fri_config* cfg, ts_or_challenger* chal, int n_rounds,
                               const int* mats_per_round, const unsigned* log_degrees,
                               const size_t* widths, const uint32_t* const* evals,
                               uint32_t* roots_out, uint32_t* zeta_out, uint32_t* opened_out,
                               uint32_t* proof_out, size_t cap_words) {
+    return pcs_commit_open_impl(cfg, chal, n_rounds, mats_per_round, log_degrees, widths, evals, 0,
+                                roots_out, zeta_out, opened_out, proof_out, cap_words);
+}
+/* the same with several points per matrix: matrix k (counted over all rounds) is opened at
+ * zeta * 7^j for j < 1 + k % 3 (two_adic_pcs.rs:344-387 loops over any list of points) */
+int64_t ts_or_pcs_commit_open_multi(const ts_or_fri_config* cfg, ts_or_challenger* chal, int n_rounds,
+                                    const int* mats_per_round, const unsigned* log_degrees,
+                                    const size_t* widths, const uint32_t* const* evals,
+                                    uint32_t* roots_out, uint32_t* zeta_out, uint32_t* opened_out,
+                                    uint32_t* proof_out, size_t cap_words) {
+    return pcs_commit_open_impl(cfg, chal, n_rounds, mats_per_round, log_degrees, widths, evals, 1,
+                                roots_out, zeta_out, opened_out, proof_out, cap_words);
+}
+static int64_t pcs_commit_open_impl(const ts_or_fri_config* cfg, ts_or_challenger* chal, int n_rounds,
+                                    const int* mats_per_round, const unsigned* log_degrees,
+                                    const size_t* widths, const uint32_t* const* evals, int multi,
+                                    uint32_t* roots_out, uint32_t* zeta_out, uint32_t* opened_out,
+                                    uint32_t* proof_out, size_t cap_words) {
     ts_or_mmcs_data* datas[16];
     int k = 0;
     for (int r = 0; r < n_rounds; r++) {
@@ -941,17 +964,19 @@ int64_t ts_or_pcs_commit_open(const ts_or_fri_config* cfg, ts_or_challenger* cha
     open_round rounds[16];
     int npts[16][16];
     const ef4* ppts[16][16];
+    ef4 zpow[3] = {zeta, ef4_mul_base(zeta, 7), ef4_mul_base(zeta, 49)};
     size_t total_w = 0;
+    int kk = 0;
     for (int r = 0; r < n_rounds; r++) {
-        for (int i = 0; i < mats_per_round[r]; i++) {
-            npts[r][i] = 1;
-            ppts[r][i] = &zeta;
+        for (int i = 0; i < mats_per_round[r]; i++, kk++) {
+            npts[r][i] = multi ? 1 + kk % 3 : 1;
+            ppts[r][i] = zpow;
         }
         rounds[r].data = datas[r];
         rounds[r].n_points = npts[r];
         rounds[r].points = ppts[r];
     }
-    for (int i = 0; i < k; i++) total_w += widths[i];
+    for (int i = 0; i < k; i++) total_w += widths[i] * (multi ? 1 + i % 3 : 1);
     ef4* opened = (ef4*)malloc((total_w + 1) * sizeof(ef4));
     size_t n_opened = 0;
     ts_or_wbuf b;

@@ -499,3 +499,48 @@ def test_fri_prove_alone_matches_oracle(ctx, orc, perm, ext, cfg, degs):
     vch = ts.BfChallenger(perm, ext)
     pcs.fri_verify(proof, vch)
     assert pch.sample_bits(8) == vch.sample_bits(8) == och.sample_bits(8)  # fri.rs:141-146
+
+
+MULTI_SHAPES = [[[5, 5, 5]], [[6, 3], [4, 4, 2]], [[3], [7, 7], [5]], [[11, 8, 11, 2]]]
+
+
+@pytest.mark.parametrize("shape", MULTI_SHAPES, ids=[str(s) for s in MULTI_SHAPES])
+def test_pcs_open_several_points_per_matrix(ctx, orc, shape):
+    # two_adic_pcs.rs:344-387 with 1, 2 or 3 points per matrix (matrix k: zeta * 7^j, j < 1 + k % 3),
+    # mixed heights and several rounds: opened values, FriProof and the verifier
+    cfg = (1, 4, 8)
+    pcs = ts.TwoAdicFriPcs(ts.FriConfig(*cfg), ctx)
+    seed, evals = 3000, []
+    for logs in shape:
+        evs = []
+        for lg in logs:
+            seed += 1
+            evs.append(rand_mat(seed, 1 << lg, 1 + seed % 5))
+        evals.append(evs)
+    oroots, ozeta, oopened, oproof = orc.pcs_commit_open(orc.FriConfig(*cfg), shape, evals, multi=True)
+    ch = ts.BfChallenger()
+    datas = [pcs.commit([((lg, 1), e.copy()) for lg, e in zip(logs, evs)])[1]
+             for logs, evs in zip(shape, evals)]
+    for d in datas:
+        ch.observe_commitment(d.root)
+    zeta = ch.sample()
+    assert (zeta == ozeta).all()
+
+    def points(k):
+        return [(zeta.astype(np.uint64) * pow(7, j, P) % P).astype(np.uint32) for j in range(1 + k % 3)]
+
+    rounds, k = [], 0
+    for d in datas:
+        pts = []
+        for _ in range(d.n_mats):
+            pts.append(points(k))
+            k += 1
+        rounds.append((d, pts))
+    vch = ch.clone()
+    opened, proof = pcs.open(rounds, ch)
+    flat = np.concatenate([p for r in opened for m in r for p in m])
+    assert (flat == oopened).all(), "opened values differ"
+    assert len(proof) == len(oproof) and (proof == oproof).all(), "FriProof differs"
+    claims = [(d.root, [(lg, list(zip(pts[m], opened[r][m]))) for m, lg in enumerate(logs)])
+              for r, ((d, pts), logs) in enumerate(zip(rounds, shape))]
+    pcs.verify(claims, proof, vch)

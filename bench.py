@@ -116,7 +116,7 @@ def algorithmic_bytes_per_proof(n: int, w: int, b: int, qd: int) -> dict:
     }
 
 
-def cpu_baseline(target_seconds: float = 25.0) -> dict:
+def cpu_baseline(target_seconds: float = 30.0) -> dict:
     """The oracle prover (oracle/, a C port of the reference's algorithm) on this box's host
     cores, on a bounded sample of the same workload."""
     import tapstark_amd as ts
@@ -132,14 +132,13 @@ def cpu_baseline(target_seconds: float = 25.0) -> dict:
     cfg = orc.FriConfig(2, 28, 8)
     orc.prove(cfg, tape, generate_synth_mul_trace(1 << 8), [])  # thread-pool warm-up
     # size the sample from a probe: the largest 2^k <= 2^20 rows expected to take <= target_seconds
-    # (cost grows a little faster than linearly, hence the 1.15 per doubling)
     probe = 16
     t0 = time.perf_counter()
     orc.prove(cfg, tape, generate_synth_mul_trace(1 << probe), [], cap_words=1 << 22)
     est = time.perf_counter() - t0
     log_n = probe
-    while log_n < 20 and est * 2 * 1.15 <= target_seconds:
-        est *= 2 * 1.15
+    while log_n < 20 and est * 2 <= target_seconds:
+        est *= 2
         log_n += 1
     trace = generate_synth_mul_trace(1 << log_n)
     t0 = time.perf_counter()

@@ -544,3 +544,33 @@ def test_pcs_open_several_points_per_matrix(ctx, orc, shape):
     claims = [(d.root, [(lg, list(zip(pts[m], opened[r][m]))) for m, lg in enumerate(logs)])
               for r, ((d, pts), logs) in enumerate(zip(rounds, shape))]
     pcs.verify(claims, proof, vch)
+
+
+# ------------------------------------------------------------------ edges of the shape space
+EDGE_CASES = [
+    ("mul64-n1", lambda: (SynthMulAir(64), generate_synth_mul_trace(1)), False, (2, 5, 8)),
+    ("fib-n1", lambda: (FibonacciAir(), generate_fibonacci_trace(0, 1, 1)), True, (2, 4, 8)),
+    ("mul3-n4-b1-nopow", lambda: (SynthMulAir(3), generate_synth_mul_trace(4, 3)), False, (1, 3, 0)),
+    ("mul64-q100", lambda: (SynthMulAir(64), generate_synth_mul_trace(1 << 10)), False, (2, 100, 8)),
+    ("mul64-b5", lambda: (SynthMulAir(64), generate_synth_mul_trace(1 << 8)), False, (5, 4, 8)),
+    ("mul200", lambda: (SynthMulAir(200), generate_synth_mul_trace(1 << 6, 200)), False, (2, 4, 8)),
+]
+
+
+@pytest.mark.parametrize("name,make,has_pis,cfg", EDGE_CASES, ids=[c[0] for c in EDGE_CASES])
+def test_edge_shapes_bit_identical(ctx, orc, name, make, has_pis, cfg):
+    # one-row traces, no proof of work, 100 queries, blowup 32, a 200-column row (13 Blake3 blocks)
+    air, trace = make()
+    pis = fibonacci_public_values(trace) if has_pis else np.zeros(0, dtype=np.uint32)
+    tape = ts.air_tape(air, len(pis))
+    config = ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(*cfg), ctx))
+    proof = ts.prove(config, air, ts.BfChallenger(), trace, pis)
+    want = orc.prove(orc.FriConfig(*cfg), tape, trace, pis)
+    assert len(proof.words) == len(want) and (proof.words == want).all()
+    ts.verify(config, air, ts.BfChallenger(), proof, pis)
+
+
+def test_zero_queries_refused(ctx):
+    with pytest.raises(ts._lib.TsError):
+        ts.prove(ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(2, 0, 8), ctx)), SynthMulAir(64),
+                 ts.BfChallenger(), generate_synth_mul_trace(4), [])

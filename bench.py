@@ -162,6 +162,9 @@ def main():
     ap.add_argument("--mode", default="replicas", choices=["replicas", "sharded"],
                     help="N > 1: independent proofs per GPU (default) or one proof over all GPUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-traces", action="store_true",
+                    help="hand every step its trace as a HOST buffer (ts_matrix_upload inside the "
+                         "timed region): the PCIe-inclusive rate, reported in DESIGN.md, never `value`")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("TS_BENCH_STREAMS", "4")),
                     help="independent proofs in flight per GPU (one context = one HIP stream and one "
                          "host thread each); the K timed steps are shared among them")
@@ -255,9 +258,16 @@ def main():
         pregen = total * n * w * 4 <= 100 << 30
         mats = [make_trace(lanes[i % S][0]) for i in range(total)] if pregen else None
 
+        if args.host_traces:
+            pregen, mats = False, None
+            host_trace = make_trace(ctx).download()
+
         def prove_one(i):
             c, conf, ca = lanes[i % S]
-            m = mats[i] if pregen else make_trace(c)
+            if args.host_traces:
+                m = ts.DeviceMatrix.upload(c, host_trace)
+            else:
+                m = mats[i] if pregen else make_trace(c)
             last["proof"] = ts.prove(conf, ca, ts.BfChallenger(), m, pis)
             if pregen:
                 mats[i] = None  # the matrix handle is spent
@@ -377,7 +387,9 @@ def main():
             "scaling": ("strong" if n_groups == 1 else "strong within a group, weak across groups")
                        if sharded else "weak", "vs_baseline": None,
             "dtype": "u32",  # BabyBear arithmetic on u32 lanes (64-bit intermediates)
-            "data": "synthetic (trace generated on the device, resident in HBM before the timed region)",
+            "data": ("synthetic (trace uploaded from host memory INSIDE the timed region: PCIe-inclusive)"
+                     if args.host_traces else
+                     "synthetic (trace generated on the device, resident in HBM before the timed region)"),
             "config": {"workload": desc, "rows": n, "width": w, "log_blowup": cfg[0],
                        "num_queries": cfg[1], "proof_of_work_bits": cfg[2], "quotient_degree": qd,
                        "parallelism": (f"{n_groups} group(s) of {gsize} GPU(s), one proof sharded over each group, "

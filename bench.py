@@ -81,7 +81,7 @@ def algorithmic_bytes_per_proof(n: int, w: int, b: int, qd: int) -> dict:
     fri_elems = 2 * N  # sum over rounds of the folded vector lengths (N + N/2 + ...)
     # Merkle parents (64 B read + 32 B written each): two N-leaf trees + FRI trees (N/2 + N/4 + ..);
     # levels with > 2^16 children go through k_merkle_level, the rest through the subtree kernel
-    parents_all = N + N + N // 2
+    parents_all = 3 * N  # N - 1 per N-leaf tree, and N/2 + N/4 + ... over the FRI trees
     # per-level launches take the levels with >= 2^16 parents (two parents per thread from 2^18 up)
     lvl2 = lvl1 = 0
     for leaves in [N, N] + [N >> r for r in range(1, 40) if (N >> r) > (1 << 16)]:

@@ -33,6 +33,52 @@ constexpr int padded(int n) { return n + (n >> 4); }
 // One round = K consecutive stages u0 .. u0+K-1 on register groups of 2^K elements spaced by the
 // distance 2^log_dl of the round's last stage.  LOG_DL >= 0 fixes that distance at compile time
 // (LDS addresses become base + immediate offsets); LOG_DL = -1 takes it from the arguments.
+// The K stages of one register group v[0 .. 2^K): global stages s_base + u0 .. + K - 1 on the group
+// whose block index at stage u0 is `hi` (chunk c).  Values stay in the lazy range [0, 2p).
+template <int K, bool INV, bool TOP>
+__device__ __forceinline__ void radix_butterflies(uint32_t (&v)[1 << K], unsigned s_base, unsigned u0,
+                                                  uint32_t c, uint32_t hi,
+                                                  const uint32_t* __restrict__ W) {
+    constexpr int R = 1 << K;
+    if (!INV) {
+#pragma unroll
+        for (int d = 0; d < K; d++) {
+            const int half = R >> (d + 1);
+            const uint32_t wb = (1u << (s_base + u0 + d)) + (c << (u0 + d)) + (hi << d);
+#pragma unroll
+            for (int q = 0; q < R; q++) {
+                if ((q & half) == 0) {
+                    // lazy range: inputs and outputs in [0, 2p) (2p < 2^32), 10 VALU
+                    // instructions instead of 11: a -> [0, p), t in [0, p), a + t and a - t + p
+                    const uint32_t a = red2p(v[q]);
+                    uint32_t t = v[q + half];
+                    if (TOP && (q >> (K - d)) == 0) t = red2p(t);
+                    else t = mont_mul(t, W[wb + (q >> (K - d))]);
+                    v[q] = a + t;
+                    v[q + half] = a - t + P;
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int d = K - 1; d >= 0; d--) {
+            const int half = R >> (d + 1);
+            const uint32_t wb = (1u << (s_base + u0 + d)) + (c << (u0 + d)) + (hi << d);
+#pragma unroll
+            for (int q = 0; q < R; q++) {
+                if ((q & half) == 0) {
+                    // lazy range [0, 2p) in and out: the product is left uncorrected
+                    const uint32_t a = red2p(v[q]), b = red2p(v[q + half]);
+                    v[q] = a + b;
+                    uint32_t dlt = a - b + P;
+                    if (!(TOP && (q >> (K - d)) == 0)) dlt = mont_mul_lazy(dlt, W[wb + (q >> (K - d))]);
+                    v[q + half] = dlt;
+                }
+            }
+        }
+    }
+}
+
 // TOP = true: the round starts at global stage 0 of a whole transform (s_base = u0 = c = 0, one group
 // block): block 0 of every stage has the twiddle w^0 = 1, i.e. butterflies with q < 2^(K-d) at local
 // stage d need no multiplication (all of stage 0, half of stage 1, ...: 47 % of a radix-16 round).
@@ -62,43 +108,7 @@ __device__ __forceinline__ void radix_round(uint32_t* s, unsigned log_total, uns
         uint32_t v[R];
 #pragma unroll
         for (int q = 0; q < R; q++) v[q] = s[addr[q]];
-        if (!INV) {
-#pragma unroll
-            for (int d = 0; d < K; d++) {
-                const int half = R >> (d + 1);
-                const uint32_t wb = (1u << (s_base + u0 + d)) + (c << (u0 + d)) + (hi << d);
-#pragma unroll
-                for (int q = 0; q < R; q++) {
-                    if ((q & half) == 0) {
-                        // lazy range: inputs and outputs in [0, 2p) (2p < 2^32), 10 VALU
-                        // instructions instead of 11: a -> [0, p), t in [0, p), a + t and a - t + p
-                        const uint32_t a = red2p(v[q]);
-                        uint32_t t = v[q + half];
-                        if (TOP && (q >> (K - d)) == 0) t = red2p(t);
-                        else t = mont_mul(t, W[wb + (q >> (K - d))]);
-                        v[q] = a + t;
-                        v[q + half] = a - t + P;
-                    }
-                }
-            }
-        } else {
-#pragma unroll
-            for (int d = K - 1; d >= 0; d--) {
-                const int half = R >> (d + 1);
-                const uint32_t wb = (1u << (s_base + u0 + d)) + (c << (u0 + d)) + (hi << d);
-#pragma unroll
-                for (int q = 0; q < R; q++) {
-                    if ((q & half) == 0) {
-                        // lazy range [0, 2p) in and out: the product is left uncorrected
-                        const uint32_t a = red2p(v[q]), b = red2p(v[q + half]);
-                        v[q] = a + b;
-                        uint32_t dlt = a - b + P;
-                        if (!(TOP && (q >> (K - d)) == 0)) dlt = mont_mul_lazy(dlt, W[wb + (q >> (K - d))]);
-                        v[q + half] = dlt;
-                    }
-                }
-            }
-        }
+        radix_butterflies<K, INV, TOP>(v, s_base, u0, c, hi, W);
 #pragma unroll
         for (int q = 0; q < R; q++) s[addr[q]] = v[q];
     }
@@ -244,7 +254,8 @@ k_lde_mid(const uint32_t* __restrict__ evals, uint64_t in_col_stride, uint32_t* 
     __syncthreads();
     if (PLAN == 1) {
         radix_round<4, true, 5, NTM>(s, 13, 4, 0, 0, Winv);
-        radix_round<4, true, 9, NTM, true>(s, 13, 0, 0, 0, Winv);
+        // the last inverse round (distance 2^9) works on elements tid + 512 q: exactly the share of
+        // the tile this thread keeps as coefficients, so it runs in registers (below)
     } else if (PLAN == 2) {
         radix_round<3, true, LOG_TILE - 10, NTM>(s, LOG_TILE, 7, 0, 0, Winv);
         radix_round<3, true, LOG_TILE - 7, NTM>(s, LOG_TILE, 4, 0, 0, Winv);
@@ -259,12 +270,29 @@ k_lde_mid(const uint32_t* __restrict__ evals, uint64_t in_col_stride, uint32_t* 
         const uint32_t i = threadIdx.x + (uint32_t)k * NTM;
         coef[k] = i < total ? s[pad(i)] : 0u;
     }
+    if constexpr (PLAN == 1) radix_butterflies<4, true, true>(coef, 0, 0, 0, 0, Winv);
     // cosets beta0 .. beta0 + n_cosets - 1 go to blocks 0 .. n_cosets - 1 of `out` (a rank of a
     // sharded prover owns a contiguous range of cosets)
     for (uint32_t bl = 0; bl < n_cosets; bl++) {
         const uint32_t beta = beta0 + bl;
         const uint32_t* sc = scale + ((uint64_t)beta << log_n);  // s_beta^k / n, one entry per coefficient
         __syncthreads();
+        if constexpr (PLAN == 1) {
+            // scaled coefficients and the first forward round (distance 2^9, the thread's own 16
+            // elements) stay in registers; LDS is written once, for the second round
+            uint32_t v[PER_THREAD];
+#pragma unroll
+            for (int k = 0; k < PER_THREAD; k++) {
+                const uint32_t i = threadIdx.x + (uint32_t)k * NTM;
+                const uint32_t kk = ((i >> 5) << LOG_M) + (i & 31) + j2_0;
+                v[k] = mont_mul(coef[k], sc[kk]);
+            }
+            radix_butterflies<4, false, true>(v, 0, 0, 0, 0, W);
+#pragma unroll
+            for (int k = 0; k < PER_THREAD; k++) s[pad(threadIdx.x + (uint32_t)k * NTM)] = v[k];
+            __syncthreads();
+            radix_round<4, false, 5, NTM>(s, 13, 4, 0, 0, W);
+        } else {
 #pragma unroll
         for (int k = 0; k < PER_THREAD; k++) {
             const uint32_t i = threadIdx.x + (uint32_t)k * NTM;
@@ -275,9 +303,8 @@ k_lde_mid(const uint32_t* __restrict__ evals, uint64_t in_col_stride, uint32_t* 
             }
         }
         __syncthreads();
+        }
         if (PLAN == 1) {
-            radix_round<4, false, 9, NTM, true>(s, 13, 0, 0, 0, W);
-            radix_round<4, false, 5, NTM>(s, 13, 4, 0, 0, W);
         } else if (PLAN == 2) {
             radix_round<4, false, LOG_TILE - 4, NTM, true>(s, LOG_TILE, 0, 0, 0, W);
             radix_round<3, false, LOG_TILE - 7, NTM>(s, LOG_TILE, 4, 0, 0, W);

@@ -259,7 +259,7 @@ k_lde_mid(const uint32_t* __restrict__ evals, uint64_t in_col_stride, uint32_t* 
     } else if (PLAN == 2) {
         radix_round<3, true, LOG_TILE - 10, NTM>(s, LOG_TILE, 7, 0, 0, Winv);
         radix_round<3, true, LOG_TILE - 7, NTM>(s, LOG_TILE, 4, 0, 0, Winv);
-        radix_round<4, true, LOG_TILE - 4, NTM, true>(s, LOG_TILE, 0, 0, 0, Winv);
+        // last inverse round: in registers, as in PLAN 1 (below)
     } else {
         tile_inverse_rt<NTM>(s, log_len, log_T, 0, 0, Winv);
     }
@@ -270,46 +270,62 @@ k_lde_mid(const uint32_t* __restrict__ evals, uint64_t in_col_stride, uint32_t* 
         const uint32_t i = threadIdx.x + (uint32_t)k * NTM;
         coef[k] = i < total ? s[pad(i)] : 0u;
     }
-    if constexpr (PLAN == 1) radix_butterflies<4, true, true>(coef, 0, 0, 0, 0, Winv);
+    // PLAN 1 / 2: the radix-16 round at the largest distance (TILE/16) has TILE/16 groups, GP =
+    // PER_THREAD/16 per thread, and group j of a thread is {tid + (j + GP q) NTM : q < 16}: its own
+    // coefficients coef[j + GP q].  That round therefore runs in registers on either side.
+    constexpr int GP = PER_THREAD / 16;
+    if constexpr (PLAN == 1 || PLAN == 2) {
+#pragma unroll
+        for (int j = 0; j < GP; j++) {
+            uint32_t v[16];
+#pragma unroll
+            for (int q = 0; q < 16; q++) v[q] = coef[j + GP * q];
+            radix_butterflies<4, true, true>(v, 0, 0, 0, 0, Winv);
+#pragma unroll
+            for (int q = 0; q < 16; q++) coef[j + GP * q] = v[q];
+        }
+    }
     // cosets beta0 .. beta0 + n_cosets - 1 go to blocks 0 .. n_cosets - 1 of `out` (a rank of a
     // sharded prover owns a contiguous range of cosets)
     for (uint32_t bl = 0; bl < n_cosets; bl++) {
         const uint32_t beta = beta0 + bl;
         const uint32_t* sc = scale + ((uint64_t)beta << log_n);  // s_beta^k / n, one entry per coefficient
         __syncthreads();
-        if constexpr (PLAN == 1) {
-            // scaled coefficients and the first forward round (distance 2^9, the thread's own 16
-            // elements) stay in registers; LDS is written once, for the second round
-            uint32_t v[PER_THREAD];
+        if constexpr (PLAN == 1 || PLAN == 2) {
+            // scaled coefficients and the first forward round (the thread's own elements) stay in
+            // registers; LDS is written once, for the following rounds
+            constexpr unsigned LT = PLAN == 1 ? 5 : LOG_TILE - 10;
+#pragma unroll
+            for (int j = 0; j < GP; j++) {
+                uint32_t v[16];
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    const uint32_t i = threadIdx.x + (uint32_t)(j + GP * q) * NTM;
+                    const uint32_t kk = ((i >> LT) << LOG_M) + (i & ((1u << LT) - 1)) + j2_0;
+                    v[q] = mont_mul(coef[j + GP * q], sc[kk]);
+                }
+                radix_butterflies<4, false, true>(v, 0, 0, 0, 0, W);
+#pragma unroll
+                for (int q = 0; q < 16; q++) s[pad(threadIdx.x + (uint32_t)(j + GP * q) * NTM)] = v[q];
+            }
+            __syncthreads();
+            if constexpr (PLAN == 1) {
+                radix_round<4, false, 5, NTM>(s, 13, 4, 0, 0, W);
+            } else {
+                radix_round<3, false, LOG_TILE - 7, NTM>(s, LOG_TILE, 4, 0, 0, W);
+                radix_round<3, false, LOG_TILE - 10, NTM>(s, LOG_TILE, 7, 0, 0, W);
+            }
+        } else {
 #pragma unroll
             for (int k = 0; k < PER_THREAD; k++) {
                 const uint32_t i = threadIdx.x + (uint32_t)k * NTM;
-                const uint32_t kk = ((i >> 5) << LOG_M) + (i & 31) + j2_0;
-                v[k] = mont_mul(coef[k], sc[kk]);
+                if (i < total) {
+                    // coefficient index of this slot
+                    const uint32_t kk = ((i >> log_T) << row_shift) + (i & tmask) + j2_0;
+                    s[pad(i)] = mont_mul(coef[k], sc[kk]);
+                }
             }
-            radix_butterflies<4, false, true>(v, 0, 0, 0, 0, W);
-#pragma unroll
-            for (int k = 0; k < PER_THREAD; k++) s[pad(threadIdx.x + (uint32_t)k * NTM)] = v[k];
             __syncthreads();
-            radix_round<4, false, 5, NTM>(s, 13, 4, 0, 0, W);
-        } else {
-#pragma unroll
-        for (int k = 0; k < PER_THREAD; k++) {
-            const uint32_t i = threadIdx.x + (uint32_t)k * NTM;
-            if (i < total) {
-                // coefficient index of this slot
-                const uint32_t kk = ((i >> log_T) << row_shift) + (i & tmask) + j2_0;
-                s[pad(i)] = mont_mul(coef[k], sc[kk]);
-            }
-        }
-        __syncthreads();
-        }
-        if (PLAN == 1) {
-        } else if (PLAN == 2) {
-            radix_round<4, false, LOG_TILE - 4, NTM, true>(s, LOG_TILE, 0, 0, 0, W);
-            radix_round<3, false, LOG_TILE - 7, NTM>(s, LOG_TILE, 4, 0, 0, W);
-            radix_round<3, false, LOG_TILE - 10, NTM>(s, LOG_TILE, 7, 0, 0, W);
-        } else {
             tile_forward_rt<NTM>(s, log_len, log_T, 0, 0, W);
         }
         uint32_t* o = out + (uint64_t)blockIdx.y * out_col_stride + ((uint64_t)bl << log_n) + j2_0;

@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, "lib", "libtapstark_hip.so")
+# TS_LIB_PATH points the binding at another build of the same library (same-box A/B of kernels)
+LIB_PATH = os.environ.get("TS_LIB_PATH") or os.path.join(PKG, "lib", "libtapstark_hip.so")
 
 u32p = C.POINTER(C.c_uint32)
 voidpp = C.POINTER(C.c_void_p)

@@ -115,6 +115,35 @@ __device__ __forceinline__ void radix_round(uint32_t* s, unsigned log_total, uns
     __syncthreads();
 }
 
+// Last forward round of a strided tile: groups read from the LDS, results written straight to the
+// tile's positions in HBM (element e of the tile lives at o[((e >> log_T) << row_shift) + (e & mask)]),
+// in canonical form.  A group's elements are 2^LOG_DL >= 2^log_T apart... and consecutive lanes hold
+// consecutive `lo`, so every store instruction writes whole 2^log_T-word row pieces, exactly like the
+// copy loop it replaces; no barrier is needed after it.
+template <int K, int LOG_DL, int NTH>
+__device__ __forceinline__ void radix_round_fwd_to_global(const uint32_t* s, unsigned log_total,
+                                                          unsigned u0, const uint32_t* __restrict__ W,
+                                                          uint32_t* __restrict__ o, unsigned log_T,
+                                                          unsigned row_shift) {
+    constexpr int R = 1 << K;
+    const uint32_t n_groups = 1u << (log_total - K);
+    const uint32_t tmask = (1u << log_T) - 1;
+    for (uint32_t g = threadIdx.x; g < n_groups; g += NTH) {
+        const uint32_t lo = g & ((1u << LOG_DL) - 1);
+        const uint32_t hi = g >> LOG_DL;
+        const uint32_t base = (hi << (K + LOG_DL)) + lo;
+        uint32_t v[R];
+#pragma unroll
+        for (int q = 0; q < R; q++) v[q] = s[pad(base + ((uint32_t)q << LOG_DL))];
+        radix_butterflies<K, false, false>(v, 0, u0, 0, hi, W);
+#pragma unroll
+        for (int q = 0; q < R; q++) {
+            const uint32_t e = base + ((uint32_t)q << LOG_DL);
+            o[((uint64_t)(e >> log_T) << row_shift) + (e & tmask)] = red2p(v[q]);
+        }
+    }
+}
+
 template <bool INV, int NTH>
 __device__ __forceinline__ void radix_round_rt(int k, uint32_t* s, unsigned log_total, unsigned u0,
                                                unsigned s_base, uint32_t c,
@@ -309,12 +338,19 @@ k_lde_mid(const uint32_t* __restrict__ evals, uint64_t in_col_stride, uint32_t* 
                 for (int q = 0; q < 16; q++) s[pad(threadIdx.x + (uint32_t)(j + GP * q) * NTM)] = v[q];
             }
             __syncthreads();
+            uint32_t* og = out + (uint64_t)blockIdx.y * out_col_stride + ((uint64_t)bl << log_n) + j2_0;
             if constexpr (PLAN == 1) {
+                // (writing this round's results straight to HBM, as PLAN 2 does below, costs 16 more
+                // VGPRs here -- 137, one workgroup per CU instead of two -- and measured 0.85 ms
+                // against 0.64; forced back to 128 VGPRs it spills)
                 radix_round<4, false, 5, NTM>(s, 13, 4, 0, 0, W);
+                for (uint32_t i = threadIdx.x; i < total; i += NTM)
+                    og[((uint64_t)(i >> 5) << LOG_M) + (i & 31)] = red2p(s[pad(i)]);
             } else {
                 radix_round<3, false, LOG_TILE - 7, NTM>(s, LOG_TILE, 4, 0, 0, W);
-                radix_round<3, false, LOG_TILE - 10, NTM>(s, LOG_TILE, 7, 0, 0, W);
+                radix_round_fwd_to_global<3, LOG_TILE - 10, NTM>(s, LOG_TILE, 7, W, og, LOG_TILE - 10, LOG_M);
             }
+            continue;  // stored; the barrier at the top of the loop protects the LDS image
         } else {
 #pragma unroll
             for (int k = 0; k < PER_THREAD; k++) {
@@ -350,10 +386,15 @@ void coset_lde(Context& ctx, uint32_t* evals, uint64_t in_col_stride, uint32_t n
     unsigned log_T = 0;
     // TS_LDE_TILE (0 = generic plan / 8192 / 16384 / 32768) picks the PLAN 2 tile: a tuning knob.
     // Measured on 2^22 x 64, log_blowup 4 (ms per launch): generic 19.1, 8192 15.7, 16384 13.8,
-    // 32768 30.3 (one workgroup per CU)
+    // 32768 30.3 (one workgroup per CU); with the register-resident outer rounds and the last round
+    // stored straight to HBM 16384 went 13.8 -> 11.7, and to 11.1 with 1024 threads (TS_LDE_THREADS)
     static const int plan2_tile = [] {
         const char* e = getenv("TS_LDE_TILE");
         return e ? atoi(e) : 16384;
+    }();
+    static const int plan2_threads = [] {
+        const char* e = getenv("TS_LDE_THREADS");
+        return e ? atoi(e) : 1024;  // 114 VGPRs, 16 waves per CU; 512 threads: 191 VGPRs, 8 waves
     }();
     const bool plan2 = two_pass && sA == 10 && plan2_tile != 0;
     if (two_pass) {
@@ -379,6 +420,8 @@ void coset_lde(Context& ctx, uint32_t* evals, uint64_t in_col_stride, uint32_t n
         beta0, n_beta, W, Winv, scale
         if (plan2 && plan2_tile == 8192)
             TS_LAUNCH(ctx, (k_lde_mid<2, 8192>), grid, dim3(NT_MID), 0, TS_MID_ARGS);
+        else if (plan2 && plan2_tile == 16384 && plan2_threads == 1024)
+            TS_LAUNCH(ctx, (k_lde_mid<2, 16384, 1024>), grid, dim3(1024), 0, TS_MID_ARGS);
         else if (plan2 && plan2_tile == 16384)
             TS_LAUNCH(ctx, (k_lde_mid<2, 16384>), grid, dim3(NT_MID), 0, TS_MID_ARGS);
         else if (plan2)

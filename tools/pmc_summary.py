@@ -38,6 +38,8 @@ def main():
     sys.path.insert(0, ".")
     from bench import algorithmic_bytes_per_proof
     alg = algorithmic_bytes_per_proof(1 << 20, 64, 2, 2)
+    if "k_merkle_level<2>" not in fetch:  # every per-level launch went through the <1> kernel
+        alg["k_merkle_level<1>"] += alg["k_merkle_level<2>"]
     kernels = {}
     for k in sorted(fetch, key=lambda k: -(fetch[k] + write.get(k, 0))):
         a = (alg.get(k) or alg.get(f"({k})") or (alg["k_lde_mid<1>"] if "k_lde_mid" in k else None)

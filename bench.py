@@ -182,8 +182,11 @@ def main():
     import tapstark_amd as ts
     from tapstark_amd.build import build
 
-    if not os.path.exists(ts._lib.LIB_PATH):
-        build()
+    if not os.path.exists(ts._lib.LIB_PATH):  # normally built by __graft_entry__.build() beforehand
+        if env.rank == 0:
+            build()
+        if env.dist is not None:
+            env.dist.barrier()
     # one GPU per rank (TS_BENCH_SHARE_GPU=1 lets a rehearsal put every rank on GPU 0)
     dev = 0 if os.environ.get("TS_BENCH_SHARE_GPU") else env.local_rank
     ctx = ts.Context(dev)  # raises without a GPU: there is no fallback path

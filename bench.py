@@ -99,8 +99,11 @@ def algorithmic_bytes_per_proof(n: int, w: int, b: int, qd: int) -> dict:
         "k_lde_mid<1>": 4 * n * wall + 4 * N * wall,
         "k_lde_mid<0>": 4 * n * wall + 4 * N * wall,
         "k_lde_fwd_contig": 8 * N * wall,
+        # the trace (one matrix, width a multiple of 16) takes the strided kernel, the batch of
+        # quotient chunks the pointer-table one; any other width sends both through the latter
+        "k_leaf_hash_strided": 4 * N * w + 32 * N,
         "k_leaf_hash<2>": 4 * N * wall + 2 * 32 * N,
-        "k_leaf_hash<1>": 4 * N * wall + 2 * 32 * N,
+        "k_leaf_hash<1>": (4 * N * 4 * qd + 32 * N) if w % 16 == 0 else (4 * N * wall + 2 * 32 * N),
         "k_leaf_hash_ef_pairs": 16 * N + 16 * N,
         "k_merkle_level<2>": 96 * lvl2,
         "k_merkle_level<1>": 96 * lvl1,

@@ -109,14 +109,16 @@ std::unique_ptr<PcsData> TwoAdicFriPcs::commit(std::vector<DeviceMatrix>& evals,
         data->tree = DevBuf<uint32_t>(&ctx_, merkle_total_digests(log_N) * 8);
         // column pointers grouped by height (tallest first), commit order inside a group
         std::vector<const uint32_t*> cols;
-        struct Group { uint64_t height; size_t first; uint32_t total; };
+        struct Group { uint64_t height; size_t first; uint32_t total; uint32_t n_mats; const ColMat* only; };
         std::vector<Group> groups;
         for (unsigned lh = log_N + 1; lh-- > 0;) {
-            Group g{1ull << lh, cols.size(), 0};
+            Group g{1ull << lh, cols.size(), 0, 0, nullptr};
             for (auto& cm : data->ldes)
                 if (cm.height == g.height) {
                     for (uint32_t c = 0; c < cm.width; c++) cols.push_back(cm.d + (uint64_t)c * cm.col_stride);
                     g.total += cm.width;
+                    g.n_mats++;
+                    g.only = &cm;
                 }
             if (g.total) groups.push_back(g);
         }
@@ -127,6 +129,12 @@ std::unique_ptr<PcsData> TwoAdicFriPcs::commit(std::vector<DeviceMatrix>& evals,
             memset(&lm, 0, sizeof lm);
             lm.cols = data->col_table.p + g.first;
             lm.total_width = g.total;
+            if (g.n_mats == 1) {  // lets the leaf kernel address the columns by stride
+                lm.n_mats = 1;
+                lm.d[0] = g.only->d;
+                lm.col_stride[0] = g.only->col_stride;
+                lm.width[0] = g.only->width;
+            }
             launch_leaf_hash(ctx_, lm, g.height, digests);
         };
         group_leaves(groups[0], data->tree.p);

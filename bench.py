@@ -405,6 +405,9 @@ def main():
                        "quotient_kernel": "hiprtc-specialised" if cair.is_jit else "interpreter",
                        "proof_words": int(len(proof.words))},
             "proofs_per_sec": res["steps_per_sec"],
+            # one proof alone on the GPU, HIP events around ts_prove (the `value` above keeps
+            # several in flight; this is the latency a single caller sees)
+            "single_proof_latency_ms": stage_sum.get("prove"),
             "roofline": roofline, "cpu_baseline": cpu,
             "stages_ms": stage_sum,
             "kernels": per_kernel,

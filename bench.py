@@ -136,9 +136,12 @@ def cpu_baseline(target_seconds: float = 30.0) -> dict:
     orc.prove(cfg, tape, generate_synth_mul_trace(1 << 8), [])  # thread-pool warm-up
     # size the sample from a probe: the largest 2^k <= 2^20 rows expected to take <= target_seconds
     probe = 16
-    t0 = time.perf_counter()
-    orc.prove(cfg, tape, generate_synth_mul_trace(1 << probe), [], cap_words=1 << 22)
-    est = time.perf_counter() - t0
+    probe_trace = generate_synth_mul_trace(1 << probe)
+    est = 1e9
+    for _ in range(2):  # the first call also pays first-touch costs; keep the faster one
+        t0 = time.perf_counter()
+        orc.prove(cfg, tape, probe_trace, [], cap_words=1 << 22)
+        est = min(est, time.perf_counter() - t0)
     log_n = probe
     while log_n < 20 and est * 2 <= target_seconds:
         est *= 2

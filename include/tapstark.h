@@ -78,9 +78,11 @@ ts_status ts_matrix_from_device(ts_ctx* ctx, const uint32_t* dev_row_major, uint
 /* Traces generated on the device (no H2D).  ts_trace_fibonacci = generate_trace_rows(a, b, n) of
  * uni-stark/tests/fib_air.rs:59-78 (n x 2: row 0 = (a, b), then (l, r) -> (r, l + r));
  * ts_trace_synth_mul = the build-defined SynthMulAir-`width` trace of BASELINE configs 3/4
- * (SplitMix64 stream `seed`, tap-stark_amd/airs.py generate_synth_mul_trace). */
+ * (SplitMix64 stream `seed`, tap-stark_amd/airs.py generate_synth_mul_trace);
+ * ts_trace_synth_ext = the SynthExt-`width` trace of config 5's stand-in (generate_synth_ext_trace). */
 ts_status ts_trace_fibonacci(ts_ctx* ctx, uint32_t a, uint32_t b, uint64_t n, ts_matrix** out);
 ts_status ts_trace_synth_mul(ts_ctx* ctx, uint64_t n, uint32_t width, uint64_t seed, ts_matrix** out);
+ts_status ts_trace_synth_ext(ts_ctx* ctx, uint64_t n, uint32_t width, uint64_t seed, ts_matrix** out);
 ts_status ts_matrix_dims(const ts_matrix* m, uint64_t* height, uint32_t* width);
 /* row-major, natural row order */
 ts_status ts_matrix_download(ts_ctx* ctx, const ts_matrix* m, uint32_t* host_row_major);
@@ -105,12 +107,20 @@ void ts_air_free(ts_ctx* ctx, ts_air* air);
 
 /* ------------------------------------------------------------------ PCS */
 /* Pcs::commit, fri/src/two_adic_pcs.rs:227-245: for each (domain, evals): coset LDE with shift
- * 31/domain.shift, bit-reversed rows, then mmcs.commit.  All matrices must have equal height
- * (mixed heights: SURVEY.md section 8(f) rank 4).  The matrices are consumed (like the moved
+ * 31/domain.shift, bit-reversed rows, then mmcs.commit.  The matrices may have different
+ * (power-of-two) heights: a shorter one's row digests are injected at the tree layer of its
+ * height and open_batch reduces the index (bf_mmcs.rs:10-15, tcs/mod.rs:339-378).  The matrices are consumed (like the moved
  * `RowMajorMatrix` arguments).  root_out = commitment. */
 ts_status ts_pcs_commit(ts_ctx* ctx, const ts_fri_config* cfg, uint32_t n_mats,
                         ts_matrix* const* evals, const uint32_t* domain_shifts,
                         uint32_t root_out[8], ts_pcs_data** out);
+/* BFMmcs::commit, basic/src/mmcs/bf_mmcs.rs:22-35 (reference impl taptree_mmcs.rs:101-114): commit
+ * to the given matrices as they are (no LDE, rows in the given order), any widths -- rows wider
+ * than 256 elements hash as multi-chunk Blake3 -- and power-of-two heights.  The result is a
+ * ts_pcs_data: ts_pcs_open_batch, ts_pcs_data_digests, ts_pcs_data_lde (= get_matrices) apply.
+ * The matrices are consumed. */
+ts_status ts_mmcs_commit(ts_ctx* ctx, uint32_t n_mats, ts_matrix* const* mats, uint32_t root_out[8],
+                         ts_pcs_data** out);
 /* BFMmcs::get_matrices (basic/src/mmcs/bf_mmcs.rs:52): committed LDE `idx`, row-major,
  * bit-reversed row order, N x width */
 ts_status ts_pcs_data_lde(ts_ctx* ctx, const ts_pcs_data* d, uint32_t idx, uint32_t* host_row_major);
@@ -215,7 +225,29 @@ typedef struct {
     int (*all_gather)(void* user, const void* send_dev, void* recv_dev, size_t bytes_per_rank,
                       void* hip_stream);
     int (*broadcast)(void* user, void* buf_dev, size_t bytes, int root, void* hip_stream);
+    /* optional (may be NULL): called on a rank whose ts_prove_sharded fails, so that its peers'
+     * pending collectives fail too instead of waiting for ever */
+    void (*abort)(void* user);
 } ts_comm;
+
+/* Native communicators (csrc/comm.cpp) for hosts without Python.
+ * RCCL over xGMI, one process or thread per GPU: rank 0 calls ts_rccl_unique_id and passes the 128
+ * bytes to its peers by any channel; every rank then calls ts_comm_rccl_create with its context
+ * (the communicator binds to the context's device; collectives are enqueued on the context's
+ * stream, no host synchronisation).  librccl is bound at run time; TS_ERR_UNSUPPORTED if absent. */
+typedef struct ts_rccl_comm ts_rccl_comm;
+int ts_rccl_available(void);
+ts_status ts_rccl_unique_id(uint8_t out[128]);
+ts_status ts_comm_rccl_create(ts_ctx* ctx, const uint8_t unique_id[128], int rank, int world,
+                              ts_comm* out, ts_rccl_comm** handle);
+void ts_comm_rccl_destroy(ts_rccl_comm* handle);
+/* In-process group: `world` ranks = `world` host threads of one process, each with its own
+ * context (same device or one device each: copies go device to device, peer to peer over xGMI).
+ * Every rank's thread takes its ts_comm with ts_comm_local_get. */
+typedef struct ts_comm_group ts_comm_group;
+ts_status ts_comm_local_group_create(int world, ts_comm_group** out);
+ts_status ts_comm_local_get(ts_comm_group* group, int rank, ts_comm* out);
+void ts_comm_local_group_destroy(ts_comm_group* group);
 
 /* prove() with the work of ONE proof split over comm->world ranks, one GPU each: rank g owns the
  * bit-reversed LDE rows [g N/G, (g+1) N/G) -- whole cosets, so world must be a power of two

@@ -20,13 +20,15 @@ ABI_SYMBOLS = [
     "ts_abi_version", "ts_ctx_create", "ts_ctx_destroy", "ts_last_error", "ts_ctx_synchronize",
     "ts_ctx_stream", "ts_ctx_set_timing", "ts_ctx_take_timings", "ts_ctx_set_kernel_timing",
     "ts_ctx_take_kernel_timings", "ts_matrix_upload",
-    "ts_matrix_from_device", "ts_trace_fibonacci", "ts_trace_synth_mul", "ts_matrix_dims", "ts_matrix_download", "ts_matrix_free",
-    "ts_air_compile", "ts_air_info", "ts_air_is_jit", "ts_air_free", "ts_pcs_commit", "ts_pcs_data_lde",
+    "ts_matrix_from_device", "ts_trace_fibonacci", "ts_trace_synth_mul", "ts_trace_synth_ext", "ts_matrix_dims", "ts_matrix_download", "ts_matrix_free",
+    "ts_air_compile", "ts_air_info", "ts_air_is_jit", "ts_air_free", "ts_pcs_commit", "ts_mmcs_commit", "ts_pcs_data_lde",
     "ts_pcs_data_info", "ts_pcs_data_matrix_info", "ts_pcs_data_digests", "ts_pcs_open_batch", "ts_pcs_data_free",
     "ts_quotient_chunks", "ts_pcs_open_reduce", "ts_pcs_open", "ts_pcs_verify", "ts_fri_prove", "ts_fri_verify", "ts_fri_fold", "ts_chal_new", "ts_chal_clone",
     "ts_chal_free", "ts_chal_observe", "ts_chal_observe_commitment", "ts_chal_sample",
     "ts_chal_sample_bits", "ts_chal_check_witness", "ts_chal_grind", "ts_chal_state", "ts_prove", "ts_prove_sharded", "ts_verify", "ts_check_constraints",
     "ts_proof_to_postcard", "ts_proof_from_postcard",
+    "ts_rccl_available", "ts_rccl_unique_id", "ts_comm_rccl_create", "ts_comm_rccl_destroy",
+    "ts_comm_local_group_create", "ts_comm_local_get", "ts_comm_local_group_destroy",
 ]
 
 STATUS = {0: "TS_OK", 1: "TS_ERR_INVALID", 2: "TS_ERR_HIP", 3: "TS_ERR_OOM",
@@ -46,12 +48,13 @@ class FriConfigC(C.Structure):
 
 ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
 BROADCAST_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
+ABORT_FN = C.CFUNCTYPE(None, C.c_void_p)
 
 
 class CommC(C.Structure):
     """``ts_comm`` (include/tapstark.h)."""
     _fields_ = [("rank", C.c_int), ("world", C.c_int), ("user", C.c_void_p),
-                ("all_gather", ALL_GATHER_FN), ("broadcast", BROADCAST_FN)]
+                ("all_gather", ALL_GATHER_FN), ("broadcast", BROADCAST_FN), ("abort", ABORT_FN)]
 
 
 class ShardOptionsC(C.Structure):
@@ -113,6 +116,7 @@ def lib() -> C.CDLL:
         l.ts_matrix_from_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, voidpp]
         l.ts_trace_fibonacci.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, voidpp]
         l.ts_trace_synth_mul.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, voidpp]
+        l.ts_trace_synth_ext.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, voidpp]
         l.ts_matrix_dims.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), u32p]
         l.ts_matrix_download.argtypes = [C.c_void_p, C.c_void_p, u32p]
         l.ts_air_compile.argtypes = [C.c_void_p, u32p, C.c_size_t, voidpp]
@@ -120,6 +124,7 @@ def lib() -> C.CDLL:
         l.ts_air_is_jit.argtypes = [C.c_void_p]
         l.ts_pcs_commit.argtypes = [C.c_void_p, C.POINTER(FriConfigC), C.c_uint32, voidpp, u32p,
                                     u32p, voidpp]
+        l.ts_mmcs_commit.argtypes = [C.c_void_p, C.c_uint32, voidpp, u32p, voidpp]
         l.ts_pcs_data_lde.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, u32p]
         l.ts_pcs_data_info.argtypes = [C.c_void_p, u32p, u32p]
         l.ts_pcs_data_digests.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, u32p]
@@ -146,6 +151,14 @@ def lib() -> C.CDLL:
                                        C.POINTER(ShardOptionsC), u32p, C.c_size_t,
                                        C.POINTER(C.c_size_t)]
         u8p = C.POINTER(C.c_uint8)
+        l.ts_rccl_unique_id.argtypes = [u8p]
+        l.ts_comm_rccl_create.argtypes = [C.c_void_p, u8p, C.c_int, C.c_int, C.POINTER(CommC), voidpp]
+        l.ts_comm_rccl_destroy.argtypes = [C.c_void_p]
+        l.ts_comm_rccl_destroy.restype = None
+        l.ts_comm_local_group_create.argtypes = [C.c_int, voidpp]
+        l.ts_comm_local_get.argtypes = [C.c_void_p, C.c_int, C.POINTER(CommC)]
+        l.ts_comm_local_group_destroy.argtypes = [C.c_void_p]
+        l.ts_comm_local_group_destroy.restype = None
         l.ts_proof_to_postcard.argtypes = [u32p, C.c_size_t, u8p, C.c_size_t, C.POINTER(C.c_size_t)]
         l.ts_proof_from_postcard.argtypes = [u8p, C.c_size_t, u32p, C.c_size_t, C.POINTER(C.c_size_t)]
         l.ts_check_constraints.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, u32p, C.c_uint32,

@@ -26,7 +26,9 @@ struct ts_air {
     ts::AirProgram prog;
     ts::DevBuf<uint32_t> code;
     std::string jit_log;
+    int device = -1;  // the device the jit module was loaded on (-1: host-only AIR)
     ~ts_air() {
+        if (device >= 0 && prog.jit_module) (void)hipSetDevice(device);
         ts::JitKernel jk;
         jk.module = prog.jit_module;
         jk.fn = prog.jit_fn;
@@ -149,7 +151,7 @@ ts_status ts_proof_from_postcard(const uint8_t* bytes, size_t n_bytes, uint32_t*
     });
 }
 
-uint32_t ts_abi_version(void) { return 1; }
+uint32_t ts_abi_version(void) { return 2; }  // 2: ts_comm.abort, native communicators, ts_mmcs_*, taptree
 
 ts_status ts_ctx_create(int device, ts_ctx** out) {
     if (!out) return TS_ERR_INVALID;
@@ -257,6 +259,10 @@ ts_status ts_trace_synth_mul(ts_ctx* ctx, uint64_t n, uint32_t width, uint64_t s
     return generated_matrix(ctx, n, width, out,
                             [&](uint32_t* p) { ts::launch_trace_synth_mul(ctx->ctx, p, n, width, seed); });
 }
+ts_status ts_trace_synth_ext(ts_ctx* ctx, uint64_t n, uint32_t width, uint64_t seed, ts_matrix** out) {
+    return generated_matrix(ctx, n, width, out,
+                            [&](uint32_t* p) { ts::launch_trace_synth_ext(ctx->ctx, p, n, width, seed); });
+}
 ts_status ts_matrix_dims(const ts_matrix* m, uint64_t* height, uint32_t* width) {
     if (!m) return TS_ERR_INVALID;
     if (height) *height = m->m.height;
@@ -306,6 +312,7 @@ ts_status ts_air_compile(ts_ctx* ctx, const uint32_t* tape, size_t n_words, ts_a
     }
     return guard(ctx, [&] {
         auto a = std::make_unique<ts_air>();
+        a->device = ctx->ctx.device;
         a->prog = ts::compile_air(tape, n_words);
         a->code = ts::DevBuf<uint32_t>(&ctx->ctx, std::max<size_t>(a->prog.code.size(), 4));
         if (!a->prog.code.empty())
@@ -352,7 +359,7 @@ ts_status ts_pcs_commit(ts_ctx* ctx, const ts_fri_config* cfg, uint32_t n_mats, 
     return guard(ctx, [&] {
         ts::TwoAdicFriPcs pcs(ctx->ctx, load_cfg(cfg));
         TS_REQUIRE(n_mats >= 1 && n_mats <= (uint32_t)ts::MAX_BATCH_MATS, ts::TS_ERR_INVALID,
-                   "commit: between 1 and 16 matrices");
+                   "commit: between 1 and 64 matrices");
         std::vector<ts::DeviceMatrix> ms;
         for (uint32_t i = 0; i < n_mats; i++) {
             TS_REQUIRE(evals[i] && evals[i]->m.buf.p, ts::TS_ERR_INVALID, "commit: null or consumed matrix");
@@ -361,6 +368,41 @@ ts_status ts_pcs_commit(ts_ctx* ctx, const ts_fri_config* cfg, uint32_t n_mats, 
         std::vector<uint32_t> shifts(domain_shifts, domain_shifts + n_mats);
         auto d = std::make_unique<ts_pcs_data>();
         d->d = pcs.commit(ms, shifts);
+        if (root_out) memcpy(root_out, d->d->root, 32);
+        *out = d.release();
+    });
+}
+ts_status ts_mmcs_commit(ts_ctx* ctx, uint32_t n_mats, ts_matrix* const* mats, uint32_t root_out[8],
+                         ts_pcs_data** out) {
+    if (!ctx || !out || !mats) return TS_ERR_INVALID;
+    *out = nullptr;
+    return guard(ctx, [&] {
+        TS_REQUIRE(n_mats >= 1 && n_mats <= (uint32_t)ts::MAX_BATCH_MATS, ts::TS_ERR_INVALID,
+                   "mmcs commit: between 1 and 64 matrices");
+        auto d = std::make_unique<ts_pcs_data>();
+        d->d = std::make_unique<ts::PcsData>();
+        uint64_t max_h = 0;
+        for (uint32_t i = 0; i < n_mats; i++) {
+            TS_REQUIRE(mats[i] && mats[i]->m.buf.p, ts::TS_ERR_INVALID, "mmcs commit: null or consumed matrix");
+            TS_REQUIRE(mats[i]->m.layout == ts::DeviceMatrix::ROW_MAJOR, ts::TS_ERR_INVALID,
+                       "mmcs commit: row-major (uploaded) matrices expected");
+            max_h = std::max(max_h, mats[i]->m.height);
+        }
+        d->d->log_height = ts::log2_strict(max_h);
+        for (uint32_t i = 0; i < n_mats; i++) {
+            ts::DeviceMatrix& m = mats[i]->m;
+            ts::DevBuf<uint32_t> cmaj(&ctx->ctx, (size_t)m.height * m.width);
+            ts::launch_transpose_plain(ctx->ctx, m.buf.p, cmaj.p, m.height, m.width, m.height);
+            ts::ColMat cm;
+            cm.d = cmaj.p;
+            cm.height = m.height;
+            cm.width = m.width;
+            cm.col_stride = m.height;
+            d->d->ldes.push_back(cm);
+            d->d->lde_storage.push_back(std::move(cmaj));
+            m.buf.reset();  // consumed, like the moved RowMajorMatrix arguments
+        }
+        ts::mmcs_commit(ctx->ctx, *d->d);
         if (root_out) memcpy(root_out, d->d->root, 32);
         *out = d.release();
     });
@@ -420,9 +462,8 @@ ts_status ts_quotient_chunks(ts_ctx* ctx, const ts_pcs_data* trace_data, uint32_
                              const uint32_t alpha[4], ts_matrix** chunks_out) {
     if (!ctx || !trace_data || !trace_data->d || !air || !alpha || !chunks_out) return TS_ERR_INVALID;
     return guard(ctx, [&] {
-        ts::FriConfig f;
-        f.log_blowup = log_blowup;
-        ts::TwoAdicFriPcs pcs(ctx->ctx, f);
+        ts_fri_config raw{log_blowup, 1, 0};
+        ts::TwoAdicFriPcs pcs(ctx->ctx, load_cfg(&raw));  // same [1, 8] bound as everywhere else
         std::vector<uint32_t> pis;
         if (n_public) {
             TS_REQUIRE(public_values, ts::TS_ERR_INVALID, "null public values");
@@ -555,18 +596,26 @@ ts_status ts_chal_clone(const ts_challenger* c, ts_challenger** out) {
     return *out ? TS_OK : TS_ERR_OOM;
 }
 void ts_chal_free(ts_challenger* c) { delete c; }
-void ts_chal_observe(ts_challenger* c, uint32_t word) { c->c.observe(word); }
-void ts_chal_observe_commitment(ts_challenger* c, const uint32_t d[8]) { c->c.observe_commitment(d); }
+// void/value returns leave no room for a status: a null handle (or out pointer) is a no-op
+void ts_chal_observe(ts_challenger* c, uint32_t word) {
+    if (c) c->c.observe(word);
+}
+void ts_chal_observe_commitment(ts_challenger* c, const uint32_t d[8]) {
+    if (c && d) c->c.observe_commitment(d);
+}
 void ts_chal_sample(ts_challenger* c, uint32_t out[4]) {
+    if (!c || !out) return;
     ts::Ef e = c->c.sample();
     memcpy(out, e.c, 16);
 }
-uint64_t ts_chal_sample_bits(ts_challenger* c, uint32_t bits) { return c->c.sample_bits(bits); }
+uint64_t ts_chal_sample_bits(ts_challenger* c, uint32_t bits) {
+    return c && bits <= 32 ? c->c.sample_bits(bits) : 0;
+}
 int ts_chal_check_witness(ts_challenger* c, uint32_t bits, uint32_t witness) {
-    return c->c.check_witness(bits, witness) ? 1 : 0;
+    return c && bits <= 32 && c->c.check_witness(bits, witness) ? 1 : 0;
 }
 ts_status ts_chal_grind(ts_challenger* c, uint32_t bits, uint32_t* witness) {
-    if (!c || !witness) return TS_ERR_INVALID;
+    if (!c || !witness || bits > 31) return TS_ERR_INVALID;
     try {
         *witness = c->c.grind(bits);
         return TS_OK;
@@ -574,7 +623,9 @@ ts_status ts_chal_grind(ts_challenger* c, uint32_t bits, uint32_t* witness) {
         return e.code;
     }
 }
-void ts_chal_state(const ts_challenger* c, uint32_t out[34]) { c->c.export_state(out); }
+void ts_chal_state(const ts_challenger* c, uint32_t out[34]) {
+    if (c && out) c->c.export_state(out);
+}
 
 // ------------------------------------------------------------------ prove
 ts_status ts_prove(ts_ctx* ctx, const ts_fri_config* cfg, const ts_air* air, ts_challenger* chal,
@@ -628,11 +679,20 @@ ts_status ts_prove_sharded(ts_ctx* ctx, const ts_fri_config* cfg, const ts_comm*
                 throw ts::Error(ts::TS_ERR_COMM, "broadcast callback failed");
         };
         ts::ShardOptions opt;
-        if (options && options->min_local_log) opt.min_local_log = options->min_local_log;
+        if (options && options->min_local_log) {
+            TS_REQUIRE(options->min_local_log <= 27, ts::TS_ERR_INVALID, "min_local_log > 27");
+            opt.min_local_log = options->min_local_log;
+        }
         if (options) opt.trace_replicated = options->trace_replicated != 0;
         ts::StageTimer t(&ctx->ctx, "prove");
-        std::vector<uint32_t> proof =
-            ts::prove_sharded(pcs, c, air->prog, chal->c, std::move(trace_rows->m), pis, opt);
+        std::vector<uint32_t> proof;
+        try {
+            proof = ts::prove_sharded(pcs, c, air->prog, chal->c, std::move(trace_rows->m), pis, opt);
+        } catch (...) {
+            // this rank is leaving the protocol: make the peers' pending collectives fail, not hang
+            if (cb.abort) cb.abort(cb.user);
+            throw;
+        }
         *n_words_out = proof.size();
         TS_REQUIRE(proof.size() <= cap_words, ts::TS_ERR_BUFFER, "proof buffer too small");
         memcpy(proof_out, proof.data(), proof.size() * 4);
@@ -651,6 +711,7 @@ ts_status ts_check_constraints(ts_ctx* ctx, const ts_air* air, const ts_matrix* 
                    "check_constraints: needs an uploaded (row-major, unconsumed) trace");
         TS_REQUIRE(trace->m.width == p.width, ts::TS_ERR_INVALID, "check_constraints: width != AIR width");
         TS_REQUIRE(n_public == p.n_public, ts::TS_ERR_INVALID, "check_constraints: public value count");
+        TS_REQUIRE(n_public == 0 || public_values, ts::TS_ERR_INVALID, "null public values");
         std::vector<uint32_t> consts(std::max<size_t>(p.const_canonical.size(), 1), 0);
         for (size_t k = 0; k < p.const_canonical.size(); k++) {
             uint32_t v = p.const_public_idx[k] != ~0u ? public_values[p.const_public_idx[k]]

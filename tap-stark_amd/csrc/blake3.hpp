@@ -4,8 +4,10 @@
 //           (one 64-byte block, CHUNK_START|CHUNK_END|ROOT);
 //       (2) the build-defined Merkle MMCS: leaf = Blake3(row bytes),
 //           node = Blake3(left || right).
-// Inputs up to one chunk (1024 bytes = 256 field elements per row) are supported on the device;
-// wider rows are refused by the host before any launch.
+// Rows up to one chunk (1024 bytes = 256 field elements) take the straight-line single-chunk path;
+// wider rows go through `hash_stream` below: chunk chaining (counter = chunk index) and the BLAKE3
+// parent tree (left subtree = the largest power of two of chunks), pinned by the official vectors
+// (tests/golden/blake3_official.json).
 #pragma once
 #include <stdint.h>
 #include "bb.hpp"
@@ -75,11 +77,12 @@ TS_HD uint32_t xor_rotr16(uint32_t x, uint32_t y) {
 // cv (8 words, updated in place) <- compress(cv, m[16], counter = 0, block_len, flags).
 // The 7 rounds use the spec's message permutation unrolled into fixed schedules, so `m` stays in
 // registers and is never moved.
-TS_HD void compress(uint32_t cv[8], const uint32_t m[16], uint32_t block_len, uint32_t flags) {
+TS_HD void compress_ctr(uint32_t cv[8], const uint32_t m[16], uint32_t counter, uint32_t block_len,
+                        uint32_t flags) {
     uint32_t s0 = cv[0], s1 = cv[1], s2 = cv[2], s3 = cv[3], s4 = cv[4], s5 = cv[5], s6 = cv[6],
              s7 = cv[7];
     uint32_t s8 = TS_B3_IV0, s9 = TS_B3_IV1, s10 = TS_B3_IV2, s11 = TS_B3_IV3;
-    uint32_t s12 = 0, s13 = 0, s14 = block_len, s15 = flags;
+    uint32_t s12 = counter, s13 = 0, s14 = block_len, s15 = flags;
     TS_B3_ROUND(m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7], m[8], m[9], m[10], m[11], m[12], m[13], m[14], m[15])
     TS_B3_ROUND(m[2], m[6], m[3], m[10], m[7], m[0], m[4], m[13], m[1], m[11], m[12], m[5], m[9], m[14], m[15], m[8])
     TS_B3_ROUND(m[3], m[4], m[10], m[12], m[13], m[2], m[7], m[14], m[6], m[5], m[9], m[0], m[11], m[15], m[8], m[1])
@@ -97,6 +100,11 @@ TS_HD void compress(uint32_t cv[8], const uint32_t m[16], uint32_t block_len, ui
     cv[7] = s7 ^ s15;
 }
 
+// counter = 0: every single-chunk input and every parent node
+TS_HD void compress(uint32_t cv[8], const uint32_t m[16], uint32_t block_len, uint32_t flags) {
+    compress_ctr(cv, m, 0u, block_len, flags);
+}
+
 TS_HD void iv(uint32_t cv[8]) {
     cv[0] = TS_B3_IV0; cv[1] = TS_B3_IV1; cv[2] = TS_B3_IV2; cv[3] = TS_B3_IV3;
     cv[4] = TS_B3_IV4; cv[5] = TS_B3_IV5; cv[6] = TS_B3_IV6; cv[7] = TS_B3_IV7;
@@ -106,6 +114,68 @@ TS_HD void iv(uint32_t cv[8]) {
 TS_HD void hash64(const uint32_t m[16], uint32_t out[8]) {
     iv(out);
     compress(out, m, 64, CHUNK_START | CHUNK_END | ROOT);
+}
+
+// parent node of the BLAKE3 tree: compress(IV, left cv || right cv, PARENT [| ROOT])
+TS_HD void parent_cv(const uint32_t l[8], const uint32_t r[8], bool root, uint32_t out[8]) {
+    uint32_t m[16];
+    for (int k = 0; k < 8; k++) {
+        m[k] = l[k];
+        m[8 + k] = r[k];
+    }
+    iv(out);
+    compress(out, m, 64, PARENT | (root ? ROOT : 0u));
+}
+
+constexpr int MAX_TREE_DEPTH = 22;  // 2^22 chunks = 2^30 words: more than any row
+
+// BLAKE3 (hash mode, 32-byte output) of `total_words` little-endian u32 words delivered by
+// load(i), any length: the incremental algorithm of the BLAKE3 paper (section 5.1.2) -- a stack of
+// subtree chaining values, merged whenever the number of finished chunks gains a factor of two.
+template <class Load>
+TS_HD void hash_stream(Load load, uint64_t total_words, uint32_t out[8]) {
+    const uint64_t n_chunks = total_words == 0 ? 1 : (total_words + 255) / 256;
+    uint32_t stack[MAX_TREE_DEPTH][8];
+    int depth = 0;
+    for (uint64_t chunk = 0; chunk < n_chunks; chunk++) {
+        const uint64_t w0 = chunk * 256;
+        const uint32_t cw = (uint32_t)(total_words - w0 < 256 ? total_words - w0 : 256);
+        const uint32_t n_blocks = cw == 0 ? 1 : (cw + 15) / 16;
+        const bool last_chunk = chunk + 1 == n_chunks;
+        uint32_t cv[8];
+        iv(cv);
+        for (uint32_t blk = 0; blk < n_blocks; blk++) {
+            uint32_t m[16];
+            const uint32_t words = cw - blk * 16 < 16 ? cw - blk * 16 : 16;
+            for (uint32_t j = 0; j < 16; j++) m[j] = j < words ? load(w0 + blk * 16 + j) : 0u;
+            const uint32_t flags = (blk == 0 ? CHUNK_START : 0u) |
+                                   (blk + 1 == n_blocks ? CHUNK_END : 0u) |
+                                   (blk + 1 == n_blocks && n_chunks == 1 ? ROOT : 0u);
+            compress_ctr(cv, m, (uint32_t)chunk, words * 4, flags);
+        }
+        if (!last_chunk) {
+            // push, then merge completed subtrees: one merge per trailing zero of the chunk count
+            uint64_t done = chunk + 1;
+            while ((done & 1) == 0) {
+                uint32_t p[8];
+                parent_cv(stack[depth - 1], cv, false, p);
+                for (int k = 0; k < 8; k++) cv[k] = p[k];
+                depth--;
+                done >>= 1;
+            }
+            for (int k = 0; k < 8; k++) stack[depth][k] = cv[k];
+            depth++;
+        } else {
+            // the last chunk closes every open subtree, top of the stack first; the last merge is the root
+            while (depth > 0) {
+                uint32_t p[8];
+                parent_cv(stack[depth - 1], cv, depth == 1, p);
+                for (int k = 0; k < 8; k++) cv[k] = p[k];
+                depth--;
+            }
+            for (int k = 0; k < 8; k++) out[k] = cv[k];
+        }
+    }
 }
 
 }  // namespace b3

@@ -83,6 +83,12 @@ struct PcsData {
     LeafMats leaf_mats() const;
 };
 
+unsigned log2_strict(uint64_t n);  // throws TS_ERR_INVALID unless n is a power of two
+
+// BFMmcs::commit (basic/src/mmcs/bf_mmcs.rs:22-35) over data.ldes, already resident column-major;
+// data.log_height = log2 of the tallest matrix.  Fills data.tree, data.col_table, data.root.
+void mmcs_commit(Context& ctx, PcsData& data);
+
 // ------------------------------------------------------------------ PCS (TwoAdicFriPcs)
 class TwoAdicFriPcs {
 public:

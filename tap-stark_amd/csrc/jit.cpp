@@ -30,11 +30,8 @@ struct Rtc {
     bool ok = false;
 };
 
-Rtc& rtc() {
-    static Rtc r;
-    static bool tried = false;
-    if (tried) return r;
-    tried = true;
+Rtc load_rtc() {
+    Rtc r;
     for (const char* name : {"libhiprtc.so", "/opt/rocm/lib/libhiprtc.so"}) {
         r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
         if (r.lib) break;
@@ -48,6 +45,11 @@ Rtc& rtc() {
     r.get_code = (decltype(r.get_code))dlsym(r.lib, "hiprtcGetCode");
     r.destroy = (decltype(r.destroy))dlsym(r.lib, "hiprtcDestroyProgram");
     r.ok = r.create && r.compile && r.log_size && r.get_log && r.code_size && r.get_code && r.destroy;
+    return r;
+}
+
+Rtc& rtc() {
+    static Rtc r = load_rtc();  // function-local static: initialised once, thread-safe
     return r;
 }
 

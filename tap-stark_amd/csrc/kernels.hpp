@@ -27,6 +27,9 @@ const uint32_t* coset_scale_table(Context& ctx, unsigned log_n, unsigned log_blo
 // src: row-major n x w (natural rows)  ->  dst: column-major, rows in bit-reversed order
 void launch_transpose_bitrev(Context& ctx, const uint32_t* src, uint32_t* dst, unsigned log_n,
                              uint32_t w, uint64_t dst_col_stride);
+// same without the bit reversal (rows stay where they are): BFMmcs::commit on given matrices
+void launch_transpose_plain(Context& ctx, const uint32_t* src, uint32_t* dst, uint64_t n, uint32_t w,
+                            uint64_t dst_col_stride);
 // dst row-major (h x w)  <-  src column-major; used by debug downloads and row gathers
 void launch_transpose_to_row_major(Context& ctx, const uint32_t* src, uint64_t col_stride,
                                    uint32_t* dst, uint64_t h, uint32_t w);
@@ -40,7 +43,7 @@ void coset_lde(Context& ctx, uint32_t* evals, uint64_t in_col_stride, uint32_t n
                uint32_t beta0 = 0, uint32_t n_beta = 0);
 
 // ---- merkle.hip ------------------------------------------------------------------------------
-constexpr int MAX_BATCH_MATS = 16;
+constexpr int MAX_BATCH_MATS = 64;
 struct LeafMats {
     const uint32_t* d[MAX_BATCH_MATS];
     uint64_t col_stride[MAX_BATCH_MATS];
@@ -190,5 +193,7 @@ void launch_gather_fri(Context& ctx, const FriGatherDesc* d_descs, uint32_t n_ro
 // build-defined SynthMulAir-w trace (airs.py generate_synth_mul_trace)
 void launch_trace_fibonacci(Context& ctx, uint32_t* out, uint32_t a, uint32_t b, uint64_t n);
 void launch_trace_synth_mul(Context& ctx, uint32_t* out, uint64_t n, uint32_t width, uint64_t seed);
+// build-defined SynthExt-w trace (airs.py generate_synth_ext_trace; config 5's stand-in)
+void launch_trace_synth_ext(Context& ctx, uint32_t* out, uint64_t n, uint32_t width, uint64_t seed);
 
 }  // namespace ts

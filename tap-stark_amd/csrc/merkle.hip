@@ -74,10 +74,31 @@ k_leaf_hash_strided(const uint32_t* __restrict__ base, uint64_t stride, uint32_t
     o[1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
 }
 
+// rows wider than one Blake3 chunk (256 elements): chunk chaining + parent tree per row
+// (b3::hash_stream); the subtree stack is indexed by a wave-uniform depth and lives in scratch.
+// Rare shape (bf_mmcs.rs:17-68 allows any width), kept simple: one thread per row.
+__global__ void __launch_bounds__(256)
+k_leaf_hash_wide(const uint32_t* const* __restrict__ cols, uint32_t total, uint64_t height,
+                 uint32_t* __restrict__ digests) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= height) return;
+    uint32_t cv[8];
+    b3::hash_stream([cols, r](uint64_t c) { return cols[c][r]; }, total, cv);
+    uint4* o = reinterpret_cast<uint4*>(digests + 8 * r);
+    o[0] = make_uint4(cv[0], cv[1], cv[2], cv[3]);
+    o[1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
+}
+
 void launch_leaf_hash(Context& ctx, const LeafMats& mats, uint64_t height, uint32_t* digests) {
-    TS_REQUIRE(mats.total_width <= 256, TS_ERR_UNSUPPORTED,
-               "leaf rows wider than 256 field elements (one Blake3 chunk) are not supported");
+    TS_REQUIRE(mats.total_width <= (1u << 20), TS_ERR_UNSUPPORTED,
+               "leaf rows wider than 2^20 field elements are not supported");
     TS_REQUIRE(mats.cols != nullptr, TS_ERR_INVALID, "leaf_hash: column pointer table missing");
+    if (mats.total_width > 256) {
+        TS_LAUNCH(ctx, k_leaf_hash_wide, dim3((unsigned)((height + 255) / 256)), dim3(256), 0, mats.cols,
+                  mats.total_width, height, digests);
+        TS_HIP(hipGetLastError());
+        return;
+    }
     static const int rows_per_thread = [] {
         const char* e = getenv("TS_LEAF_ROWS");
         return e ? atoi(e) : 1;

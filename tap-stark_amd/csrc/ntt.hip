@@ -164,6 +164,31 @@ void launch_transpose_bitrev(Context& ctx, const uint32_t* src, uint32_t* dst, u
     TS_HIP(hipGetLastError());
 }
 
+// src row-major [n][w]  ->  dst[c][r] = src[r][c], any n
+__global__ void k_transpose_plain(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst,
+                                  uint64_t n, uint32_t w, uint64_t dst_col_stride) {
+    __shared__ uint32_t tile[64][65];
+    const uint64_t r0 = (uint64_t)blockIdx.x * 64;
+    const uint32_t c0 = blockIdx.y * 64;
+    const uint32_t tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (uint32_t i = ty; i < 64; i += 4) {
+        const uint32_t c = c0 + tx;
+        if (c < w && r0 + i < n) tile[i][tx] = src[(r0 + i) * w + c];
+    }
+    __syncthreads();
+    for (uint32_t cc = ty; cc < 64; cc += 4) {
+        const uint32_t c = c0 + cc;
+        if (c < w && r0 + tx < n) dst[(uint64_t)c * dst_col_stride + r0 + tx] = tile[tx][cc];
+    }
+}
+
+void launch_transpose_plain(Context& ctx, const uint32_t* src, uint32_t* dst, uint64_t n, uint32_t w,
+                            uint64_t dst_col_stride) {
+    dim3 grid((unsigned)((n + 63) / 64), (w + 63) / 64);
+    TS_LAUNCH(ctx, k_transpose_plain, grid, dim3(256), 0, src, dst, n, w, dst_col_stride);
+    TS_HIP(hipGetLastError());
+}
+
 // dst row-major [h][w]  <-  src column-major
 __global__ void k_transpose_to_row_major(const uint32_t* __restrict__ src, uint64_t col_stride,
                                          uint32_t* __restrict__ dst, uint64_t h, uint32_t w) {

@@ -51,6 +51,69 @@ LeafMats PcsData::leaf_mats() const {
     return lm;
 }
 
+// ------------------------------------------------------------------ BFMmcs::commit
+// basic/src/mmcs/bf_mmcs.rs:22-35 on matrices already resident (column-major): builds the Blake3
+// Merkle tree over data.ldes (data.log_height = log2 of the tallest) and leaves the root in data.root.
+void mmcs_commit(Context& ctx, PcsData& data) {
+    const unsigned log_H = data.log_height;
+    const uint64_t N = 1ull << log_H;
+    bool uniform = true;
+    for (auto& cm : data.ldes) uniform = uniform && cm.height == N;
+    {
+        StageTimer t(&ctx, "merkle_commit");
+        data.tree = DevBuf<uint32_t>(&ctx, merkle_total_digests(log_H) * 8);
+        // column pointers grouped by height (tallest first), commit order inside a group
+        std::vector<const uint32_t*> cols;
+        struct Group { uint64_t height; size_t first; uint32_t total; uint32_t n_mats; const ColMat* only; };
+        std::vector<Group> groups;
+        for (unsigned lh = log_H + 1; lh-- > 0;) {
+            Group g{1ull << lh, cols.size(), 0, 0, nullptr};
+            for (auto& cm : data.ldes)
+                if (cm.height == g.height) {
+                    for (uint32_t c = 0; c < cm.width; c++) cols.push_back(cm.d + (uint64_t)c * cm.col_stride);
+                    g.total += cm.width;
+                    g.n_mats++;
+                    g.only = &cm;
+                }
+            if (g.total) groups.push_back(g);
+        }
+        data.col_table = DevBuf<const uint32_t*>(&ctx, cols.size());
+        h2d(ctx, data.col_table.p, cols.data(), cols.size() * sizeof(const uint32_t*));
+        auto group_leaves = [&](const Group& g, uint32_t* digests) {
+            LeafMats lm;
+            memset(&lm, 0, sizeof lm);
+            lm.cols = data.col_table.p + g.first;
+            lm.total_width = g.total;
+            if (g.n_mats == 1) {  // lets the leaf kernel address the columns by stride
+                lm.n_mats = 1;
+                lm.d[0] = g.only->d;
+                lm.col_stride[0] = g.only->col_stride;
+                lm.width[0] = g.only->width;
+            }
+            launch_leaf_hash(ctx, lm, g.height, digests);
+        };
+        group_leaves(groups[0], data.tree.p);
+        if (uniform) {
+            launch_merkle_levels(ctx, data.tree.p, log_H);
+        } else {
+            DevBuf<uint32_t> inj(&ctx, 8 * (N / 2));
+            size_t gi = 1;
+            for (unsigned l = 1; l <= log_H; l++) {
+                uint32_t* children = data.tree.p + 8 * merkle_level_offset(log_H, l - 1);
+                uint32_t* parents = data.tree.p + 8 * merkle_level_offset(log_H, l);
+                const uint64_t n_par = N >> l;
+                launch_merkle_one_level(ctx, children, parents, n_par);
+                if (gi < groups.size() && groups[gi].height == n_par) {
+                    group_leaves(groups[gi], inj.p);
+                    launch_merkle_inject(ctx, parents, inj.p, n_par);
+                    gi++;
+                }
+            }
+        }
+        d2h_sync(ctx, data.root, data.tree.p + 8 * (merkle_total_digests(log_H) - 1), 32);
+    }
+}
+
 // ------------------------------------------------------------------ commit
 // Matrices of different heights share one tree (basic/src/mmcs/bf_mmcs.rs:22-35 commits a mixed batch;
 // the tree itself is build-defined, see merkle.hip): leaves hash the rows of the tallest matrices,
@@ -58,15 +121,13 @@ LeafMats PcsData::leaf_mats() const {
 std::unique_ptr<PcsData> TwoAdicFriPcs::commit(std::vector<DeviceMatrix>& evals,
                                                const std::vector<uint32_t>& domain_shifts) {
     TS_REQUIRE(!evals.empty() && evals.size() <= (size_t)MAX_BATCH_MATS, TS_ERR_INVALID,
-               "commit: between 1 and 16 matrices per batch");
+               "commit: between 1 and MAX_BATCH_MATS (64) matrices per batch");
     TS_REQUIRE(evals.size() == domain_shifts.size(), TS_ERR_INVALID, "commit: one domain per matrix");
     uint64_t max_n = 0;
-    bool uniform = true;
     for (auto& m : evals) {
         TS_REQUIRE(m.width >= 1 && m.buf.p, TS_ERR_INVALID, "commit: empty matrix");
         log2_strict(m.height);
         max_n = std::max(max_n, m.height);
-        uniform = uniform && m.height == evals[0].height;
     }
     const unsigned log_N = log2_strict(max_n) + fri_.log_blowup;
     TS_REQUIRE(log_N <= 27, TS_ERR_INVALID, "commit: LDE larger than the two-adic subgroup");
@@ -104,59 +165,7 @@ std::unique_ptr<PcsData> TwoAdicFriPcs::commit(std::vector<DeviceMatrix>& evals,
             m.buf.reset();  // consumed
         }
     }
-    {
-        StageTimer t(&ctx_, "merkle_commit");
-        data->tree = DevBuf<uint32_t>(&ctx_, merkle_total_digests(log_N) * 8);
-        // column pointers grouped by height (tallest first), commit order inside a group
-        std::vector<const uint32_t*> cols;
-        struct Group { uint64_t height; size_t first; uint32_t total; uint32_t n_mats; const ColMat* only; };
-        std::vector<Group> groups;
-        for (unsigned lh = log_N + 1; lh-- > 0;) {
-            Group g{1ull << lh, cols.size(), 0, 0, nullptr};
-            for (auto& cm : data->ldes)
-                if (cm.height == g.height) {
-                    for (uint32_t c = 0; c < cm.width; c++) cols.push_back(cm.d + (uint64_t)c * cm.col_stride);
-                    g.total += cm.width;
-                    g.n_mats++;
-                    g.only = &cm;
-                }
-            if (g.total) groups.push_back(g);
-        }
-        data->col_table = DevBuf<const uint32_t*>(&ctx_, cols.size());
-        h2d(ctx_, data->col_table.p, cols.data(), cols.size() * sizeof(const uint32_t*));
-        auto group_leaves = [&](const Group& g, uint32_t* digests) {
-            LeafMats lm;
-            memset(&lm, 0, sizeof lm);
-            lm.cols = data->col_table.p + g.first;
-            lm.total_width = g.total;
-            if (g.n_mats == 1) {  // lets the leaf kernel address the columns by stride
-                lm.n_mats = 1;
-                lm.d[0] = g.only->d;
-                lm.col_stride[0] = g.only->col_stride;
-                lm.width[0] = g.only->width;
-            }
-            launch_leaf_hash(ctx_, lm, g.height, digests);
-        };
-        group_leaves(groups[0], data->tree.p);
-        if (uniform) {
-            launch_merkle_levels(ctx_, data->tree.p, log_N);
-        } else {
-            DevBuf<uint32_t> inj(&ctx_, 8 * (N / 2));
-            size_t gi = 1;
-            for (unsigned l = 1; l <= log_N; l++) {
-                uint32_t* children = data->tree.p + 8 * merkle_level_offset(log_N, l - 1);
-                uint32_t* parents = data->tree.p + 8 * merkle_level_offset(log_N, l);
-                const uint64_t n_par = N >> l;
-                launch_merkle_one_level(ctx_, children, parents, n_par);
-                if (gi < groups.size() && groups[gi].height == n_par) {
-                    group_leaves(groups[gi], inj.p);
-                    launch_merkle_inject(ctx_, parents, inj.p, n_par);
-                    gi++;
-                }
-            }
-        }
-        d2h_sync(ctx_, data->root, data->tree.p + 8 * (merkle_total_digests(log_N) - 1), 32);
-    }
+    mmcs_commit(ctx_, *data);
     return data;
 }
 

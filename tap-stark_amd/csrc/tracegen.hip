@@ -78,7 +78,57 @@ k_trace_synth_mul(uint32_t* __restrict__ out, uint64_t n, uint32_t width, uint32
     }
 }
 
+// SynthExt-w (airs.py generate_synth_ext_trace): every element
+// (row, c) is stream value row*width + c, except z = x*y in F[X]/(X^4 - 11) for each group of 12
+// columns (x, y, z) and the last column = 7 + row.  One thread per (row, group): it draws x and y,
+// multiplies, and writes the group's 12 columns; the columns after the last group are filled by
+// the threads with g == groups.
+__global__ void __launch_bounds__(256)
+k_trace_synth_ext(uint32_t* __restrict__ out, uint64_t n, uint32_t width, uint32_t groups, uint64_t seed) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * (groups + 1)) return;
+    const uint64_t row = t / (groups + 1);
+    const uint32_t g = (uint32_t)(t % (groups + 1));
+    uint32_t* o = out + row * width;
+    const uint64_t s0 = row * width;
+    if (g == groups) {
+        for (uint32_t c = 12 * groups; c + 1 < width; c++) o[c] = splitmix_mod_p(seed, s0 + c);
+        o[width - 1] = (uint32_t)((7 + row) % P);
+        return;
+    }
+    const uint32_t base = 12 * g;
+    uint32_t x[4], y[4];
+    for (int i = 0; i < 4; i++) {
+        x[i] = splitmix_mod_p(seed, s0 + base + i);
+        y[i] = splitmix_mod_p(seed, s0 + base + 4 + i);
+        o[base + i] = x[i];
+        o[base + 4 + i] = y[i];
+    }
+    const uint32_t w11 = to_mont(11u);
+    for (int k = 0; k < 4; k++) {
+        uint32_t acc = 0;
+        for (int i = 0; i < 4; i++)
+            for (int j = 0; j < 4; j++) {
+                if (((i + j) & 3) != k) continue;
+                uint32_t term = mont_mul(x[i], to_mont(y[j]));  // canonical product
+                if (i + j >= 4) term = mont_mul(term, w11);
+                acc = add(acc, term);
+            }
+        o[base + 8 + k] = acc;
+    }
+}
+
 }  // namespace
+
+void launch_trace_synth_ext(Context& ctx, uint32_t* out, uint64_t n, uint32_t width, uint64_t seed) {
+    TS_REQUIRE(width >= 1 && width <= 4096, TS_ERR_INVALID, "synth_ext trace: bad width");
+    const uint32_t groups = (width - 1) / 12;
+    const uint64_t total = n * (groups + 1);
+    TS_REQUIRE(total < (1ull << 40), TS_ERR_INVALID, "synth_ext trace: too large");
+    TS_LAUNCH(ctx, k_trace_synth_ext, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, out, n, width,
+              groups, seed);
+    TS_HIP(hipGetLastError());
+}
 
 void launch_trace_fibonacci(Context& ctx, uint32_t* out, uint32_t a, uint32_t b, uint64_t n) {
     const uint64_t threads = (n + FIB_BLOCK - 1) / FIB_BLOCK;

@@ -45,19 +45,8 @@ struct Reader {
 };
 
 void hash_words(const uint32_t* w, size_t n, uint32_t out[8]) {
-    // single-chunk Blake3 over n <= 256 words (the MMCS never hashes more: rows <= 256 elements)
-    uint32_t cv[8];
-    b3::iv(cv);
-    const size_t n_blocks = n == 0 ? 1 : (n + 15) / 16;
-    for (size_t blk = 0; blk < n_blocks; blk++) {
-        uint32_t m[16] = {0};
-        const size_t words = n - blk * 16 < 16 ? n - blk * 16 : 16;
-        for (size_t j = 0; j < words; j++) m[j] = w[blk * 16 + j];
-        const uint32_t flags = (blk == 0 ? b3::CHUNK_START : 0u) |
-                               (blk + 1 == n_blocks ? (b3::CHUNK_END | b3::ROOT) : 0u);
-        b3::compress(cv, m, (uint32_t)words * 4, flags);
-    }
-    memcpy(out, cv, 32);
+    // Blake3 over n words, any length (multi-chunk rows included)
+    b3::hash_stream([w](uint64_t i) { return w[i]; }, n, out);
 }
 void compress2(const uint32_t* l, const uint32_t* r, uint32_t out[8]) {
     uint32_t m[16];
@@ -77,7 +66,6 @@ bool mmcs_verify(const std::vector<uint64_t>& heights, const std::vector<uint32_
         max_h = std::max(max_h, heights[i]);
         total += widths[i];
     }
-    if (total > 256 * heights.size()) return false;
     unsigned log_max = 0;
     while ((1ull << log_max) < max_h) log_max++;
     if (path_len != log_max || (index >> log_max) != 0) return false;
@@ -89,7 +77,6 @@ bool mmcs_verify(const std::vector<uint64_t>& heights, const std::vector<uint32_
             off += widths[i];
         }
         if (buf.empty()) return false;
-        if (buf.size() > 256) return false;
         hash_words(buf.data(), buf.size(), out);
         return true;
     };
@@ -187,6 +174,9 @@ static int fri_verify_impl(const FriConfig& fri, BfChallenger& challenger,
     if (rb.bad) return 9;
     if (Q != fri.num_queries) return 2;  // :39-41 InvalidProofShape
     const unsigned log_max_height = R + fri.log_blowup;
+    // BabyBear's two-adicity is 27: a taller domain does not exist, and `have`/`ro` below,
+    // sample_bits and two_adic_generator all assume it (both paths; R comes from untrusted input).
+    if (log_max_height > 27) return pass_through ? 9 : 1;
     if (!pass_through && log_max_height != log_global_max_height) return 1;
     if (pass_through) log_global_max_height = log_max_height;
     // the PoW witness follows the queries in the buffer: locate it with a dry parse

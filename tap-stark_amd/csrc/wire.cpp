@@ -15,8 +15,9 @@
 // Two types are this build's own, because the reference's are taptree-specific:
 //   Commitment = Vec<[[u8; 4]; 8]> with ONE root (survey row M)  -> varint(1) + 32 bytes,
 //   MMCS proof = Vec<[u8; 32]>, the sibling path, leaf level first -> varint(len) + 32 len bytes
-// (the shape of upstream Plonky3's FieldMerkleTreeMmcs proof).  The grinding witness is a BabyBear
-// element (basic/src/challenger/mod.rs:95-105).
+// (the shape of upstream Plonky3's FieldMerkleTreeMmcs proof).  The grinding witness is NOT a field
+// element: `type Witness = PF` with PF = [u8; 4] (basic/src/challenger/mod.rs:91,
+// chan_field.rs:61), which postcard writes as 4 raw bytes, little-endian word, no range check.
 #include <string.h>
 
 #include <vector>
@@ -52,8 +53,15 @@ struct ByteWriter {
         }
         b.push_back((uint8_t)v);
     }
-    void felts(const uint32_t* p, size_t n) {  // n field elements, no length
-        for (size_t i = 0; i < n; i++) varint(p[i]);
+    bool bad = false;
+    void felts(const uint32_t* p, size_t n) {  // n canonical field elements, no length
+        for (size_t i = 0; i < n; i++) {
+            if (p[i] >= P) bad = true;
+            varint(p[i]);
+        }
+    }
+    void raw_u32(uint32_t v) {  // [u8; 4]
+        for (int k = 0; k < 4; k++) b.push_back((uint8_t)(v >> (8 * k)));
     }
     void digest(const uint32_t* d) {  // [[u8; 4]; 8]: the words' little-endian bytes
         for (int i = 0; i < 8; i++)
@@ -84,6 +92,17 @@ struct ByteReader {
         const uint64_t v = varint();
         if (v >= P) bad = true;  // a canonical BabyBear element
         return (uint32_t)v;
+    }
+    uint32_t raw_u32() {  // [u8; 4]
+        if (pos > len || len - pos < 4) { bad = true; return 0; }
+        uint32_t w = 0;
+        for (int k = 0; k < 4; k++) w |= (uint32_t)b[pos++] << (8 * k);
+        return w;
+    }
+    // a count of elements that take at least `min_bytes` each cannot exceed what is left
+    bool fits(uint64_t count, uint64_t min_bytes) {
+        if (bad || pos > len || count > (len - pos) / min_bytes) { bad = true; return false; }
+        return true;
     }
     void digest(std::vector<uint32_t>& out) {
         if (pos > len || len - pos < 32) { bad = true; return; }
@@ -181,9 +200,9 @@ bool tspf_to_postcard(const uint32_t* words, size_t n_words, std::vector<uint8_t
     const uint32_t pow = r.get();
     if (r.bad || r.pos != n_words) return false;
     w.felts(fp, 4);
-    w.varint(pow);
+    w.raw_u32(pow);
     w.varint(degree_bits);
-    return true;
+    return !w.bad;
 }
 
 // postcard -> TSPF v1.  Returns false on malformed input (truncated, non-canonical field element,
@@ -196,9 +215,10 @@ bool postcard_to_tspf(const uint8_t* bytes, size_t n_bytes, std::vector<uint32_t
     uint64_t width = 0;
     for (int k = 0; k < 2; k++) {
         const uint64_t wd = r.varint();
-        if (r.bad || wd > MAX_COUNT || (k == 1 && wd != width)) return false;
+        if (r.bad || wd > MAX_COUNT || (k == 1 && wd != width) || !r.fits(4 * wd, 1)) return false;
         width = wd;
-        for (uint64_t i = 0; i < 4 * wd; i++) body.push_back(r.felt());
+        for (uint64_t i = 0; i < 4 * wd && !r.bad; i++) body.push_back(r.felt());
+        if (r.bad) return false;
     }
     const uint64_t qd = r.varint();
     if (r.bad || qd > 64) return false;
@@ -211,7 +231,7 @@ bool postcard_to_tspf(const uint8_t* bytes, size_t n_bytes, std::vector<uint32_t
     body.push_back((uint32_t)R);
     for (uint64_t i = 0; i < R; i++) r.commitment(body);
     const uint64_t Q = r.varint();
-    if (r.bad || Q > MAX_COUNT) return false;
+    if (r.bad || Q > MAX_COUNT || !r.fits(Q, 1)) return false;
     body.push_back((uint32_t)Q);
     for (uint64_t q = 0; q < Q && !r.bad; q++) {
         const uint64_t n_batches = r.varint();
@@ -223,14 +243,16 @@ bool postcard_to_tspf(const uint8_t* bytes, size_t n_bytes, std::vector<uint32_t
             body.push_back((uint32_t)n_mats);
             for (uint64_t m = 0; m < n_mats; m++) {
                 const uint64_t mw = r.varint();
-                if (r.bad || mw > MAX_COUNT) return false;
+                if (r.bad || mw > MAX_COUNT || !r.fits(mw, 1)) return false;
                 body.push_back((uint32_t)mw);
-                for (uint64_t i = 0; i < mw; i++) body.push_back(r.felt());
+                for (uint64_t i = 0; i < mw && !r.bad; i++) body.push_back(r.felt());
+                if (r.bad) return false;
             }
             const uint64_t pl = r.varint();
             if (r.bad || pl > 64) return false;
             body.push_back((uint32_t)pl);
-            for (uint64_t l = 0; l < pl; l++) r.digest(body);
+            for (uint64_t l = 0; l < pl && !r.bad; l++) r.digest(body);
+            if (r.bad) return false;
         }
         if (r.varint() != R) return false;
         for (uint64_t i = 0; i < R; i++) {
@@ -239,11 +261,12 @@ bool postcard_to_tspf(const uint8_t* bytes, size_t n_bytes, std::vector<uint32_t
             const uint64_t pl = r.varint();
             if (r.bad || pl > 64) return false;
             body.push_back((uint32_t)pl);
-            for (uint64_t l = 0; l < pl; l++) r.digest(body);
+            for (uint64_t l = 0; l < pl && !r.bad; l++) r.digest(body);
+            if (r.bad) return false;
         }
     }
     for (int i = 0; i < 4; i++) body.push_back(r.felt());
-    const uint32_t pow = r.felt();
+    const uint32_t pow = r.raw_u32();
     body.push_back(pow);
     const uint64_t degree_bits = r.varint();
     if (r.bad || r.pos != n_bytes || degree_bits > 64) return false;

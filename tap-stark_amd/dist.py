@@ -47,7 +47,7 @@ class TorchComm:
         # keep the ctypes thunks alive as long as the struct
         self._ag = _lib.ALL_GATHER_FN(self._all_gather)
         self._bc = _lib.BROADCAST_FN(self._broadcast)
-        self.c = _lib.CommC(self.rank, self.world, None, self._ag, self._bc)
+        self.c = _lib.CommC(self.rank, self.world, None, self._ag, self._bc, _lib.ABORT_FN())
 
     # -- callbacks (called from inside ts_prove_sharded, on the calling thread) -------------------
     def _all_gather(self, _user, send, recv, nbytes, stream):

@@ -144,6 +144,15 @@ class DeviceMatrix:
                                             C.byref(h)))
         return cls(ctx, h)
 
+    @classmethod
+    def synth_ext(cls, ctx: Context, n: int, width: int = 163, seed: int | None = None) -> "DeviceMatrix":
+        """The SynthExt-``width`` trace of ``airs.generate_synth_ext_trace``, computed in HBM."""
+        from .airs import SPLITMIX_SEED
+        h = C.c_void_p()
+        ctx.check(ctx._l.ts_trace_synth_ext(ctx.h, n, width, SPLITMIX_SEED if seed is None else seed,
+                                            C.byref(h)))
+        return cls(ctx, h)
+
     def dims(self):
         hh, ww = C.c_uint64(), C.c_uint32()
         self.ctx.check(self.ctx._l.ts_matrix_dims(self.h, C.byref(hh), C.byref(ww)))
@@ -242,6 +251,29 @@ class PcsData:
                 self.ctx._l.ts_pcs_data_free(self.ctx.h, self.h)
         except Exception:
             pass
+
+
+class Blake3Mmcs:
+    """``BFMmcs`` (basic/src/mmcs/bf_mmcs.rs:17-68) with the build-defined Blake3 Merkle tree, on
+    the device: ``commit`` to matrices as given (no LDE), ``open_batch`` via the returned PcsData."""
+
+    def __init__(self, ctx: Context | None = None):
+        self.ctx = ctx or default_context()
+
+    def commit(self, inputs) -> tuple[np.ndarray, PcsData]:
+        ctx = self.ctx
+        mats = [m if isinstance(m, DeviceMatrix) else DeviceMatrix.upload(ctx, m) for m in inputs]
+        arr = (C.c_void_p * len(mats))(*[m.h for m in mats])
+        root = np.zeros(8, dtype=np.uint32)
+        h = C.c_void_p()
+        ctx.check(ctx._l.ts_mmcs_commit(ctx.h, len(mats), arr, _p(root), C.byref(h)))
+        return root, PcsData(ctx, h, root)
+
+    def commit_matrix(self, m):
+        return self.commit([m])
+
+    def open_batch(self, index: int, data: PcsData):
+        return data.open_batch(index)
 
 
 class TwoAdicFriPcs:

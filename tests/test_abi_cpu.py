@@ -29,7 +29,7 @@ def test_header_symbols_all_exported(lib):
     assert declared == set(_lib.ABI_SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.ts_abi_version() == 1
+    assert lib.ts_abi_version() == 2
 
 
 def test_no_cpu_fallback_without_device(lib):
@@ -209,7 +209,9 @@ def _postcard_reference_encoder(proof: "ts.Proof") -> bytes:
             varint(1); varint(2); felts(vals)
             path(pth)
     felts(proof.final_poly)
-    varint(proof.pow_witness)
+    # `type Witness = PF`, PF = [u8; 4] (basic/src/challenger/mod.rs:91, chan_field.rs:61): postcard
+    # writes a fixed-size byte array as its raw bytes -- no length, no varint, no field reduction
+    out.extend(int(proof.pow_witness).to_bytes(4, "little"))
     # Proof.degree_bits
     varint(proof.degree_bits)
     return bytes(out)
@@ -242,8 +244,26 @@ def test_postcard_wire_format_round_trip(lib, orc):
         nc[off:end + 1] = b"\xff\xff\xff\xff\x0f"
         with pytest.raises(_lib.TsError):
             ts.Proof.from_postcard(bytes(nc))
+        # the witness is [u8; 4], not a field element: the 4 bytes before the trailing degree_bits
+        # varint are its little-endian bytes, and any 32-bit value survives the round trip
+        assert data[-5:-1] == int(proof.pow_witness).to_bytes(4, "little") and data[-1] == proof.degree_bits
+        big = bytearray(data)
+        big[-5:-1] = b"\xff\xff\xff\xff"
+        assert ts.Proof.from_postcard(bytes(big)).pow_witness == 0xFFFFFFFF
+        assert ts.Proof.from_postcard(bytes(big)).to_postcard() == bytes(big)
     with pytest.raises(_lib.TsError):
         ts.Proof(words=words[:10]).to_postcard()
+    # a non-canonical opened value in the words is refused by the encoder too
+    w2 = words.copy()
+    w2[5 + 16] = 0x78000001
+    with pytest.raises(_lib.TsError):
+        ts.Proof(words=w2).to_postcard()
+    # a ten-byte input that announces 2^24-element rows is refused at once (no half-gigabyte of zeros)
+    import time
+    t0 = time.time()
+    with pytest.raises(_lib.TsError):
+        ts.Proof.from_postcard(b"\x01" + bytes(32) + b"\x01" + bytes(32) + b"\x80\x80\x80\x08" + b"\x00" * 6)
+    assert time.time() - t0 < 0.5
 
 
 # ------------------------------------------------------------------ Pcs::verify, any shape (host)
@@ -378,3 +398,47 @@ def test_native_fri_verify_on_oracle_fri_proofs(lib, orc, perm, ext):
         assert got == want, (pos, got, want)
         rejected = rejected + (want != 0)
     assert rejected >= 3  # (a changed PoW witness can still be a witness under the test permutation)
+
+
+@pytest.mark.parametrize("R", [26, 27, 31, 32, 0xFFFFFFFF])
+def test_native_fri_verify_refuses_oversized_round_count(lib, R):
+    # a caller-supplied proof may claim any round count: R + log_blowup > 27 (BabyBear's
+    # two-adicity) must be refused before the query loop indexes its per-height arrays or the
+    # challenger is asked for more than 27 bits (fri/src/verifier.rs:20-60 shape check)
+    cfg = (2, 1, 0)
+    pcs = ts.TwoAdicFriPcs(ts.FriConfig(*cfg), host_only=True)
+    R_eff = min(R, 40)
+    words = [R] + [0] * (8 * R_eff) + [1]  # Q = 1
+    words += [0]  # no reduced openings in the input proof
+    for r in range(R_eff):
+        words += [0] * 8 + [0]
+    words += [0, 0, 0, 0, 0]
+    with pytest.raises(ts.VerificationError):
+        pcs.fri_verify(np.array(words, dtype=np.uint32), ts.BfChallenger())
+
+
+def test_native_pcs_verify_rows_wider_than_one_blake3_chunk(lib, orc):
+    # bf_mmcs.rs:17-68 takes matrices of any width; a row of more than 256 elements is more than
+    # one Blake3 chunk (chunk chaining + parent nodes).  Prover = oracle, verifier = the product's
+    # host code (csrc/blake3.hpp hash_stream); the widths straddle 1, 2 and 3 chunks.
+    from tapstark_amd.airs import splitmix64_stream
+    cfg = (1, 2, 4)
+    shape = [[3, 2]]
+    evals = [[splitmix64_stream(91, 8 * 300).reshape(8, 300), splitmix64_stream(92, 4 * 520).reshape(4, 520)]]
+    roots, zeta, opened, proof = orc.pcs_commit_open(orc.FriConfig(*cfg), shape, evals)
+    pcs = ts.TwoAdicFriPcs(ts.FriConfig(*cfg), host_only=True)
+
+    def transcript():
+        ch = ts.BfChallenger()
+        ch.observe_commitment(roots[0])
+        assert (ch.sample() == zeta).all()
+        return ch
+
+    claims = [(roots[0], [(3, [(zeta, opened[:300])]), (2, [(zeta, opened[300:820])])])]
+    pcs.verify(claims, proof, transcript())
+    bad = proof.copy()
+    # a word inside the first opened row of the first query (R, commits, Q, n_batches, n_mats, width, row...)
+    pos = 1 + 8 * int(proof[0]) + 1 + 3 + 299
+    bad[pos] = (int(bad[pos]) + 1) % 0x78000001
+    with pytest.raises(ts.VerificationError):
+        pcs.verify(claims, bad, transcript())

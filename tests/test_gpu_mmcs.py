@@ -1,0 +1,80 @@
+"""GPU tests of the MMCS layer on its own (BFMmcs, basic/src/mmcs/bf_mmcs.rs:17-68): the device
+Blake3 leaf hash against the official BLAKE3 vectors, rows wider than one chunk, batches of more
+than 16 matrices, mixed heights -- every digest level against the oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import tapstark_amd as ts
+from tapstark_amd.airs import splitmix64_stream
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from tapstark_amd.build import build
+
+    build()
+    return ts.default_context()
+
+
+def rand_mat(seed, h, w):
+    return splitmix64_stream(seed, h * w).reshape(h, w)
+
+
+def test_device_leaf_hash_official_blake3_vectors(ctx):
+    # a one-matrix commit whose row IS the official test input (bytes i % 251, as little-endian
+    # words): the leaf digest must be the official digest.  Covers the strided single-chunk kernel
+    # (multiples of 64 B), the pointer-table kernel (partial last block) and the multi-chunk path
+    # (> 1024 B: chunk counters, parent nodes, ROOT on the last parent only).
+    vec = json.load(open(os.path.join(GOLDEN, "blake3_official.json")))
+    cases = {int(k): v for g in ("official_lengths", "word_lengths") for k, v in vec[g].items()
+             if int(k) % 4 == 0 and 0 < int(k) <= 16384}
+    assert {64, 1024, 1028, 2048, 2052, 4096, 8192, 16384} <= set(cases)
+    mmcs = ts.Blake3Mmcs(ctx)
+    for ln, hexd in sorted(cases.items()):
+        row = np.frombuffer(bytes(i % 251 for i in range(ln)), dtype="<u4")
+        m = np.tile(row, (4, 1))  # four identical rows: every leaf must agree
+        root, data = mmcs.commit([m])
+        leaves = data.digests(0)
+        for r in range(4):
+            assert leaves[r].astype("<u4").tobytes().hex() == hexd, f"len {ln} row {r}"
+
+
+@pytest.mark.parametrize("shape", [[(6, 300)], [(5, 257), (5, 3)], [(4, 1030), (3, 700), (4, 2)],
+                                   [(9, 513)], [(3, 4100)]], ids=str)
+def test_commit_rows_wider_than_one_chunk(ctx, orc, shape):
+    mats = [rand_mat(700 + i, 1 << lh, w) for i, (lh, w) in enumerate(shape)]
+    mmcs = ts.Blake3Mmcs(ctx)
+    root, data = mmcs.commit([m.copy() for m in mats])
+    om = orc.OracleMmcs(mats)
+    for lvl in range(data.log_height + 1):
+        assert (data.digests(lvl) == om.layer(lvl)).all(), f"level {lvl}"
+    assert (root == om.root).all()
+    for idx in {0, (1 << data.log_height) - 1, 5 % (1 << data.log_height)}:
+        rows, path = data.open_batch(idx)
+        orows, opath = om.open(idx)
+        assert (rows == orows).all() and (path == opath).all()
+        assert om.verify(idx, rows, path, root)
+
+
+def test_commit_more_than_16_matrices(ctx, orc):
+    # taptree_mmcs.rs:101-114 takes any Vec of matrices; 40 here, three different heights
+    mats = [rand_mat(900 + i, 1 << (6 - i % 3), 1 + i % 5) for i in range(40)]
+    mmcs = ts.Blake3Mmcs(ctx)
+    root, data = mmcs.commit([m.copy() for m in mats])
+    om = orc.OracleMmcs(mats)
+    assert (root == om.root).all()
+    for idx in (0, 63, 37):
+        rows, path = data.open_batch(idx)
+        orows, opath = om.open(idx)
+        assert (rows == orows).all() and (path == opath).all()
+    # the same batch through Pcs::commit (with the LDE in front)
+    pcs = ts.TwoAdicFriPcs(ts.FriConfig(1, 2, 0), ctx)
+    root2, data2 = pcs.commit([((6 - i % 3, 1), m.copy()) for i, m in enumerate(mats)])
+    ldes = [orc.commit_lde(m, 1, 1) for m in mats]
+    assert (root2 == orc.OracleMmcs(ldes).root).all()

@@ -158,6 +158,10 @@ PROOF_CASES = [
     ("mul64_2p13_b4", lambda: (SynthMulAir(64), generate_synth_mul_trace(1 << 13)), False, (4, 16, 8)),
     ("mul7_2p6_b3", lambda: (SynthMulAir(7), generate_synth_mul_trace(1 << 6, 7)), False, (3, 7, 4)),
     ("ext163_2p8", lambda: (SynthExtAir(163), generate_synth_ext_trace(1 << 8, 163)), False, (2, 16, 8)),
+    # BASELINE config 5's FRI parameters (log_blowup 4, 16 queries; README.md:91,101) at sizes the
+    # oracle prover finishes in seconds
+    ("ext163_2p8_b4", lambda: (SynthExtAir(163), generate_synth_ext_trace(1 << 8, 163)), False, (4, 16, 8)),
+    ("ext163_2p11_b4", lambda: (SynthExtAir(163), generate_synth_ext_trace(1 << 11, 163)), False, (4, 16, 8)),
 ]
 
 
@@ -317,6 +321,41 @@ def test_config5_shape(ctx, orc):
     bad = proof.words.copy()
     bad[40] = (int(bad[40]) + 1) % P
     assert orc.verify(orc.FriConfig(*cfg), tape, bad, []) != 0
+
+
+def test_config5_baseline_shape(ctx, orc):
+    """BASELINE config 5 at its full shape: SynthExt-163, 2^20 x 163, log_blowup 4, 16 queries
+    (shape from README.md:91,101; the AIR is this build's stand-in).  The trace is
+    generated on the device (683 MB never crosses PCIe); the LDE is 10.9 GB.  Accept + determinism +
+    tamper rejection, as for configs 2 and 3."""
+    air = SynthExtAir(163)
+    tape = ts.air_tape(air, 0)
+    cfg = (4, 16, 8)
+    config = ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(*cfg), ctx))
+    cair = ts.CompiledAir(ctx, tape)
+    n = 1 << 20
+    t = ts.DeviceMatrix.synth_ext(ctx, n, 163)
+    assert ts.check_constraints(cair, t, [], ctx) == -1
+    p1 = ts.prove(config, cair, ts.BfChallenger(), t, [])
+    ocfg = orc.FriConfig(*cfg)
+    assert orc.verify(ocfg, tape, p1.words, []) == 0
+    ts.verify(config, air, ts.BfChallenger(), p1, [])
+    p2 = ts.prove(config, cair, ts.BfChallenger(), ts.DeviceMatrix.synth_ext(ctx, n, 163), [])
+    assert (p1.words == p2.words).all(), "proving is not deterministic"
+    for pos in (30, len(p1.words) // 2, len(p1.words) - 3):
+        bad = p1.words.copy()
+        bad[pos] = (int(bad[pos]) + 1) % P
+        assert orc.verify(ocfg, tape, bad, []) != 0
+    assert p1.degree_bits == 20 and len(p1.commit_phase_commits) == 20
+    assert len(p1.query_proofs) == 16 and len(p1.trace_local) == 163
+
+
+@pytest.mark.parametrize("log_n,w", [(0, 13), (4, 25), (9, 163), (12, 163), (7, 37)])
+def test_trace_synth_ext_on_device(ctx, log_n, w):
+    n = 1 << log_n
+    got = ts.DeviceMatrix.synth_ext(ctx, n, w).download()
+    want = generate_synth_ext_trace(n, w)
+    assert (got == want).all()
 
 
 # ------------------------------------------------------------------ general PCS (fri/tests/pcs.rs)

@@ -152,3 +152,124 @@ def test_sharded_rejects_partial_cosets(ctx, tmp_path):
     )
     p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=240)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+
+
+# ------------------------------------------------------------------ native communicators (csrc/comm.cpp)
+def run_local_ranks(spec):
+    """G ranks = G threads of THIS process, each with its own context on the one GPU, talking
+    through the library's in-process communicator (ts_comm_local_*): no torch, no subprocesses, so
+    eight ranks fit a box that allows six processes on its card."""
+    import threading
+
+    from tapstark_amd.comm import LocalCommGroup
+
+    G = spec["world"]
+    air, trace, pis = make_case(spec["air"], spec["log_n"])
+    n = trace.shape[0]
+    group = LocalCommGroup(G)
+    proofs, bits, errors = [None] * G, [None] * G, [None] * G
+
+    def rank_main(r):
+        try:
+            ctx = ts.Context(0)
+            config = ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(*spec["cfg"]), ctx))
+            rows = trace if spec.get("replicated") else np.ascontiguousarray(trace[r * n // G:(r + 1) * n // G])
+            ch = ts.BfChallenger()
+            p = ts.prove_sharded(config, air, ch, rows, pis, group.comm(r), spec["min_local_log"],
+                                 trace_replicated=bool(spec.get("replicated")))
+            proofs[r], bits[r] = p.words, ch.sample_bits(20)
+        except BaseException as e:  # noqa: BLE001
+            errors[r] = e
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(G)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert not any(t.is_alive() for t in threads), "a rank is stuck in a collective"
+    return proofs, bits, errors
+
+
+LOCAL_CASES = [
+    # air, log_n, (log_blowup, queries, pow), world, min_local_log, replicated
+    ("mul64", 10, (3, 16, 8), 8, 4, False),    # one coset per rank
+    ("mul64", 12, (4, 16, 8), 8, 6, False),    # config 4's split: 16 cosets, two per rank, row-sliced trace
+    ("mul64", 13, (4, 16, 8), 8, 12, True),    # the same with a replicated trace and the two-pass NTT (n > 4096)
+    ("ext25", 9, (4, 5, 8), 8, 2, False),
+    ("fib", 11, (3, 9, 8), 8, 1, False),
+    ("mul64", 11, (2, 28, 8), 4, 4, False),    # the headline config's FRI parameters over 4 ranks
+]
+
+
+@pytest.mark.parametrize("air,log_n,cfg,world,mll,repl", LOCAL_CASES,
+                         ids=[f"{c[0]}-2p{c[1]}-b{c[2][0]}-G{c[3]}-m{c[4]}{'-repl' if c[5] else ''}"
+                              for c in LOCAL_CASES])
+def test_sharded_eight_ranks_native_comm(ctx, orc, air, log_n, cfg, world, mll, repl):
+    spec = {"air": air, "log_n": log_n, "cfg": list(cfg), "world": world, "min_local_log": mll,
+            "replicated": repl}
+    want, want_bits, (air_obj, pis) = single_gpu_proof(ctx, spec)
+    proofs, bits, errors = run_local_ranks(spec)
+    for r in range(world):
+        assert errors[r] is None, f"rank {r}: {errors[r]!r}"
+        assert len(proofs[r]) == len(want.words), f"rank {r}: proof length"
+        assert (proofs[r] == want.words).all(), f"rank {r}: {int((proofs[r] != want.words).sum())} words differ"
+        assert bits[r] == want_bits
+    tape = ts.air_tape(air_obj, len(pis))
+    assert orc.verify(orc.FriConfig(*cfg), tape, proofs[0], pis) == 0
+
+
+def test_sharded_failure_on_one_rank_does_not_hang_the_others(ctx):
+    # ADVICE r1: a rank that throws between collectives must not leave its peers waiting.  Rank 2
+    # is handed a trace slice of the wrong width: it fails its argument checks and aborts the
+    # communicator; every other rank returns TS_ERR_COMM instead of blocking in the all-gather.
+    import threading
+
+    from tapstark_amd._lib import TsError
+    from tapstark_amd.comm import LocalCommGroup
+
+    G = 4
+    air, trace, pis = make_case("mul7", 8)
+    n = trace.shape[0]
+    group = LocalCommGroup(G)
+    errors = [None] * G
+
+    def rank_main(r):
+        try:
+            c = ts.Context(0)
+            config = ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(2, 4, 8), c))
+            rows = np.ascontiguousarray(trace[r * n // G:(r + 1) * n // G])
+            if r == 2:
+                rows = np.ascontiguousarray(rows[:, :5])
+            ts.prove_sharded(config, ts.CompiledAir(c, ts.air_tape(air, 0)), ts.BfChallenger(), rows, pis,
+                             group.comm(r), 2)
+        except BaseException as e:  # noqa: BLE001
+            errors[r] = e
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(G)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in threads), "a rank is stuck in a collective"
+    assert all(isinstance(e, TsError) for e in errors), errors
+    assert errors[2].code == 1 and {errors[r].code for r in (0, 1, 3)} == {7}
+
+
+def test_rccl_native_comm_world_of_one(ctx, orc):
+    # the C++ RCCL communicator (ncclAllGather / ncclBroadcast on the context's stream) with a
+    # world of one: the only size a one-GPU box can run; G > 1 over xGMI is unverified (DESIGN.md)
+    from tapstark_amd import comm as tc
+
+    if not tc.rccl_available():
+        pytest.skip("librccl not loadable")
+    spec = {"air": "mul64", "log_n": 12, "cfg": [2, 28, 8], "world": 1, "min_local_log": 6}
+    want, want_bits, _ = single_gpu_proof(ctx, spec)
+    air, trace, pis = make_case("mul64", 12)
+    c = ts.Context(0)
+    rc = tc.RcclComm(c, tc.rccl_unique_id(), 0, 1)
+    config = ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(2, 28, 8), c))
+    ch = ts.BfChallenger()
+    p = ts.prove_sharded(config, air, ch, trace, pis, rc, 6)
+    assert (p.words == want.words).all()
+    assert ch.sample_bits(20) == want_bits
+    rc.close()

@@ -28,6 +28,22 @@ def test_blake3_reference_kats(orc):
         assert orc.blake3(data).hex() == k["digest"], k["source"]
 
 
+def _pattern(n):
+    return bytes(i % 251 for i in range(n))
+
+
+def test_blake3_official_vectors(orc):
+    # the official BLAKE3 test-vector set (input byte i % 251, lengths straddling every block and
+    # chunk boundary up to 100 chunks), digests from the BLAKE3 team's C code as vendored in LLVM
+    # (tests/golden/make_blake3_vectors.py): pins multi-block and multi-chunk hashing -- what every
+    # Merkle leaf uses -- on something that is not this repository's own output
+    vec = json.load(open(os.path.join(GOLDEN, "blake3_official.json")))
+    assert len(vec["official_lengths"]) == 35
+    for group in ("official_lengths", "word_lengths"):
+        for ln, hexd in vec[group].items():
+            assert orc.blake3(_pattern(int(ln))).hex() == hexd, ln
+
+
 def test_blake3_multiblock_multichunk_self_consistency(orc):
     # lengths straddling block (64) and chunk (1024) boundaries must all differ and be stable
     seen = set()

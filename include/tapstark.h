@@ -311,6 +311,71 @@ ts_status ts_proof_to_postcard(const uint32_t* proof, size_t n_words, uint8_t* o
 ts_status ts_proof_from_postcard(const uint8_t* bytes, size_t n_bytes, uint32_t* proof_out,
                                  size_t cap_words, size_t* n_words_out);
 
+/* ------------------------------------------------------------------ taptree-compatible MMCS
+ * The reference's real BFMmcs (basic/src/mmcs/taptree_mmcs.rs:24-119) commits to Bitcoin taptrees:
+ * tagged SHA-256 (BIP-341 TapLeaf / TapBranch with lexicographically sorted children), a complete
+ * binary tree over one script leaf per row (basic/src/tcs/builder.rs:38-93), one tree per query.
+ * Digests cross the ABI as 32 bytes (the byte string Bitcoin hashes), not as words.
+ *
+ * The lock scripts inside a leaf script come from un-vendored crates (bitcomm / primitives) and are
+ * therefore SUPPLIED BY THE CALLER as bytes; ts_tap_winternitz_lock_script is a stand-in built from
+ * the reference's local copy of the construction (scripts/src/bit_comm/winternitz.rs:171-274,
+ * bit_comm_u32.rs:80-85, u32/u32_std.rs:122-173).  Script execution against a witness
+ * (tcs/mod.rs:143-147) is out of scope. */
+typedef struct ts_taptree ts_taptree;
+typedef struct ts_tap_mmcs_data ts_tap_mmcs_data;
+/* TapLeaf hash of a script (NodeInfo::new_leaf_with_ver(script, TapScript), builder.rs:24-29), host */
+ts_status ts_tapleaf_hash(const uint8_t* script, size_t len, uint8_t out[32]);
+/* TapNodeHash::from_node_hashes(a, b) (complete_taptree.rs:57-60), host */
+ts_status ts_tapbranch_hash(const uint8_t a[32], const uint8_t b[32], uint8_t out[32]);
+/* lock script of a bit commitment over u32_count limbs (1 = BabyBear, 4 = EF4), host */
+ts_status ts_tap_winternitz_lock_script(const uint8_t* secret, size_t secret_len, uint32_t u32_count,
+                                        uint8_t* out, size_t cap, size_t* len_out);
+/* CommitedLeaf::generate_script (tcs/mod.rs:197-225), host: lock_offsets has n_evals + 2 entries
+ * (index lock, then one lock per evaluation); values = n_evals * u32_size canonical limbs */
+ts_status ts_tap_leaf_script(const uint8_t* lock_scripts, const uint64_t* lock_offsets, uint32_t n_evals,
+                             uint32_t u32_size, uint64_t index, const uint32_t* values, uint8_t* out,
+                             size_t cap, size_t* len_out);
+/* CompleteTaptree::new_with_scripts (complete_taptree.rs:67-75): script i = bytes
+ * [offsets[i], offsets[i+1]); n_leaves must be a power of two (builder.rs:40).  Hashed on the device. */
+ts_status ts_taptree_from_scripts(ts_ctx* ctx, const uint8_t* scripts, const uint64_t* offsets,
+                                  uint64_t n_leaves, ts_taptree** out);
+/* CompleteTaptree::combine (complete_taptree.rs:90-133): leaves of `a` keep their indices, those of
+ * `b` follow; the inputs stay valid */
+ts_status ts_taptree_combine(const ts_taptree* a, const ts_taptree* b, ts_taptree** out);
+ts_status ts_taptree_info(const ts_taptree* t, uint64_t* leaf_count, uint8_t root[32]);
+/* get_leaf_proof (complete_taptree.rs:155-159): leaf hash + sibling path, leaf-most first */
+ts_status ts_taptree_leaf_proof(const ts_taptree* t, uint64_t index, uint8_t leaf_hash[32],
+                                uint8_t* path, uint32_t cap_nodes, uint32_t* depth);
+/* verify_inclusion (complete_taptree.rs:53-64), host; 1 = included */
+int ts_taptree_verify_inclusion(const uint8_t root[32], const uint8_t leaf_hash[32], const uint8_t* path,
+                                uint32_t depth);
+void ts_taptree_free(ts_taptree* t);
+/* TapTreeMmcs::commit (taptree_mmcs.rs:101-114 -> tcs/mod.rs:284-292,238-282,339-378): num_queries
+ * trees over the rows of the matrices (tallest first, power-of-two heights, consumed).  u32_size =
+ * F::U32_SIZE (1 or 4): an evaluation is u32_size consecutive columns.  Tree q uses lock scripts
+ * [q (1 + n_evals), (q + 1)(1 + n_evals)) of `lock_offsets` (num_queries (1 + n_evals) + 1 entries,
+ * n_evals = total width / u32_size).  The leaf scripts are assembled and hashed on the device.
+ * roots_out: num_queries x 32 bytes (Commitment = Vec<TreeRoot>). */
+ts_status ts_tap_mmcs_commit(ts_ctx* ctx, uint32_t n_mats, ts_matrix* const* mats, uint32_t u32_size,
+                             uint32_t num_queries, const uint8_t* lock_scripts,
+                             const uint64_t* lock_offsets, uint8_t* roots_out, ts_tap_mmcs_data** out);
+ts_status ts_tap_mmcs_info(const ts_tap_mmcs_data* d, uint32_t* n_mats, uint32_t* log_max_height,
+                           uint32_t* n_evals, uint32_t* num_queries);
+/* open_batch (taptree_mmcs.rs:46-75): rows of every matrix at index >> bits_reduced (concatenated),
+ * the sibling path in tree query_times_index (log_max_height x 32 bytes) and, if script_len is not
+ * NULL, the opened leaf's script (CommitedProof.leaf, tcs/mod.rs:103-108) */
+ts_status ts_tap_mmcs_open_batch(const ts_tap_mmcs_data* d, uint32_t query_times_index, uint64_t index,
+                                 uint32_t* rows_out, uint8_t* path_out, uint8_t* script_out,
+                                 size_t script_cap, size_t* script_len);
+/* verify_batch (taptree_mmcs.rs:77-99), host: rebuilds the leaf from the tree's lock scripts
+ * (n_evals + 2 offsets), the index and the opened values, and checks its inclusion under `root` */
+ts_status ts_tap_mmcs_verify_batch(const uint8_t* lock_scripts, const uint64_t* lock_offsets,
+                                   uint32_t n_evals, uint32_t u32_size, uint64_t index,
+                                   const uint32_t* opened_values, const uint8_t* path, uint32_t depth,
+                                   const uint8_t root[32], int* ok);
+void ts_tap_mmcs_free(ts_tap_mmcs_data* d);
+
 /* library/ABI version (bumped on any incompatible change) */
 uint32_t ts_abi_version(void);
 

@@ -200,6 +200,26 @@ int64_t ts_or_fri_prove(const ts_or_fri_config* cfg, ts_or_challenger* chal, int
 int ts_or_fri_verify(const ts_or_fri_config* cfg, ts_or_challenger* chal, const uint32_t* proof,
                      size_t n_words);
 
+/* ------------------------------------------------------------------ taptree commitment (taptree.c)
+ * reference basic/src/tcs/{mod,builder,complete_taptree}.rs; hashing per BIP-340/341 */
+void ts_or_sha256(const uint8_t* in, size_t len, uint8_t out[32]);
+void ts_or_tagged_hash(const char* tag, const uint8_t* msg, size_t len, uint8_t out[32]);
+void ts_or_tapleaf_hash(const uint8_t* script, size_t len, unsigned version, uint8_t out[32]);
+void ts_or_tapbranch(const uint8_t a[32], const uint8_t b[32], uint8_t out[32]);
+size_t ts_or_script_push_int(uint64_t v, uint8_t* out);
+size_t ts_or_tap_leaf_script(const uint8_t* const* locks, const size_t* lock_lens, uint64_t index,
+                             const uint32_t* values, uint32_t n_evals, uint32_t u32_size, uint8_t* out,
+                             size_t cap);
+size_t ts_or_padding_matrix(int n_mats, const uint32_t* const* mats, const size_t* heights,
+                            const size_t* widths, uint32_t* out);
+void ts_or_taptree_build(size_t n, const uint8_t* leaf_hashes, uint8_t* nodes, size_t* leaf_indices);
+void ts_or_taptree_path(size_t n, const uint8_t* nodes, size_t index, uint8_t* path);
+int ts_or_taptree_verify_inclusion(const uint8_t root[32], const uint8_t leaf[32], const uint8_t* path,
+                                   size_t depth);
+int ts_or_tap_commit_polys(int n_mats, const uint32_t* const* mats, const size_t* heights,
+                           const size_t* widths, uint32_t u32_size, const uint8_t* const* locks,
+                           const size_t* lock_lens, uint8_t* nodes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -386,3 +386,106 @@ def fri_prove(cfg: FriConfig, inputs, chal: OracleChallenger) -> np.ndarray:
 def fri_verify(cfg: FriConfig, proof, chal: OracleChallenger) -> int:
     proof = _u32(proof)
     return int(lib().ts_or_fri_verify(C.byref(cfg), C.byref(chal.c), _p(proof), C.c_size_t(len(proof))))
+
+
+# ---------------------------------------------------------------- taptree commitment (taptree.c)
+def sha256(data: bytes) -> bytes:
+    out = (C.c_uint8 * 32)()
+    lib().ts_or_sha256(data, C.c_size_t(len(data)), out)
+    return bytes(out)
+
+
+def tagged_hash(tag: str, msg: bytes) -> bytes:
+    out = (C.c_uint8 * 32)()
+    lib().ts_or_tagged_hash(tag.encode(), msg, C.c_size_t(len(msg)), out)
+    return bytes(out)
+
+
+def tapleaf_hash(script: bytes, version: int = 0xC0) -> bytes:
+    out = (C.c_uint8 * 32)()
+    lib().ts_or_tapleaf_hash(script, C.c_size_t(len(script)), version, out)
+    return bytes(out)
+
+
+def tapbranch(a: bytes, b: bytes) -> bytes:
+    out = (C.c_uint8 * 32)()
+    lib().ts_or_tapbranch(a, b, out)
+    return bytes(out)
+
+
+def script_push_int(v: int) -> bytes:
+    out = (C.c_uint8 * 16)()
+    lib().ts_or_script_push_int.restype = C.c_size_t
+    n = lib().ts_or_script_push_int(C.c_uint64(v), out)
+    return bytes(out[:n])
+
+
+def _locks_c(locks):
+    arr = (C.c_char_p * len(locks))(*locks)
+    lens = (C.c_size_t * len(locks))(*[len(x) for x in locks])
+    return arr, lens
+
+
+def tap_leaf_script(locks, index: int, values, u32_size: int = 1) -> bytes:
+    vals = _u32(values).reshape(-1)
+    arr, lens = _locks_c(locks)
+    fn = lib().ts_or_tap_leaf_script
+    fn.restype = C.c_size_t
+    n_evals = len(locks) - 1
+    n = fn(arr, lens, C.c_uint64(index), _p(vals), n_evals, u32_size, None, C.c_size_t(0))
+    out = (C.c_uint8 * max(n, 1))()
+    fn(arr, lens, C.c_uint64(index), _p(vals), n_evals, u32_size, out, C.c_size_t(n))
+    return bytes(out[:n])
+
+
+def padding_matrix(mats) -> np.ndarray:
+    mats = [_u32(m) for m in mats]
+    n = len(mats)
+    ptrs = (u32p * n)(*[_p(m) for m in mats])
+    hs = (C.c_size_t * n)(*[m.shape[0] for m in mats])
+    ws = (C.c_size_t * n)(*[m.shape[1] for m in mats])
+    out = np.zeros((max(m.shape[0] for m in mats), sum(m.shape[1] for m in mats)), dtype=np.uint32)
+    lib().ts_or_padding_matrix(n, ptrs, hs, ws, _p(out))
+    return out
+
+
+class OracleTaptree:
+    """build_tree (builder.rs:38-93) over leaf hashes: every level + the index dictionary."""
+
+    def __init__(self, leaf_hashes):
+        n = len(leaf_hashes)
+        self.n = n
+        self.nodes = (C.c_uint8 * (32 * (2 * n - 1)))()
+        self.leaf_indices = (C.c_size_t * n)()
+        lib().ts_or_taptree_build(C.c_size_t(n), b"".join(leaf_hashes), self.nodes, self.leaf_indices)
+        nb = bytes(self.nodes)
+        self.root = nb[-32:]
+        self.levels, off, cnt = [], 0, n
+        while cnt >= 1:
+            self.levels.append([nb[32 * (off + i):32 * (off + i) + 32] for i in range(cnt)])
+            off += cnt
+            cnt //= 2
+
+    @classmethod
+    def from_scripts(cls, scripts):
+        return cls([tapleaf_hash(s) for s in scripts])
+
+    def path(self, index: int):
+        depth = self.n.bit_length() - 1
+        out = (C.c_uint8 * max(32 * depth, 1))()
+        lib().ts_or_taptree_path(C.c_size_t(self.n), self.nodes, C.c_size_t(index), out)
+        ob = bytes(out)
+        return [ob[32 * k:32 * k + 32] for k in range(depth)]
+
+
+def taptree_verify_inclusion(root: bytes, leaf: bytes, path) -> bool:
+    return bool(lib().ts_or_taptree_verify_inclusion(root, leaf, b"".join(path) or b"\0", C.c_size_t(len(path))))
+
+
+def tap_commit_polys(mats, locks, u32_size: int = 1) -> OracleTaptree:
+    """commit_polys (tcs/mod.rs:238-282) for one tree."""
+    mats = [_u32(m) for m in mats]
+    ys = padding_matrix(mats)
+    n_evals = ys.shape[1] // u32_size
+    assert len(locks) == 1 + n_evals
+    return OracleTaptree.from_scripts([tap_leaf_script(locks, i, ys[i], u32_size) for i in range(ys.shape[0])])

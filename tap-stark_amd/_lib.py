@@ -29,6 +29,10 @@ ABI_SYMBOLS = [
     "ts_proof_to_postcard", "ts_proof_from_postcard",
     "ts_rccl_available", "ts_rccl_unique_id", "ts_comm_rccl_create", "ts_comm_rccl_destroy",
     "ts_comm_local_group_create", "ts_comm_local_get", "ts_comm_local_group_destroy",
+    "ts_tapleaf_hash", "ts_tapbranch_hash", "ts_tap_winternitz_lock_script", "ts_tap_leaf_script",
+    "ts_taptree_from_scripts", "ts_taptree_combine", "ts_taptree_info", "ts_taptree_leaf_proof",
+    "ts_taptree_verify_inclusion", "ts_taptree_free", "ts_tap_mmcs_commit", "ts_tap_mmcs_info",
+    "ts_tap_mmcs_open_batch", "ts_tap_mmcs_verify_batch", "ts_tap_mmcs_free",
 ]
 
 STATUS = {0: "TS_OK", 1: "TS_ERR_INVALID", 2: "TS_ERR_HIP", 3: "TS_ERR_OOM",
@@ -159,6 +163,28 @@ def lib() -> C.CDLL:
         l.ts_comm_local_get.argtypes = [C.c_void_p, C.c_int, C.POINTER(CommC)]
         l.ts_comm_local_group_destroy.argtypes = [C.c_void_p]
         l.ts_comm_local_group_destroy.restype = None
+        u64p = C.POINTER(C.c_uint64)
+        szp = C.POINTER(C.c_size_t)
+        l.ts_tapleaf_hash.argtypes = [C.c_char_p, C.c_size_t, u8p]
+        l.ts_tapbranch_hash.argtypes = [u8p, u8p, u8p]
+        l.ts_tap_winternitz_lock_script.argtypes = [C.c_char_p, C.c_size_t, C.c_uint32, u8p, C.c_size_t, szp]
+        l.ts_tap_leaf_script.argtypes = [C.c_char_p, u64p, C.c_uint32, C.c_uint32, C.c_uint64, u32p, u8p,
+                                         C.c_size_t, szp]
+        l.ts_taptree_from_scripts.argtypes = [C.c_void_p, C.c_char_p, u64p, C.c_uint64, voidpp]
+        l.ts_taptree_combine.argtypes = [C.c_void_p, C.c_void_p, voidpp]
+        l.ts_taptree_info.argtypes = [C.c_void_p, u64p, u8p]
+        l.ts_taptree_leaf_proof.argtypes = [C.c_void_p, C.c_uint64, u8p, u8p, C.c_uint32, u32p]
+        l.ts_taptree_verify_inclusion.argtypes = [u8p, u8p, u8p, C.c_uint32]
+        l.ts_taptree_free.argtypes = [C.c_void_p]
+        l.ts_taptree_free.restype = None
+        l.ts_tap_mmcs_commit.argtypes = [C.c_void_p, C.c_uint32, voidpp, C.c_uint32, C.c_uint32, C.c_char_p,
+                                         u64p, u8p, voidpp]
+        l.ts_tap_mmcs_info.argtypes = [C.c_void_p, u32p, u32p, u32p, u32p]
+        l.ts_tap_mmcs_open_batch.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, u32p, u8p, u8p, C.c_size_t, szp]
+        l.ts_tap_mmcs_verify_batch.argtypes = [C.c_char_p, u64p, C.c_uint32, C.c_uint32, C.c_uint64, u32p, u8p,
+                                               C.c_uint32, u8p, C.POINTER(C.c_int)]
+        l.ts_tap_mmcs_free.argtypes = [C.c_void_p]
+        l.ts_tap_mmcs_free.restype = None
         l.ts_proof_to_postcard.argtypes = [u32p, C.c_size_t, u8p, C.c_size_t, C.POINTER(C.c_size_t)]
         l.ts_proof_from_postcard.argtypes = [u8p, C.c_size_t, u32p, C.c_size_t, C.POINTER(C.c_size_t)]
         l.ts_check_constraints.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, u32p, C.c_uint32,

@@ -8,20 +8,9 @@
 #include <string>
 #include <vector>
 
-#include "../../include/tapstark.h"
-#include "host.hpp"
+#include "abi_types.hpp"
 #include "jit.hpp"
 
-struct ts_ctx {
-    ts::Context ctx;
-    explicit ts_ctx(int dev) : ctx(dev) {}
-};
-struct ts_matrix {
-    ts::DeviceMatrix m;
-};
-struct ts_pcs_data {
-    std::unique_ptr<ts::PcsData> d;
-};
 struct ts_air {
     ts::AirProgram prog;
     ts::DevBuf<uint32_t> code;

@@ -1,0 +1,169 @@
+"""GPU tests of the taptree-compatible commitment: the SHA-256
+kernels (TapLeaf over host-supplied scripts and over leaf scripts assembled on the device, TapBranch
+levels) against the oracle, on the reference's own test shapes:
+  basic/src/tcs/complete_taptree.rs:163-369  test_build_tree, test_combine_tree, test_combine_with_different_depth
+  basic/src/tcs/mod.rs:520-718               test_taptree_mmcs, test_taptree_mmcs_with_multi_query
+  basic/src/mmcs/taptree_mmcs.rs:133-231     the same three matrices through the BFMmcs surface
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import tapstark_amd as ts
+from tapstark_amd import taptree as tt
+from tapstark_amd._lib import TsError
+from tapstark_amd.airs import splitmix64_stream
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+KATS = json.load(open(os.path.join(GOLDEN, "kats.json")))
+P = 0x78000001
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from tapstark_amd.build import build
+
+    build()
+    return ts.default_context()
+
+
+def num_script(orc, i):  # script! { {i} OP_ADD }
+    return orc.script_push_int(i) + b"\x93"
+
+
+def locks_for(q, n_evals, u32=1):
+    return [tt.winternitz_lock_script(bytes([q, s & 0xFF, s >> 8, 9]), 1 if s == 0 else u32)
+            for s in range(1 + n_evals)]
+
+
+def test_build_tree(ctx, orc):
+    # complete_taptree.rs:163-209
+    scripts = [num_script(orc, i) for i in range(16)]
+    tree = tt.CompleteTaptree.new_with_scripts(scripts, ctx)
+    want = orc.OracleTaptree.from_scripts(scripts)
+    assert tree.leaf_count == 16 and tree.root == want.root
+    for q in range(16):
+        leaf, path = tree.get_leaf_proof(q)
+        assert leaf == orc.tapleaf_hash(scripts[q]) == tt.tapleaf_hash(scripts[q])
+        assert path == want.path(q)
+        assert tt.verify_inclusion(tree.root, leaf, path)  # verify_inclusion_by_index
+        assert orc.taptree_verify_inclusion(tree.root, leaf, path)
+    one = tt.CompleteTaptree.new_with_scripts([scripts[3]], ctx)  # a single leaf is its own root
+    assert one.root == orc.tapleaf_hash(scripts[3]) and one.get_leaf_proof(0) == (one.root, [])
+    with pytest.raises(TsError):  # builder.rs:40 assert!(is_power_of_two(leaf_count))
+        tt.CompleteTaptree.new_with_scripts(scripts[:15], ctx)
+
+
+@pytest.mark.parametrize("nb", [8, 4], ids=["test_combine_tree", "test_combine_with_different_depth"])
+def test_combine(ctx, orc, nb):
+    # complete_taptree.rs:211-369: merkle indices follow [self leaves..., other leaves...]
+    a_s = [num_script(orc, i) for i in range(8)]
+    b_s = [num_script(orc, 8 + i) for i in range(nb)]
+    a, b = tt.CompleteTaptree.new_with_scripts(a_s, ctx), tt.CompleteTaptree.new_with_scripts(b_s, ctx)
+    oa, ob = orc.OracleTaptree.from_scripts(a_s), orc.OracleTaptree.from_scripts(b_s)
+    for first, second, fs, ss, of, os_ in ((a, b, a_s, b_s, oa, ob), (b, a, b_s, a_s, ob, oa)):
+        c = first.combine(second)
+        assert c.leaf_count == len(fs) + len(ss)
+        assert c.root == orc.tapbranch(of.root, os_.root)
+        for q, script in enumerate(fs + ss):
+            leaf, path = c.get_leaf_proof(q)
+            assert leaf == orc.tapleaf_hash(script)
+            inner = of.path(q) + [os_.root] if q < len(fs) else os_.path(q - len(fs)) + [of.root]
+            assert path == inner
+            assert tt.verify_inclusion(c.root, leaf, path)
+
+
+def test_tapleaf_kernel_on_scripts_of_every_length(ctx, orc):
+    # host-supplied scripts of 0..1100 bytes: every alignment of the tail, the 0xfd compact-size
+    # switch at 253 bytes, padding boundaries of SHA-256 (55/56/64 mod 64)
+    rng = np.random.default_rng(7)
+    lens = list(range(0, 140)) + [247, 250, 251, 252, 253, 254, 255, 256, 300, 511, 512, 1000, 1100]
+    lens += [int(x) for x in rng.integers(0, 1100, 256 - len(lens))]
+    scripts = [bytes(rng.integers(0, 256, n, dtype=np.uint8)) for n in lens]
+    tree = tt.CompleteTaptree.new_with_scripts(scripts, ctx)
+    want = orc.OracleTaptree.from_scripts(scripts)
+    assert tree.root == want.root
+    for q in range(len(scripts)):
+        leaf, path = tree.get_leaf_proof(q)
+        assert leaf == want.levels[0][q], f"leaf {q} (len {lens[q]})"
+    assert tree.get_leaf_proof(200)[1] == want.path(200)
+
+
+def three_matrices():
+    k = KATS["padding_matrix"]
+    return [np.array(k[n], dtype=np.uint32) for n in ("mat_3", "mat_1", "mat_2")], k["leaf_ys"]
+
+
+@pytest.mark.parametrize("query_times", [1, 8], ids=["test_taptree_mmcs", "test_taptree_mmcs_with_multi_query"])
+def test_taptree_mmcs_reference_shape(ctx, orc, query_times):
+    # tcs/mod.rs:520-718 and taptree_mmcs.rs:133-231: mat_1 4x2, mat_2 4x4, mat_3 8x1
+    mats, leaf_ys = three_matrices()
+    mm = tt.TapTreeMmcs(query_times, locks_for, ctx=ctx)
+    roots, data = mm.commit([m.copy() for m in mats])
+    assert len(roots) == query_times == data.num_queries and data.n_evals == 7 and data.log_max_height == 3
+    assert len(set(roots)) == query_times  # a tree per query, each with its own bit commitments
+    for q in range(query_times):
+        want = orc.tap_commit_polys(mats, locks_for(q, 7))
+        assert roots[q] == want.root, f"tree {q}"
+        for index in range(8):
+            rows, path, script = mm.open_batch(q, index, data, 7)
+            assert rows.tolist() == leaf_ys[index]  # the layout written at tcs/mod.rs:594-602
+            assert path == want.path(index)
+            assert script == orc.tap_leaf_script(locks_for(q, 7), index, rows)
+            assert orc.tapleaf_hash(script) == want.levels[0][index]
+            assert mm.verify_batch(data.tree_locks(q), index, rows, path, roots[q])
+            bad = rows.copy()
+            bad[2] = (int(bad[2]) + 1) % P
+            assert not mm.verify_batch(data.tree_locks(q), index, bad, path, roots[q])
+            assert not mm.verify_batch(data.tree_locks(q), index, rows, path, roots[(q + 1) % query_times]) \
+                or query_times == 1
+
+
+def test_taptree_mmcs_extension_field_rows(ctx, orc):
+    # F::U32_SIZE = 4 (tcs/mod.rs:239-246 CommitType::U128): the FRI commit-phase matrices have rows of
+    # two EF4 elements (fri/src/prover.rs:112); limbs are pushed last first (tcs/mod.rs:214-217)
+    m = splitmix64_stream(77, 64 * 8).reshape(64, 8)
+    mm = tt.TapTreeMmcs(3, lambda q, n: locks_for(q, n, 4), u32_size=4, ctx=ctx)
+    roots, data = mm.commit([m.copy()])
+    assert data.n_evals == 2
+    for q in range(3):
+        want = orc.tap_commit_polys([m], locks_for(q, 2, 4), 4)
+        assert roots[q] == want.root
+        for index in (0, 17, 63):
+            rows, path, script = mm.open_batch(q, index, data, 8)
+            assert (rows == m[index]).all() and path == want.path(index)
+            assert script == orc.tap_leaf_script(locks_for(q, 2, 4), index, rows, 4)
+            assert mm.verify_batch(data.tree_locks(q), index, rows, path, roots[q])
+
+
+@pytest.mark.parametrize("small", [False, True], ids=["field-elements", "small-values"])
+def test_taptree_mmcs_larger_mixed_heights(ctx, orc, small):
+    # random field elements (4-byte pushes almost everywhere) and small values (pushes of 1-2 bytes:
+    # neighbouring leaves drift apart in the byte stream, the divergent case for the leaf kernel)
+    shapes = [(10, 5), (10, 1), (8, 3), (5, 2)]
+    mats = [splitmix64_stream(300 + i, (1 << lh) * w).reshape(1 << lh, w) for i, (lh, w) in enumerate(shapes)]
+    if small:
+        mats = [m % np.uint32(300) for m in mats]
+    mm = tt.TapTreeMmcs(2, locks_for, ctx=ctx)
+    roots, data = mm.commit([m.copy() for m in mats])
+    ys = orc.padding_matrix(mats)
+    for q in range(2):
+        want = orc.tap_commit_polys(mats, locks_for(q, 11))
+        assert roots[q] == want.root
+        for index in (0, 1, 511, 1023, 700):
+            rows, path, script = mm.open_batch(q, index, data, 11)
+            assert (rows == ys[index]).all() and path == want.path(index)
+            assert mm.verify_batch(data.tree_locks(q), index, rows, path, roots[q])
+
+
+def test_taptree_mmcs_refuses_what_the_reference_panics_on(ctx):
+    m_small, m_tall = np.zeros((4, 2), dtype=np.uint32), np.zeros((8, 1), dtype=np.uint32)
+    mm = tt.TapTreeMmcs(1, locks_for, ctx=ctx)
+    with pytest.raises(TsError) as e:  # taptree_mmcs.rs:68-72 assert_eq!(openings_flatten, openings_evals)
+        mm.commit([m_small, m_tall])
+    assert e.value.code == 5
+    with pytest.raises(TsError):  # width not a multiple of U32_SIZE
+        tt.TapTreeMmcs(1, lambda q, n: locks_for(q, n, 4), u32_size=4, ctx=ctx).commit([np.zeros((4, 6), dtype=np.uint32)])

@@ -24,6 +24,7 @@ Context::~Context() {
     if (d_twiddle_inv) hipFree(d_twiddle_inv);
     for (auto& t : scale_tables) hipFree(t.d);
     if (d_selectors) hipFree(d_selectors);
+    if (d_ticket) hipFree(d_ticket);
     for (auto& kv : free_blocks) hipFree(kv.second);
     for (auto& kv : live_blocks) hipFree(kv.first);
     if (h_pinned) hipHostFree(h_pinned);
@@ -80,6 +81,14 @@ void Context::release_cache() {
         bytes_reserved -= kv.first;
     }
     free_blocks.clear();
+}
+
+uint32_t* Context::ticket() {
+    if (!d_ticket) {
+        TS_HIP(hipMalloc((void**)&d_ticket, 64));
+        TS_HIP(hipMemsetAsync(d_ticket, 0, 64, stream));
+    }
+    return d_ticket;
 }
 
 void* Context::pinned(size_t bytes) {

@@ -75,6 +75,11 @@ struct Context {
     uint32_t* d_selectors = nullptr;
     unsigned sel_log_n = ~0u, sel_log_qd = ~0u;
 
+    // one zero-initialised word the "last workgroup done" kernels count in (merkle.hip); each
+    // kernel leaves it at zero, and launches on the one stream run in order
+    uint32_t* d_ticket = nullptr;
+    uint32_t* ticket();
+
     // pinned host staging
     void* h_pinned = nullptr;
     size_t h_pinned_bytes = 0;

@@ -7,6 +7,7 @@
 // The folded vector is an array of EF4 (16 B); a fold thread produces two adjacent outputs, i.e.
 // exactly one leaf of the NEXT round's commit-phase matrix, and hashes it in the same pass.
 #include "blake3.hpp"
+#include "blake3_quad.hpp"
 #include "chal_dev.hpp"
 #include "kernels.hpp"
 
@@ -204,7 +205,10 @@ void launch_chal_round(Context& ctx, DevChallenger* ch, const uint32_t* root, ui
 // tree (L_t - 1 digests, leaves first) at sum_{j<t} (L_j - 1) (in digests).
 constexpr int TAIL_NT = 512;
 constexpr int TAIL_MAX = 1 << FRI_TAIL_LOG;
+constexpr int TAIL_STRIDE = TAIL_MAX / 2;  // digest images: [word][node], one stride for both
 
+// Every compression here is shared by four lanes (blake3_quad.hpp): the kernel is one long chain of
+// dependent compressions (leaf, log2(h) levels, the sponge, per round), i.e. pure latency.
 __global__ void __launch_bounds__(TAIL_NT)
 k_fri_tail(const Ef* __restrict__ in, uint32_t L0, uint32_t blowup, DevChallenger* __restrict__ ch,
            const uint32_t* __restrict__ Winv, Ef* __restrict__ tail_vecs,
@@ -212,9 +216,21 @@ k_fri_tail(const Ef* __restrict__ in, uint32_t L0, uint32_t blowup, DevChallenge
            Ef* __restrict__ betas_out, Ef* __restrict__ final_out) {
     __shared__ Ef bufA[TAIL_MAX];
     __shared__ Ef bufB[TAIL_MAX / 2];
-    __shared__ uint32_t digA[8 * (TAIL_MAX / 2)];
-    __shared__ uint32_t digB[8 * (TAIL_MAX / 4)];
+    __shared__ uint32_t digA[8 * TAIL_STRIDE];
+    __shared__ uint32_t digB[8 * TAIL_STRIDE];
     __shared__ Ef s_beta;
+    const uint32_t j = threadIdx.x & 3;
+    uint32_t moff[28], lidx[28], lmask = 0;  // tree-node offsets; leaf word indices and their validity
+    {
+        uint32_t idx[28];
+        b3::quad_schedule(j, idx);
+#pragma unroll
+        for (int k = 0; k < 28; k++) {
+            moff[k] = (idx[k] & 7) * TAIL_STRIDE + (idx[k] >> 3);
+            lidx[k] = idx[k] & 7;
+            lmask |= (idx[k] < 8 ? 1u : 0u) << k;
+        }
+    }
     Ef* cur = bufA;
     Ef* nxt = bufB;
     for (uint32_t i = threadIdx.x; i < L0; i += TAIL_NT) cur[i] = load_ef(in + i);
@@ -223,48 +239,41 @@ k_fri_tail(const Ef* __restrict__ in, uint32_t L0, uint32_t blowup, DevChallenge
     while (L > blowup) {
         const uint32_t h = L >> 1;
         for (uint32_t i = threadIdx.x; i < L; i += TAIL_NT) store_ef(tail_vecs + voff + i, cur[i]);
-        // leaves: rows (cur[2i], cur[2i+1])
-        for (uint32_t i = threadIdx.x; i < h; i += TAIL_NT) {
-            const Ef a = cur[2 * i], b = cur[2 * i + 1];
-            uint32_t m[16] = {a.c[0], a.c[1], a.c[2], a.c[3], b.c[0], b.c[1], b.c[2], b.c[3],
-                              0, 0, 0, 0, 0, 0, 0, 0};
-            uint32_t cv[8];
-            b3::iv(cv);
-            b3::compress(cv, m, 32, b3::CHUNK_START | b3::CHUNK_END | b3::ROOT);
+        // leaves: rows (cur[2i], cur[2i+1]) = 8 words, one short block
+        for (uint32_t q = threadIdx.x; q < 4 * h; q += TAIL_NT) {
+            const uint32_t i = q >> 2;
+            const uint32_t* row = reinterpret_cast<const uint32_t*>(cur + 2 * i);
+            uint32_t lo, hi;
+            b3::compress_quad(j, b3::iv_word(j), b3::iv_word(4 + j),
+                              [&](int k) { return ((lmask >> k) & 1u) ? row[lidx[k]] : 0u; }, 32,
+                              b3::CHUNK_START | b3::CHUNK_END | b3::ROOT, lo, hi);
             uint32_t* o = tail_trees + 8 * (uint64_t)(toff + i);
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                o[k] = cv[k];
-                digA[k * (TAIL_MAX / 2) + i] = cv[k];
-            }
+            o[j] = lo;
+            o[4 + j] = hi;
+            digA[j * TAIL_STRIDE + i] = lo;
+            digA[(4 + j) * TAIL_STRIDE + i] = hi;
         }
         __syncthreads();
         uint32_t* src = digA;
-        uint32_t src_stride = TAIL_MAX / 2;
         uint32_t n = h, lvl_off = toff, lvl = 0;
         while (n > 1) {
             const uint32_t n_par = n >> 1;
             uint32_t* dst = (lvl & 1) ? digA : digB;
-            const uint32_t dst_stride = (lvl & 1) ? TAIL_MAX / 2 : TAIL_MAX / 4;
-            for (uint32_t i = threadIdx.x; i < n_par; i += TAIL_NT) {
-                uint32_t m[16];
-#pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    m[k] = src[k * src_stride + 2 * i];
-                    m[8 + k] = src[k * src_stride + 2 * i + 1];
-                }
-                uint32_t cv[8];
-                b3::hash64(m, cv);
+            for (uint32_t q = threadIdx.x; q < 4 * n_par; q += TAIL_NT) {
+                const uint32_t i = q >> 2;
+                const uint32_t* base = src + 2 * i;
+                uint32_t lo, hi;
+                b3::compress_quad(j, b3::iv_word(j), b3::iv_word(4 + j),
+                                  [&](int k) { return base[moff[k]]; }, 64,
+                                  b3::CHUNK_START | b3::CHUNK_END | b3::ROOT, lo, hi);
                 uint32_t* o = tail_trees + 8 * (uint64_t)(lvl_off + n + i);
-#pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    o[k] = cv[k];
-                    dst[k * dst_stride + i] = cv[k];
-                }
+                o[j] = lo;
+                o[4 + j] = hi;
+                dst[j * TAIL_STRIDE + i] = lo;
+                dst[(4 + j) * TAIL_STRIDE + i] = hi;
             }
             __syncthreads();
             src = dst;
-            src_stride = dst_stride;
             lvl_off += n;
             n = n_par;
             lvl++;
@@ -272,7 +281,7 @@ k_fri_tail(const Ef* __restrict__ in, uint32_t L0, uint32_t blowup, DevChallenge
         if (threadIdx.x == 0) {
             uint32_t root[8];
             for (int k = 0; k < 8; k++) {
-                root[k] = src[k * src_stride];
+                root[k] = src[k * TAIL_STRIDE];
                 roots_out[8 * t + k] = root[k];
             }
             const Ef beta = dc_observe_root_and_sample(ch, root);

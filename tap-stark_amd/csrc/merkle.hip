@@ -7,6 +7,7 @@
 #include <stdlib.h>
 
 #include "blake3.hpp"
+#include "blake3_quad.hpp"
 #include "chal_dev.hpp"
 #include "kernels.hpp"
 
@@ -247,65 +248,107 @@ void launch_shard_top(Context& ctx, const uint32_t* subroots, uint32_t G, uint32
     TS_HIP(hipGetLastError());
 }
 
-// A workgroup reduces a subtree of S = 2^log_s consecutive nodes of level `first_level` to its
-// root (log_s levels), storing every intermediate level in the tree.  Between levels the digests
-// stay in LDS, word-interleaved ([word][node]) so that reads and writes are bank-conflict free.
-template <int NTH, int SUBTREE_LOG>
-__global__ void __launch_bounds__(NTH)
-k_merkle_subtree(uint32_t* __restrict__ tree, unsigned log_leaves, unsigned first_level,
-                 unsigned log_s, unsigned n_levels, DevChallenger* __restrict__ ch,
-                 uint32_t* __restrict__ root_out, Ef* __restrict__ beta_out) {
-    __shared__ uint32_t bufA[8 * (1 << (SUBTREE_LOG - 1))];
-    __shared__ uint32_t bufB[8 * (1 << (SUBTREE_LOG - 2))];
-    uint64_t off = 0;
-    for (unsigned l = 0; l < first_level; l++) off += (uint64_t)1 << (log_leaves - l);
-    uint64_t n_level = (uint64_t)1 << (log_leaves - first_level);  // nodes in the current level
-    const uint32_t S = 1u << log_s;
-    uint64_t sub0 = (uint64_t)blockIdx.x * S;  // first node of this subtree in the current level
-    uint32_t* src = nullptr;                   // LDS source (nullptr: read level from global)
-    uint32_t src_stride = 0;
-    for (unsigned l = 0; l < n_levels; l++) {
-        const uint32_t n_par = S >> (l + 1);
-        uint32_t* dst = (l & 1) ? bufB : bufA;
-        const uint32_t dst_stride = (l & 1) ? (1u << (SUBTREE_LOG - 2)) : (1u << (SUBTREE_LOG - 1));
-        const uint64_t par_off = off + n_level;  // next level's offset in the tree
-        for (uint32_t i = threadIdx.x; i < n_par; i += NTH) {
-            uint32_t m[16];
-            if (src == nullptr) {
-                const uint4* ch = reinterpret_cast<const uint4*>(tree + 8 * (off + sub0 + 2 * (uint64_t)i));
-                uint4 a = ch[0], b = ch[1], c = ch[2], d = ch[3];
-                m[0] = a.x; m[1] = a.y; m[2] = a.z; m[3] = a.w;
-                m[4] = b.x; m[5] = b.y; m[6] = b.z; m[7] = b.w;
-                m[8] = c.x; m[9] = c.y; m[10] = c.z; m[11] = c.w;
-                m[12] = d.x; m[13] = d.y; m[14] = d.z; m[15] = d.w;
-            } else {
-#pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    m[k] = src[k * src_stride + 2 * i];
-                    m[8 + k] = src[k * src_stride + 2 * i + 1];
-                }
-            }
-            uint32_t cv[8];
-            b3::hash64(m, cv);
-            uint4* o = reinterpret_cast<uint4*>(tree + 8 * (par_off + (sub0 >> 1) + i));
-            o[0] = make_uint4(cv[0], cv[1], cv[2], cv[3]);
-            o[1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
-#pragma unroll
-            for (int k = 0; k < 8; k++) dst[k * dst_stride + i] = cv[k];
+// The last <= 16 levels of a tree in ONE launch.  Workgroup g reduces the subtree of S = 2^log_s
+// consecutive nodes of level `first_level` to its root (log_s levels); the workgroup that finishes
+// LAST (a ticket counter in device memory) then reduces the n_sub sub-roots to the tree root, and
+// runs the challenger step if asked.  Every level is stored in the tree.
+//   * a level is staged through LDS as [word][node] (bank-conflict free for both access patterns);
+//   * four lanes share one compression (blake3_quad.hpp): these levels are latency-bound -- fewer
+//     nodes than lanes, a chain of dependent compressions -- and the quad form cuts the chain by ~3.5x.
+constexpr int SUB_NTH = 256;
+constexpr int SUB_S = 256;  // nodes a workgroup takes in (2^8)
+
+struct SubLds {
+    uint32_t in[8 * SUB_S];  // stride SUB_S in all three images, so that one set of offsets serves
+    uint32_t a[8 * SUB_S];
+    uint32_t b[8 * SUB_S];
+};
+
+// reduces `count` (a power of two <= SUB_S) nodes lying in lds.in to one; level l of the result
+// (count >> (l+1) nodes) goes to tree + 8 * (level_off[l] + node0 >> (l+1) ...).  Returns the LDS
+// image holding the root (node 0).
+__device__ __forceinline__ const uint32_t* reduce_in_lds(SubLds& lds, uint32_t count, uint32_t* tree,
+                                                         uint64_t first_parent_off,
+                                                         uint64_t parents_in_level, uint64_t node0,
+                                                         const uint32_t moff[28]) {
+    const uint32_t j = threadIdx.x & 3;
+    const uint32_t* src = lds.in;
+    uint64_t par_off = first_parent_off, n_level = parents_in_level, p0 = node0 >> 1;
+    unsigned l = 0;
+    for (uint32_t n_par = count >> 1; n_par >= 1; n_par >>= 1, l++) {
+        uint32_t* dst = (l & 1) ? lds.b : lds.a;
+        for (uint32_t t = threadIdx.x; t < 4 * n_par; t += SUB_NTH) {
+            const uint32_t i = t >> 2;
+            const uint32_t* base = src + 2 * i;
+            uint32_t lo, hi;
+            b3::compress_quad(j, b3::iv_word(j), b3::iv_word(4 + j),
+                              [&](int k) { return base[moff[k]]; }, 64,
+                              b3::CHUNK_START | b3::CHUNK_END | b3::ROOT, lo, hi);
+            dst[j * SUB_S + i] = lo;
+            dst[(4 + j) * SUB_S + i] = hi;
+            uint32_t* o = tree + 8 * (par_off + p0 + i);
+            o[j] = lo;
+            o[4 + j] = hi;
         }
         __syncthreads();
         src = dst;
-        src_stride = dst_stride;
-        off = par_off;
+        par_off += n_level;
         n_level >>= 1;
-        sub0 >>= 1;
+        p0 >>= 1;
+    }
+    return src;
+}
+
+__device__ __forceinline__ void stage_nodes(SubLds& lds, const uint32_t* nodes, uint32_t count) {
+    // count nodes x 8 words, coalesced read, transposed into [word][node]
+    for (uint32_t e = threadIdx.x; e < 8 * count; e += SUB_NTH) lds.in[(e & 7) * SUB_S + (e >> 3)] = nodes[e];
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(SUB_NTH)
+k_merkle_top(uint32_t* __restrict__ tree, unsigned log_leaves, unsigned first_level, unsigned log_s,
+             uint32_t* __restrict__ ticket, DevChallenger* __restrict__ ch,
+             uint32_t* __restrict__ root_out, Ef* __restrict__ beta_out) {
+    __shared__ SubLds lds;
+    __shared__ uint32_t s_last;
+    uint32_t moff[28];
+    {
+        uint32_t idx[28];
+        b3::quad_schedule(threadIdx.x & 3, idx);
+#pragma unroll
+        for (int k = 0; k < 28; k++) moff[k] = (idx[k] & 7) * SUB_S + (idx[k] >> 3);
+    }
+    uint64_t off = 0;
+    for (unsigned l = 0; l < first_level; l++) off += (uint64_t)1 << (log_leaves - l);
+    const uint64_t n_level = (uint64_t)1 << (log_leaves - first_level);
+    const uint32_t S = 1u << log_s;
+    const uint32_t n_sub = (uint32_t)(n_level >> log_s);
+    const uint64_t sub0 = (uint64_t)blockIdx.x * S;
+    stage_nodes(lds, tree + 8 * (off + sub0), S);
+    const uint32_t* top = reduce_in_lds(lds, S, tree, off + n_level, n_level >> 1, sub0, moff);
+    bool finisher = n_sub == 1;
+    if (n_sub > 1) {
+        // publish this sub-root (already stored by reduce_in_lds), then take a ticket
+        __threadfence();
+        __syncthreads();
+        if (threadIdx.x == 0) s_last = atomicAdd(ticket, 1u) == n_sub - 1 ? 1u : 0u;
+        __syncthreads();
+        if (s_last) {
+            __threadfence();  // acquire: the other workgroups' sub-roots
+            uint64_t off2 = off;
+            for (unsigned l = 0; l < log_s; l++) off2 += (uint64_t)1 << (log_leaves - first_level - l);
+            stage_nodes(lds, tree + 8 * off2, n_sub);
+            top = reduce_in_lds(lds, n_sub, tree, off2 + n_sub, n_sub >> 1, 0, moff);
+            if (threadIdx.x == 0) *ticket = 0;  // ready for the next launch on this stream
+            finisher = true;
+        }
     }
     // device-resident transcript (fri/src/prover.rs:114-116): the workgroup that produced the root
     // observes it and samples the next challenge, saving a kernel launch per FRI round
-    if (ch != nullptr && n_level == 1 && threadIdx.x == 0 && blockIdx.x == 0 && src != nullptr) {
+    if (finisher && ch != nullptr && threadIdx.x == 0) {
         uint32_t root[8];
         for (int k = 0; k < 8; k++) {
-            root[k] = src[k * src_stride];
+            root[k] = top[k * SUB_S];
             root_out[k] = root[k];
         }
         const Ef beta = dc_observe_root_and_sample(ch, root);
@@ -314,18 +357,7 @@ k_merkle_subtree(uint32_t* __restrict__ tree, unsigned log_leaves, unsigned firs
 }
 
 // Levels with more than 2^16 children: one launch per level (bandwidth-bound, ~3.7 TB/s of digest
-// traffic).  The last <= 16 levels are latency-bound (one Blake3 compression of ~680 dependent
-// instructions per level): they are done by at most two launches of the LDS subtree kernel, the
-// first with many small workgroups, the second with one workgroup that reaches the root (and, if
-// asked, feeds the device challenger).
-template <int NTH, int LOG_S>
-static void launch_subtree(Context& ctx, uint32_t* tree, unsigned log_leaves, unsigned level,
-                           unsigned log_s, unsigned n_levels, uint64_t n_sub, DevChallenger* ch,
-                           uint32_t* root_out, Ef* beta_out) {
-    TS_LAUNCH(ctx, (k_merkle_subtree<NTH, LOG_S>), dim3((unsigned)n_sub), dim3(NTH), 0, tree,
-              log_leaves, level, log_s, n_levels, ch, root_out, beta_out);
-}
-
+// traffic).  The last <= 16 levels are latency-bound: one launch of k_merkle_top.
 bool launch_merkle_levels(Context& ctx, uint32_t* tree, unsigned log_leaves, DevChallenger* ch,
                           uint32_t* root_out, Ef* beta_out) {
     unsigned level = 0;
@@ -337,22 +369,14 @@ bool launch_merkle_levels(Context& ctx, uint32_t* tree, unsigned log_leaves, Dev
         off += n_children;
         level++;
     }
-    bool chal_done = false;
-    unsigned remaining = log_leaves - level;
-    if (remaining > 8) {  // first half: 2^(remaining - a) workgroups of 2^a children each
-        const unsigned a = (remaining + 1) / 2;  // <= 8
-        launch_subtree<128, 8>(ctx, tree, log_leaves, level, a, a, (uint64_t)1 << (remaining - a),
-                               nullptr, nullptr, nullptr);
-        level += a;
-        remaining -= a;
-    }
-    if (remaining > 0) {
-        launch_subtree<128, 8>(ctx, tree, log_leaves, level, remaining, remaining, 1, ch, root_out,
-                               beta_out);
-        chal_done = ch != nullptr;
-    }
+    const unsigned remaining = log_leaves - level;
+    if (remaining == 0) return false;
+    // first phase: workgroups of 2^a nodes; second phase (last workgroup): 2^(remaining - a) sub-roots
+    const unsigned a = remaining <= 8 ? remaining : 8;
+    TS_LAUNCH(ctx, k_merkle_top, dim3(1u << (remaining - a)), dim3(SUB_NTH), 0, tree, log_leaves, level, a,
+              ctx.ticket(), ch, root_out, beta_out);
     TS_HIP(hipGetLastError());
-    return chal_done;
+    return ch != nullptr;
 }
 
 }  // namespace ts

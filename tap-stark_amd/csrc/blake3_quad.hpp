@@ -19,6 +19,12 @@ namespace b3 {
 
 #if defined(__HIPCC__)
 
+// Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() also drains the
+// wave's outstanding global stores (s_waitcnt vmcnt(0): 1-2 us each time near the top of a tree,
+// where every level stores its few digests and then meets at a barrier); the digests of a level
+// travel to the next one through LDS, so the stores may stay in flight.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // message schedule, 4 bits per position: round r, positions 0..7 in LO[r], 8..15 in HI[r]
 // (the rows of TS_B3_ROUND in blake3.hpp; row r+1 = row r permuted by the BLAKE3 message permutation)
 __device__ __forceinline__ uint32_t sched_word(int r, uint32_t pos) {

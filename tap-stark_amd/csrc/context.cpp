@@ -85,8 +85,8 @@ void Context::release_cache() {
 
 uint32_t* Context::ticket() {
     if (!d_ticket) {
-        TS_HIP(hipMalloc((void**)&d_ticket, 64));
-        TS_HIP(hipMemsetAsync(d_ticket, 0, 64, stream));
+        TS_HIP(hipMalloc((void**)&d_ticket, 64 * 17));  // the global word + 16 group words, a line each
+        TS_HIP(hipMemsetAsync(d_ticket, 0, 64 * 17, stream));
     }
     return d_ticket;
 }

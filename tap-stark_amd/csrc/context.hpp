@@ -75,8 +75,8 @@ struct Context {
     uint32_t* d_selectors = nullptr;
     unsigned sel_log_n = ~0u, sel_log_qd = ~0u;
 
-    // one zero-initialised word the "last workgroup done" kernels count in (merkle.hip); each
-    // kernel leaves it at zero, and launches on the one stream run in order
+    // zero-initialised words (17 lines of 64 bytes) the "last workgroup done" kernels count in
+    // (merkle.hip); each kernel leaves them at zero, and launches on the one stream run in order
     uint32_t* d_ticket = nullptr;
     uint32_t* ticket();
 

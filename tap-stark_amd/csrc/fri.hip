@@ -253,7 +253,7 @@ k_fri_tail(const Ef* __restrict__ in, uint32_t L0, uint32_t blowup, DevChallenge
             digA[j * TAIL_STRIDE + i] = lo;
             digA[(4 + j) * TAIL_STRIDE + i] = hi;
         }
-        __syncthreads();
+        b3::lds_barrier();
         uint32_t* src = digA;
         uint32_t n = h, lvl_off = toff, lvl = 0;
         while (n > 1) {
@@ -272,7 +272,7 @@ k_fri_tail(const Ef* __restrict__ in, uint32_t L0, uint32_t blowup, DevChallenge
                 dst[j * TAIL_STRIDE + i] = lo;
                 dst[(4 + j) * TAIL_STRIDE + i] = hi;
             }
-            __syncthreads();
+            b3::lds_barrier();
             src = dst;
             lvl_off += n;
             n = n_par;
@@ -288,11 +288,11 @@ k_fri_tail(const Ef* __restrict__ in, uint32_t L0, uint32_t blowup, DevChallenge
             s_beta = beta;
             store_ef(betas_out + t, beta);
         }
-        __syncthreads();
+        b3::lds_barrier();
         const Ef half_beta_mont = ef_mul_base(ef_to_mont(s_beta), HALF_MONT);
         for (uint32_t i = threadIdx.x; i < h; i += TAIL_NT)
             nxt[i] = fold_one(cur[2 * i], cur[2 * i + 1], Winv[h + i], half_beta_mont, HALF_MONT);
-        __syncthreads();
+        b3::lds_barrier();
         Ef* tmp = cur;
         cur = nxt;
         nxt = tmp;

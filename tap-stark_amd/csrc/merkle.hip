@@ -270,7 +270,7 @@ struct SubLds {
 __device__ __forceinline__ const uint32_t* reduce_in_lds(SubLds& lds, uint32_t count, uint32_t* tree,
                                                          uint64_t first_parent_off,
                                                          uint64_t parents_in_level, uint64_t node0,
-                                                         const uint32_t moff[28]) {
+                                                         const uint32_t moff[28], bool publish_root) {
     const uint32_t j = threadIdx.x & 3;
     const uint32_t* src = lds.in;
     uint64_t par_off = first_parent_off, n_level = parents_in_level, p0 = node0 >> 1;
@@ -286,11 +286,19 @@ __device__ __forceinline__ const uint32_t* reduce_in_lds(SubLds& lds, uint32_t c
                               b3::CHUNK_START | b3::CHUNK_END | b3::ROOT, lo, hi);
             dst[j * SUB_S + i] = lo;
             dst[(4 + j) * SUB_S + i] = hi;
-            uint32_t* o = tree + 8 * (par_off + p0 + i);
-            o[j] = lo;
-            o[4 + j] = hi;
+            {
+                uint32_t* o = tree + 8 * (par_off + p0 + i);
+                if (publish_root && n_par == 1) {
+                    // the sub-root another workgroup will read: written through (sc1), see k_merkle_top
+                    __hip_atomic_store(o + j, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(o + 4 + j, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    o[j] = lo;
+                    o[4 + j] = hi;
+                }
+            }
         }
-        __syncthreads();
+        b3::lds_barrier();  // the level's global stores stay in flight
         src = dst;
         par_off += n_level;
         n_level >>= 1;
@@ -299,10 +307,13 @@ __device__ __forceinline__ const uint32_t* reduce_in_lds(SubLds& lds, uint32_t c
     return src;
 }
 
+template <bool SC1>
 __device__ __forceinline__ void stage_nodes(SubLds& lds, const uint32_t* nodes, uint32_t count) {
     // count nodes x 8 words, coalesced read, transposed into [word][node]
-    for (uint32_t e = threadIdx.x; e < 8 * count; e += SUB_NTH) lds.in[(e & 7) * SUB_S + (e >> 3)] = nodes[e];
-    __syncthreads();
+    for (uint32_t e = threadIdx.x; e < 8 * count; e += SUB_NTH)
+        lds.in[(e & 7) * SUB_S + (e >> 3)] =
+            SC1 ? __hip_atomic_load(nodes + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : nodes[e];
+    __syncthreads();  // (waits for the loads: their values are what goes to LDS)
 }
 
 __global__ void __launch_bounds__(SUB_NTH)
@@ -324,22 +335,33 @@ k_merkle_top(uint32_t* __restrict__ tree, unsigned log_leaves, unsigned first_le
     const uint32_t S = 1u << log_s;
     const uint32_t n_sub = (uint32_t)(n_level >> log_s);
     const uint64_t sub0 = (uint64_t)blockIdx.x * S;
-    stage_nodes(lds, tree + 8 * (off + sub0), S);
-    const uint32_t* top = reduce_in_lds(lds, S, tree, off + n_level, n_level >> 1, sub0, moff);
+    stage_nodes<false>(lds, tree + 8 * (off + sub0), S);
+    const uint32_t* top = reduce_in_lds(lds, S, tree, off + n_level, n_level >> 1, sub0, moff, n_sub > 1);
     bool finisher = n_sub == 1;
     if (n_sub > 1) {
-        // publish this sub-root (already stored by reduce_in_lds), then take a ticket
-        __threadfence();
+        // Hand-off between workgroups.  Per-XCD L2s are not coherent with each other and a CU's L1
+        // is never refreshed by another CU's stores, so (MI355X_MICROARCH.md, "Valid forms" and its
+        // table of measured hand-offs): every handed-off byte -- the 32-byte sub-root -- is stored
+        // sc1 (written through, dropped from the XCD's L2) and loaded sc1 (bypassing L1); the
+        // storing wave drains its stores, the workgroup meets, ONE lane adds to the ticket counter
+        // at agent scope; the workgroup whose add came last loads after a barrier behind that add.
+        // No release/acquire fence: those cost 2-6 us each here, more than the levels themselves.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (threadIdx.x == 0) s_last = atomicAdd(ticket, 1u) == n_sub - 1 ? 1u : 0u;
+        if (threadIdx.x == 0) {
+            // (counting in groups of 16 workgroups on separate lines, to spare the one word 256
+            // adds from eight XCDs, measured 26.9 against 27.7 us per 2^16-leaf tree: not worth it)
+            const uint32_t tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = tk == n_sub - 1 ? 1u : 0u;
+        }
         __syncthreads();
         if (s_last) {
-            __threadfence();  // acquire: the other workgroups' sub-roots
             uint64_t off2 = off;
             for (unsigned l = 0; l < log_s; l++) off2 += (uint64_t)1 << (log_leaves - first_level - l);
-            stage_nodes(lds, tree + 8 * off2, n_sub);
-            top = reduce_in_lds(lds, n_sub, tree, off2 + n_sub, n_sub >> 1, 0, moff);
-            if (threadIdx.x == 0) *ticket = 0;  // ready for the next launch on this stream
+            stage_nodes<true>(lds, tree + 8 * off2, n_sub);
+            top = reduce_in_lds(lds, n_sub, tree, off2 + n_sub, n_sub >> 1, 0, moff, false);
+            if (threadIdx.x == 0)  // ready for the next launch on this stream
+                __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             finisher = true;
         }
     }

@@ -55,11 +55,11 @@ def workload(name: str, log_n: int, need_host_trace: bool):
     if name == "config5":  # build-defined stand-in for the RISC0-recursion-style AIR
         from tapstark_amd.airs import SynthExtAir, generate_synth_ext_trace
         air = SynthExtAir(163)
-        host = generate_synth_ext_trace(n, 163)  # no device generator for this one: uploaded
+        host = generate_synth_ext_trace(n, 163) if need_host_trace else None
         pis = np.zeros(0, dtype=np.uint32)
         desc = (f"SynthExt-163 (build-defined, EF4 multiplication constraints), trace 2^{log_n}x163, "
                 "log_blowup=4, 16 queries, pow 8")
-        return air, host, pis, desc, (4, 16, 8), (n, 163), lambda c: ts.DeviceMatrix.upload(c, host)
+        return air, host, pis, desc, (4, 16, 8), (n, 163), lambda c: ts.DeviceMatrix.synth_ext(c, n, 163)
     if name == "config2":
         air = FibonacciAir()
         trace = generate_fibonacci_trace(0, 1, n) if need_host_trace else None
@@ -80,7 +80,7 @@ def algorithmic_bytes_per_proof(n: int, w: int, b: int, qd: int) -> dict:
     wall = w + 4 * qd  # every committed column (trace + quotient chunks)
     fri_elems = 2 * N  # sum over rounds of the folded vector lengths (N + N/2 + ...)
     # Merkle parents (64 B read + 32 B written each): two N-leaf trees + FRI trees (N/2 + N/4 + ..);
-    # levels with > 2^16 children go through k_merkle_level, the rest through the subtree kernel
+    # levels with > 2^16 children go through k_merkle_level, the rest through k_merkle_top
     parents_all = 3 * N  # N - 1 per N-leaf tree, and N/2 + N/4 + ... over the FRI trees
     # per-level launches take the levels with >= 2^16 parents (two parents per thread from 2^18 up)
     lvl2 = lvl1 = 0
@@ -107,7 +107,7 @@ def algorithmic_bytes_per_proof(n: int, w: int, b: int, qd: int) -> dict:
         "k_leaf_hash_ef_pairs": 16 * N + 16 * N,
         "k_merkle_level<2>": 96 * lvl2,
         "k_merkle_level<1>": 96 * lvl1,
-        "(k_merkle_subtree<NTH, LOG_S>)": 96 * small,
+        "k_merkle_top": 96 * small,
         "k_selectors": 12 * n * qd,
         "k_quotient_jit": 4 * n * qd * w + 12 * n * qd + 16 * n * qd,
         "k_quotient<256>": 4 * n * qd * w + 12 * n * qd + 16 * n * qd,
@@ -119,9 +119,20 @@ def algorithmic_bytes_per_proof(n: int, w: int, b: int, qd: int) -> dict:
     }
 
 
-def cpu_baseline(target_seconds: float = 30.0) -> dict:
-    """The oracle prover (oracle/, a C port of the reference's algorithm) on this box's host
-    cores, on a bounded sample of the same workload."""
+def _omp_set_threads(n: int):
+    import ctypes
+    try:
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(int(n))
+    except OSError:
+        pass
+
+
+def cpu_baseline(target_seconds: float = 20.0) -> dict:
+    """The oracle prover (oracle/, a C port of the reference's algorithm: the Rust reference cannot
+    be built here) on this box's host cores, on a bounded sample of the same workload: the median
+    of 5 runs after a warm-up with every core of the GPU's share, plus one
+    1-thread sample -- the reference as configured is single-threaded (no manifest enables
+    p3-maybe-rayon's `parallel`)."""
     import tapstark_amd as ts
     from oracle import oracle_py as orc
     from tapstark_amd.airs import SynthMulAir, generate_synth_mul_trace
@@ -134,26 +145,39 @@ def cpu_baseline(target_seconds: float = 30.0) -> dict:
     tape = ts.air_tape(air, 0)
     cfg = orc.FriConfig(2, 28, 8)
     orc.prove(cfg, tape, generate_synth_mul_trace(1 << 8), [])  # thread-pool warm-up
-    # size the sample from a probe: the largest 2^k <= 2^20 rows expected to take <= target_seconds
-    probe = 16
-    probe_trace = generate_synth_mul_trace(1 << probe)
-    est = 1e9
-    for _ in range(2):  # the first call also pays first-touch costs; keep the faster one
+    _omp_set_threads(cores)
+
+    def timed(trace):
         t0 = time.perf_counter()
-        orc.prove(cfg, tape, probe_trace, [], cap_words=1 << 22)
-        est = min(est, time.perf_counter() - t0)
+        orc.prove(cfg, tape, trace, [], cap_words=1 << 22)
+        return time.perf_counter() - t0
+
+    # size the sample from a probe: the largest 2^k <= 2^20 rows for which 1 warm-up + 5 runs fit
+    probe = 15
+    probe_trace = generate_synth_mul_trace(1 << probe)
+    est = min(timed(probe_trace), timed(probe_trace))
     log_n = probe
-    while log_n < 20 and est * 2 <= target_seconds:
+    while log_n < 20 and est * 2 * 6 <= target_seconds:
         est *= 2
         log_n += 1
     trace = generate_synth_mul_trace(1 << log_n)
-    t0 = time.perf_counter()
-    orc.prove(cfg, tape, trace, [], cap_words=1 << 22)
-    dt = time.perf_counter() - t0
+    timed(trace)  # warm-up at size
+    runs = sorted(timed(trace) for _ in range(5))
+    dt = runs[2]
+    # one thread, on a sample 1/8 the size (about the same wall time)
+    log_n1 = max(log_n - 3, 10)
+    trace1 = generate_synth_mul_trace(1 << log_n1)
+    _omp_set_threads(1)
+    dt1 = min(timed(trace1), timed(trace1))
+    _omp_set_threads(cores)
     return {"value": (64 << log_n) / dt, "unit": "trace cells/sec", "cores": cores, "kind": "port",
-            "sample": f"one oracle prove() of SynthMulAir-64 2^{log_n}x64, log_blowup=2, 28 queries "
-                      f"({dt:.2f} s, OpenMP over {cores} host threads)",
-            "proofs_per_sec": 1.0 / dt}
+            "sample": f"oracle prove() of SynthMulAir-64 2^{log_n}x64, log_blowup=2, 28 queries: median of 5 "
+                      f"runs after a warm-up ({runs[0]:.2f}..{runs[4]:.2f} s, median {dt:.2f} s), OpenMP over "
+                      f"{cores} host threads",
+            "proofs_per_sec": 1.0 / dt,
+            "runs_s": [round(r, 3) for r in runs],
+            "one_thread": {"value": (64 << log_n1) / dt1, "unit": "trace cells/sec", "cores": 1,
+                           "sample": f"the same prover on 2^{log_n1}x64, best of 2 ({dt1:.2f} s), 1 thread"}}
 
 
 def main():
@@ -245,17 +269,29 @@ def main():
                 gr = dist.new_group(list(range(gi * gsize, (gi + 1) * gsize)))
                 if env.rank // gsize == gi:
                     group = gr
-        comm = TorchComm(dev, group=group)
         grank = env.rank % gsize
+        # the collectives: the library's own RCCL communicator (csrc/comm.cpp: ncclAllGather /
+        # ncclBroadcast on the context's stream; what a Rust host would link), bootstrapped with a
+        # unique id made by each group's first rank and handed round over torch.distributed;
+        # TS_BENCH_COMM=torch uses the torch.distributed callbacks (tap-stark_amd/dist.py) instead
+        use_native = os.environ.get("TS_BENCH_COMM", "rccl") == "rccl" and dist.get_backend() == "nccl"
+        if use_native:
+            from tapstark_amd import comm as tcomm
+            ids = [None] * dist.get_world_size()
+            dist.all_gather_object(ids, tcomm.rccl_unique_id() if grank == 0 else None)
+            comm = tcomm.RcclComm(ctx, ids[(env.rank // gsize) * gsize], grank, gsize)
+            comm.backend = "rccl (native ts_comm)"
+        else:
+            comm = TorchComm(dev, group=group)
         # every rank generates the whole trace on its own device (ts_trace_*): nothing to exchange
         # for the input; TS_BENCH_SLICED=1 hands out row slices instead (adds the trace all-gather)
         sliced = bool(os.environ.get("TS_BENCH_SLICED"))
         if sliced:
             full = make_trace(ctx).download()
             rows = np.ascontiguousarray(full[grank * n // gsize:(grank + 1) * n // gsize])
-            mats = [ts.DeviceMatrix.upload(ctx, rows) for _ in range(total)]
+            mats = [ts.DeviceMatrix.upload(ctx, rows) for _ in range(total + 1)]
         else:
-            mats = [make_trace(ctx) for _ in range(total)]
+            mats = [make_trace(ctx) for _ in range(total + 1)]
 
         def prove_one(i):
             last["proof"] = ts.prove_sharded(config, cair, ts.BfChallenger(), mats[i], pis, comm,
@@ -321,8 +357,18 @@ def main():
     # sharded: the ranks of a group share each step's n*w cells
     res = run_timed(env, step, args.steps, args.warmup, local_sync,
                     units_per_step=float(n * w) / (gsize if sharded else 1), run_steps=run_steps)
+    shard_stages = None
     if sharded:
         res["steps_per_sec"] = n_groups * args.steps / res["elapsed_s"]
+        # one more proof with the stage timers on, on every rank: where a rank's time goes
+        ctx.set_timing(True)
+        prove_one(total)
+        mine = {}
+        for k, v in ctx.take_timings():
+            mine[k] = round(mine.get(k, 0.0) + v, 3)
+        ctx.set_timing(False)
+        shard_stages = [None] * dist.get_world_size()
+        dist.all_gather_object(shard_stages, mine)
 
     out = None
     if env.rank == 0:
@@ -364,28 +410,102 @@ def main():
         # HBM traffic of that kernel from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE and
         # --pmc WRITE_SIZE in separate passes, KiB units, FETCH_SIZE doubled for gfx950:
         # profiles/*_pmc_traffic.json, made from tools/prof_prove.py); bytes per launch, or null
-        traffic = None
+        # NOT measured in this run (PMC collection needs rocprofv3 around the process): the file it
+        # comes from and that file's hash are reported beside it
+        traffic, traffic_source = None, None
         try:
             import glob
-            pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
-            if pmc_files and args.workload == "config3" and args.log_n == 20:  # what was profiled
+            import hashlib
+            tag = {"config3": "", "config2": "config2_", "config4": "config4_"}.get(args.workload)
+            pmc_files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json"))
+                               if tag is not None and (("config" in os.path.basename(f)) == bool(tag))
+                               and (not tag or tag in os.path.basename(f)))
+            if pmc_files and args.log_n == (22 if args.workload == "config4" else 20):
                 ks = json.load(open(pmc_files[-1]))["kernels"]
                 stem = dom.strip("()").rstrip(">")  # "k_lde_mid<1" matches "k_lde_mid<1, 8192, 512>"
                 pk = ks.get(dom) or next((v for k, v in ks.items() if k.startswith(stem)), None)
                 if pk:
                     traffic = round((pk["fetch_bytes_per_proof_corrected"] + pk["write_bytes_per_proof"])
                                     / pk["launches_per_proof"])
+                    traffic_source = {
+                        "file": os.path.relpath(pmc_files[-1], ROOT),
+                        "sha256": hashlib.sha256(open(pmc_files[-1], "rb").read()).hexdigest(),
+                        "note": "static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run "
+                                "(tools/prof_prove.py), not collected in this run"}
         except Exception:
-            traffic = None
+            traffic, traffic_source = None, None
         lpp = kt[dom][0] / reps
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved / 1e9, 2),
                     "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 4),
-                    "traffic": traffic,
+                    "traffic": traffic, "traffic_source": traffic_source,
                     "alg_bytes_per_launch": round((alg_bytes(dom) or 0) / lpp) if lpp else None,
                     "avg_launch_ms": round(kt[dom][1] / kt[dom][0], 5),
                     "launches_per_proof": kt[dom][0] / reps,
                     "alg_bytes_per_proof": alg_bytes(dom),
                     "kernel_ms_total_per_proof": round(sum(v[1] for v in kt.values()) / reps, 3)}
+        # ---- the stage and the whole job against the same roofline (SURVEY.md section 8(d) terms)
+        N_ = n << cfg[0]
+        wall_ = w + 4 * qd
+        A1 = 4 * n * w + 4 * N_ * w            # trace LDE: read n x w, write N x w
+        C1 = 16 * n * qd + 16 * N_ * qd        # chunk LDE
+        whole = (A1 + 32 * (2 * N_ - 1) + (4 * n * qd * w + 16 * n * qd) + C1 + 32 * (2 * N_ - 1)
+                 + (4 * N_ * w + 16 * N_ * qd + 16 * N_) + (32 * N_ + 16 * N_ + 64 * N_))
+        lde_ms = stage_sum.get("coset_lde")
+        roofline_stage = None
+        if lde_ms:
+            roofline_stage = {"stage": "coset_lde (trace + quotient chunks)", "alg_bytes": A1 + C1,
+                              "ms": lde_ms, "achieved": round((A1 + C1) / (lde_ms * 1e-3) / 1e9, 1),
+                              "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                              "frac": round((A1 + C1) / (lde_ms * 1e-3) / HBM_PEAK, 4),
+                              "note": "single proof alone on the GPU; the stage is three passes (60 n W bytes "
+                                      "moved for 20 n W algorithmic) and VALU-bound, see alu_ceiling"}
+        roofline_whole = {"alg_bytes_per_proof": whole, "ms_per_step": round(res["ms_per_step"], 4),
+                          "achieved": round(whole / (res["ms_per_step"] * 1e-3) / 1e9, 1), "peak": HBM_PEAK / 1e9,
+                          "unit": "GB/s", "frac": round(whole / (res["ms_per_step"] * 1e-3) / HBM_PEAK, 4)}
+        # ---- the integer-ALU ceiling, measured in this run with the library's own arithmetic
+        log_n_ = n.bit_length() - 1
+        butterflies = wall_ * (n // 2) * log_n_ * (1 + (1 << cfg[0]))
+        compressions = N_ * ((4 * w + 63) // 64) + N_ * ((16 * qd + 63) // 64) + N_ + 3 * N_
+
+        def ms_of(*names):
+            return sum(v["ms_per_proof"] for k, v in per_kernel.items() if any(x in k for x in names))
+        bf_peak, b3_peak = ctx.alu_ceiling(0), ctx.alu_ceiling(1)
+        ntt_ms = ms_of("k_intt_contig", "k_lde_mid", "k_lde_fwd_contig")
+        b3_ms = ms_of("k_leaf_hash", "k_merkle_level", "k_merkle_top", "k_merkle_subtree")
+        alu_ceiling = {
+            "butterflies_per_s_peak": round(bf_peak), "butterflies_per_proof": butterflies,
+            "ntt_kernels_ms": round(ntt_ms, 4), "ntt_ms_at_peak": round(butterflies / bf_peak * 1e3, 4),
+            "ntt_frac_of_alu_peak": round(butterflies / bf_peak * 1e3 / ntt_ms, 4) if ntt_ms else None,
+            "blake3_compressions_per_s_peak": round(b3_peak), "blake3_compressions_per_proof": compressions,
+            "merkle_kernels_ms": round(b3_ms, 4), "merkle_ms_at_peak": round(compressions / b3_peak * 1e3, 4),
+            "merkle_frac_of_alu_peak": round(compressions / b3_peak * 1e3 / b3_ms, 4) if b3_ms else None,
+            "note": "peaks from ts_bench_alu (register-resident loops of the same butterfly / compression code, "
+                    "no memory traffic); FRI-round leaf hashes fused into the fold kernel are not in merkle_kernels_ms"}
+        # ---- the rate a caller sees who hands over HOST traces (never `value`): pinned buffer,
+        # asynchronous upload on each lane's stream, the upload of one lane overlapping the proofs of the others
+        h2d = None
+        if not sharded and not args.host_traces and args.workload in ("config3", "config2") and S > 1:
+            try:
+                pin = ts.PinnedHostMatrix(n, w)
+                pin.array[:] = make_trace(ctx).download()
+                k2 = 6 * S
+
+                def h2d_job(l):
+                    c, conf, ca = lanes[l]
+                    for _ in range(k2 // S):
+                        ts.prove(conf, ca, ts.BfChallenger(), ts.DeviceMatrix.upload_async(c, pin), pis)
+                list(pool.map(h2d_job, range(S)))  # warm-up
+                local_sync()
+                t0 = time.perf_counter()
+                list(pool.map(h2d_job, range(S)))
+                local_sync()
+                dt_h = time.perf_counter() - t0
+                h2d = {"ms_per_step": round(1e3 * dt_h / k2, 4), "steps": k2,
+                       "h2d_GB_per_s": round(n * w * 4 * k2 / dt_h / 1e9, 1),
+                       "note": "every step uploads its trace from page-locked host memory inside the timed "
+                               "region (hipMemcpyAsync on the lane's stream); PCIe Gen5 x16 bounds it"}
+            except Exception as e:  # never let the extra leg take the headline down
+                h2d = {"error": repr(e)}
         cpu = None if args.no_cpu_baseline else cpu_baseline()
         proof = last["proof"]
         out = {
@@ -411,8 +531,10 @@ def main():
             # one proof alone on the GPU, HIP events around ts_prove (the `value` above keeps
             # several in flight; this is the latency a single caller sees)
             "single_proof_latency_ms": stage_sum.get("prove"),
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "roofline_stage": roofline_stage, "roofline_whole": roofline_whole,
+            "alu_ceiling": alu_ceiling, "h2d_inclusive": h2d, "cpu_baseline": cpu,
             "stages_ms": stage_sum,
+            "shard_stages_ms_per_rank": shard_stages,
             "kernels": per_kernel,
         }
     if sharded and env.dist is None:

@@ -73,6 +73,13 @@ ts_status ts_ctx_take_kernel_timings(ts_ctx* ctx, char* buf, size_t cap);
 ts_status ts_matrix_upload(ts_ctx* ctx, const uint32_t* host_row_major, uint64_t height,
                            uint32_t width, ts_matrix** out);
 /* same from a device pointer (e.g. a torch tensor's data_ptr); the data is copied */
+/* The same without waiting for the copy: `host_pinned` must come from ts_host_alloc (page-locked:
+ * the copy then runs at the full PCIe rate, asynchronously on the context's stream) and must stay
+ * untouched until the next ts_ctx_synchronize / blocking call on this context. */
+ts_status ts_matrix_upload_async(ts_ctx* ctx, const uint32_t* host_pinned, uint64_t height,
+                                 uint32_t width, ts_matrix** out);
+ts_status ts_host_alloc(size_t bytes, void** out);
+void ts_host_free(void* p);
 ts_status ts_matrix_from_device(ts_ctx* ctx, const uint32_t* dev_row_major, uint64_t height,
                                 uint32_t width, ts_matrix** out);
 /* Traces generated on the device (no H2D).  ts_trace_fibonacci = generate_trace_rows(a, b, n) of
@@ -375,6 +382,11 @@ ts_status ts_tap_mmcs_verify_batch(const uint8_t* lock_scripts, const uint64_t* 
                                    const uint32_t* opened_values, const uint8_t* path, uint32_t depth,
                                    const uint8_t root[32], int* ok);
 void ts_tap_mmcs_free(ts_tap_mmcs_data* d);
+
+/* Measurement aid: the whole-chip rate of NTT butterflies (kind 0) or Blake3 compressions (kind 1)
+ * with no memory traffic, using the library's own arithmetic -- the integer-ALU ceiling bench.py
+ * reports beside the achieved rates. */
+ts_status ts_bench_alu(ts_ctx* ctx, int kind, double* units_per_second);
 
 /* library/ABI version (bumped on any incompatible change) */
 uint32_t ts_abi_version(void);

@@ -29,6 +29,7 @@ ABI_SYMBOLS = [
     "ts_proof_to_postcard", "ts_proof_from_postcard",
     "ts_rccl_available", "ts_rccl_unique_id", "ts_comm_rccl_create", "ts_comm_rccl_destroy",
     "ts_comm_local_group_create", "ts_comm_local_get", "ts_comm_local_group_destroy",
+    "ts_bench_alu", "ts_host_alloc", "ts_host_free", "ts_matrix_upload_async",
     "ts_tapleaf_hash", "ts_tapbranch_hash", "ts_tap_winternitz_lock_script", "ts_tap_leaf_script",
     "ts_taptree_from_scripts", "ts_taptree_combine", "ts_taptree_info", "ts_taptree_leaf_proof",
     "ts_taptree_verify_inclusion", "ts_taptree_free", "ts_tap_mmcs_commit", "ts_tap_mmcs_info",
@@ -165,6 +166,11 @@ def lib() -> C.CDLL:
         l.ts_comm_local_group_destroy.restype = None
         u64p = C.POINTER(C.c_uint64)
         szp = C.POINTER(C.c_size_t)
+        l.ts_bench_alu.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
+        l.ts_host_alloc.argtypes = [C.c_size_t, voidpp]
+        l.ts_host_free.argtypes = [C.c_void_p]
+        l.ts_host_free.restype = None
+        l.ts_matrix_upload_async.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, voidpp]
         l.ts_tapleaf_hash.argtypes = [C.c_char_p, C.c_size_t, u8p]
         l.ts_tapbranch_hash.argtypes = [u8p, u8p, u8p]
         l.ts_tap_winternitz_lock_script.argtypes = [C.c_char_p, C.c_size_t, C.c_uint32, u8p, C.c_size_t, szp]

@@ -198,9 +198,24 @@ ts_status ts_ctx_take_kernel_timings(ts_ctx* ctx, char* buf, size_t cap) {
     });
 }
 
+ts_status ts_bench_alu(ts_ctx* ctx, int kind, double* units_per_second) {
+    if (!ctx || !units_per_second) return TS_ERR_INVALID;
+    return guard(ctx, [&] { *units_per_second = ts::alu_ceiling(ctx->ctx, kind); });
+}
+
+// pinned host memory for traces handed over as host buffers (PCIe at full rate, truly async copies)
+ts_status ts_host_alloc(size_t bytes, void** out) {
+    if (!out || bytes == 0) return TS_ERR_INVALID;
+    *out = nullptr;
+    return hipHostMalloc(out, bytes, hipHostMallocDefault) == hipSuccess ? TS_OK : TS_ERR_OOM;
+}
+void ts_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
+}
+
 // ------------------------------------------------------------------ matrices
 static ts_status matrix_from(ts_ctx* ctx, const uint32_t* src, uint64_t height, uint32_t width,
-                             hipMemcpyKind kind, ts_matrix** out) {
+                             hipMemcpyKind kind, ts_matrix** out, bool sync = true) {
     if (!ctx || !out) return TS_ERR_INVALID;
     *out = nullptr;
     return guard(ctx, [&] {
@@ -213,13 +228,17 @@ static ts_status matrix_from(ts_ctx* ctx, const uint32_t* src, uint64_t height, 
         m->m.width = width;
         m->m.layout = ts::DeviceMatrix::ROW_MAJOR;
         TS_HIP(hipMemcpyAsync(m->m.buf.p, src, (size_t)height * width * 4, kind, ctx->ctx.stream));
-        ctx->ctx.sync();
+        if (sync) ctx->ctx.sync();
         *out = m.release();
     });
 }
 ts_status ts_matrix_upload(ts_ctx* ctx, const uint32_t* host, uint64_t height, uint32_t width,
                            ts_matrix** out) {
     return matrix_from(ctx, host, height, width, hipMemcpyHostToDevice, out);
+}
+ts_status ts_matrix_upload_async(ts_ctx* ctx, const uint32_t* host_pinned, uint64_t height,
+                                 uint32_t width, ts_matrix** out) {
+    return matrix_from(ctx, host_pinned, height, width, hipMemcpyHostToDevice, out, false);
 }
 ts_status ts_matrix_from_device(ts_ctx* ctx, const uint32_t* dev, uint64_t height, uint32_t width,
                                 ts_matrix** out) {

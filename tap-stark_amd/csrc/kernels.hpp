@@ -188,6 +188,10 @@ void launch_gather_fri(Context& ctx, const FriGatherDesc* d_descs, uint32_t n_ro
                        uint32_t max_log_leaves, const uint32_t* d_indices, uint32_t n_idx,
                        uint32_t* out);
 
+// ---- alubench.hip ---------------------------------------------------------------------------
+// whole-chip rate of NTT butterflies (kind 0) or Blake3 compressions (kind 1), no memory traffic
+double alu_ceiling(Context& ctx, int kind);
+
 // ---- tracegen.hip ----------------------------------------------------------------------------
 // row-major traces generated in place (no H2D): Fibonacci (uni-stark/tests/fib_air.rs:59-78) and the
 // build-defined SynthMulAir-w trace (airs.py generate_synth_mul_trace)

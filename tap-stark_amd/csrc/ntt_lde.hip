@@ -389,8 +389,9 @@ void coset_lde(Context& ctx, uint32_t* evals, uint64_t in_col_stride, uint32_t n
     TS_REQUIRE(ncols >= 1 && ncols <= 65535, TS_ERR_INVALID, "coset_lde: bad column count");
     const bool two_pass = log_n > (unsigned)LOG_M;
     const unsigned sA = two_pass ? log_n - LOG_M : 0;  // stages done by the strided (middle) kernel
-    TS_REQUIRE((1u << sA) <= (unsigned)TILE_ELEMS, TS_ERR_UNSUPPORTED,
-               "coset_lde: trace longer than 2^25 rows is not supported yet");
+    // sA <= 13 fits the 8192-element tile; sA = 14 (n = 2^26, the longest trace a blowup of 2 leaves
+    // room for below the two-adicity 27) takes a 16384-element tile (68 KB of LDS)
+    TS_REQUIRE(sA <= 14, TS_ERR_INVALID, "coset_lde: log_n > 26");
     ctx.ensure_twiddles(log_n == 0 ? 1 : log_n);
     const uint32_t* W = ctx.d_twiddle_fwd;
     const uint32_t* Winv = ctx.d_twiddle_inv;
@@ -408,7 +409,7 @@ void coset_lde(Context& ctx, uint32_t* evals, uint64_t in_col_stride, uint32_t n
         return e ? atoi(e) : 1024;  // 114 VGPRs, 16 waves per CU; 512 threads: 191 VGPRs, 8 waves
     }();
     const bool plan2 = two_pass && sA == 10 && plan2_tile != 0;
-    if (two_pass) {
+    if (two_pass && sA <= 13) {
         while ((1u << (sA + log_T + 1)) <= (unsigned)TILE_ELEMS && log_T < 6) log_T++;
         if (plan2) log_T = plan2_tile == 8192 ? 3 : (plan2_tile == 16384 ? 4 : 5);
     }
@@ -423,13 +424,21 @@ void coset_lde(Context& ctx, uint32_t* evals, uint64_t in_col_stride, uint32_t n
         // the vectorised chunk loads need 16-byte aligned columns
         TS_REQUIRE(in_col_stride % 4 == 0 && out_col_stride % 4 == 0, TS_ERR_INVALID,
                    "coset_lde: column strides must be multiples of 4 elements");
-        TS_LAUNCH(ctx, k_intt_contig, dim3(1u << sA, ncols), dim3(NT), 0, evals, in_col_stride, log_n,
-                  Winv);
+        {
+            // (stage names: the sharded prover reports where a rank's time goes; this part is the
+            // one every rank repeats for all columns)
+            StageTimer t(&ctx, "lde: inverse NTT, contiguous stages (replicated when sharded)");
+            TS_LAUNCH(ctx, k_intt_contig, dim3(1u << sA, ncols), dim3(NT), 0, evals, in_col_stride, log_n,
+                      Winv);
+        }
+        StageTimer t_rest(&ctx, "lde: strided pass + forward NTT of the owned cosets");
         const dim3 grid(1u << (LOG_M - log_T), ncols);
 #define TS_MID_ARGS                                                                            \
     (const uint32_t*)evals, in_col_stride, out, out_col_stride, log_n, sA, log_T, (unsigned)LOG_M, \
         beta0, n_beta, W, Winv, scale
-        if (plan2 && plan2_tile == 8192)
+        if (sA == 14)
+            TS_LAUNCH(ctx, (k_lde_mid<0, 16384>), grid, dim3(NT_MID), 0, TS_MID_ARGS);
+        else if (plan2 && plan2_tile == 8192)
             TS_LAUNCH(ctx, (k_lde_mid<2, 8192>), grid, dim3(NT_MID), 0, TS_MID_ARGS);
         else if (plan2 && plan2_tile == 16384 && plan2_threads == 1024)
             TS_LAUNCH(ctx, (k_lde_mid<2, 16384, 1024>), grid, dim3(1024), 0, TS_MID_ARGS);

@@ -56,6 +56,12 @@ class Context:
     def stream(self) -> int:
         return int(self._l.ts_ctx_stream(self.h) or 0)
 
+    def alu_ceiling(self, kind: int) -> float:
+        """Whole-chip NTT butterflies/s (kind 0) or Blake3 compressions/s (kind 1), no memory traffic."""
+        r = C.c_double()
+        self.check(self._l.ts_bench_alu(self.h, kind, C.byref(r)))
+        return float(r.value)
+
     def set_timing(self, enabled: bool):
         self.check(self._l.ts_ctx_set_timing(self.h, int(enabled)))
 
@@ -106,6 +112,27 @@ def default_context() -> Context:
     return _default_ctx
 
 
+class PinnedHostMatrix:
+    """A row-major u32 matrix in page-locked host memory (``ts_host_alloc``), as a numpy view."""
+
+    def __init__(self, height: int, width: int):
+        self.shape = (height, width)
+        p = C.c_void_p()
+        rc = _lib.lib().ts_host_alloc(height * width * 4, C.byref(p))
+        if rc:
+            raise _lib.TsError(rc, "ts_host_alloc")
+        self.ptr = p
+        self.array = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint32)), shape=(height, width))
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                _lib.lib().ts_host_free(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
 class DeviceMatrix:
     """``RowMajorMatrix<Val>`` resident in HBM (``ts_matrix``)."""
 
@@ -120,6 +147,13 @@ class DeviceMatrix:
         h = C.c_void_p()
         ctx.check(ctx._l.ts_matrix_upload(ctx.h, _p(values), values.shape[0], values.shape[1],
                                           C.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def upload_async(cls, ctx: Context, pinned: "PinnedHostMatrix") -> "DeviceMatrix":
+        """H2D from page-locked memory without waiting (``ts_matrix_upload_async``)."""
+        h = C.c_void_p()
+        ctx.check(ctx._l.ts_matrix_upload_async(ctx.h, pinned.ptr, pinned.shape[0], pinned.shape[1], C.byref(h)))
         return cls(ctx, h)
 
     @classmethod

@@ -78,3 +78,44 @@ def test_commit_more_than_16_matrices(ctx, orc):
     root2, data2 = pcs.commit([((6 - i % 3, 1), m.copy()) for i, m in enumerate(mats)])
     ldes = [orc.commit_lde(m, 1, 1) for m in mats]
     assert (root2 == orc.OracleMmcs(ldes).root).all()
+
+
+def test_commit_longest_trace_2pow26(ctx, orc):
+    # the longest trace the field allows at log_blowup 1: n = 2^26, LDE of 2^27 rows = the whole
+    # two-adic subgroup (two_adic_pcs.rs:233-241).  The oracle is too slow to diff against at this
+    # size: the column is the evaluation of c1 X + c2 X^2 on H_n (built by doubling), so every LDE
+    # row is known in closed form; a random sample of rows, the leaf digests under them and the
+    # Merkle paths above them are checked.
+    P = 0x78000001
+    log_n, b = 26, 1
+    n, N = 1 << log_n, 1 << (log_n + b)
+    w_n = pow(0x1A427A41, 1 << (27 - log_n), P)
+    x = np.ones(n, dtype=np.uint64)
+    m, step = 1, w_n
+    while m < n:  # x[i] = w_n^i
+        x[m:2 * m] = x[:m] * np.uint64(step) % np.uint64(P)
+        step = step * step % P
+        m *= 2
+    c1, c2 = 123456789, 987654321
+    col = (np.uint64(c1) * x % np.uint64(P) + np.uint64(c2) * (x * x % np.uint64(P)) % np.uint64(P)) % np.uint64(P)
+    del x
+    pcs = ts.TwoAdicFriPcs(ts.FriConfig(b, 2, 0), ctx)
+    root, data = pcs.commit([((log_n, 1), col.astype(np.uint32).reshape(n, 1))])
+    del col
+    assert data.log_height == log_n + b
+    W_N = pow(0x1A427A41, 1 << (27 - (log_n + b)), P)
+    rng = np.random.default_rng(5)
+    leaves = data.digests(0)
+    for r in [0, 1, N - 1, N // 2] + [int(v) for v in rng.integers(0, N, 40)]:
+        j = int(format(r, f"0{log_n + b}b")[::-1], 2)
+        y = 31 * pow(W_N, j, P) % P
+        want = (c1 * y + c2 * y * y) % P
+        rows, path = data.open_batch(r)
+        assert int(rows[0]) == want, f"row {r}"
+        assert leaves[r].astype("<u4").tobytes() == orc.blake3(int(want).to_bytes(4, "little"))
+        om_ok = orc.OracleMmcs.verify  # the oracle's verify_batch needs only the shape
+        hs = (ts.stark.C.c_size_t * 1)(N)
+        ws = (ts.stark.C.c_size_t * 1)(1)
+        assert orc.lib().ts_or_mmcs_verify(1, hs, ws, ts.stark.C.c_size_t(r), ts.stark._p(rows),
+                                           ts.stark._p(path), ts.stark.C.c_size_t(path.shape[0]),
+                                           ts.stark._p(root))

@@ -1,7 +1,7 @@
 """profiles/*_pmc_traffic.json from two rocprofv3 --pmc runs (FETCH_SIZE, WRITE_SIZE; separate
 passes) of tools/prof_prove.py.
 
-    pmc_summary.py FETCH_counter_collection.csv WRITE_counter_collection.csv N_PROOFS OUT.json
+    pmc_summary.py FETCH_counter_collection.csv WRITE_counter_collection.csv N_PROOFS OUT.json [config]
 
 Units and corrections follow /opt/skills/guides/MI355X_MICROARCH.md (HBM / rocprofv3 section): both
 counters are in KiB; on gfx950 FETCH_SIZE reports half of the bytes of wide coalesced streaming reads,
@@ -33,11 +33,14 @@ def load(path, counter):
 
 def main():
     f_csv, w_csv, n_proofs, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+    cfg_name = sys.argv[5] if len(sys.argv) > 5 else "config3"
+    shape = {"config3": (1 << 20, 64, 2, 2), "config2": (1 << 20, 2, 2, 1), "config4": (1 << 22, 64, 4, 2),
+             "config5": (1 << 20, 163, 4, 1)}[cfg_name]
     fetch, cnt = load(f_csv, "FETCH_SIZE")
     write, _ = load(w_csv, "WRITE_SIZE")
     sys.path.insert(0, ".")
     from bench import algorithmic_bytes_per_proof
-    alg = algorithmic_bytes_per_proof(1 << 20, 64, 2, 2)
+    alg = algorithmic_bytes_per_proof(*shape)
     if "k_leaf_hash_strided" not in fetch:  # no strided launch: the table kernel hashed everything
         alg["k_leaf_hash<1>"] = alg["k_leaf_hash<2>"]
     if "k_merkle_level<2>" not in fetch:  # every per-level launch went through the <1> kernel
@@ -45,13 +48,13 @@ def main():
     kernels = {}
     for k in sorted(fetch, key=lambda k: -(fetch[k] + write.get(k, 0))):
         a = (alg.get(k) or alg.get(f"({k})") or (alg["k_lde_mid<1>"] if "k_lde_mid" in k else None)
-             or (alg["(k_merkle_subtree<NTH, LOG_S>)"] if "k_merkle_subtree" in k else None))
+             or (alg["k_merkle_top"] if "k_merkle_top" in k else None))
         kernels[k] = {"launches_per_proof": cnt[k] / n_proofs,
                       "fetch_bytes_per_proof_corrected": 2 * 1024 * fetch[k] / n_proofs,
                       "write_bytes_per_proof": 1024 * write.get(k, 0.0) / n_proofs,
                       "alg_bytes_per_proof": a}
     json.dump({"_comment": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) on "
-                           f"tools/prof_prove.py, {n_proofs} proofs of C3; KiB units x1024; FETCH_SIZE "
+                           f"tools/prof_prove.py, {n_proofs} proofs of {cfg_name}; KiB units x1024; FETCH_SIZE "
                            "doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of wide coalesced "
                            "reads); per proof", "kernels": kernels}, open(out, "w"), indent=1)
     for k, v in kernels.items():

@@ -272,7 +272,7 @@ k_lde_mid(const uint32_t* __restrict__ evals, uint64_t in_col_stride, uint32_t* 
     // Tiles narrower than 128 B (log_T < 5) share every cache line they touch with their neighbours:
     // neighbouring tiles go to workgroups of the same XCD (ids 8 apart), whose L2 then merges the
     // pieces of a line (measured on 2^22 x 64, log_blowup 4: 19.6 -> 15.7 ms at 32 B, 14.5 -> 13.8 at 64 B)
-    const bool remap = PLAN != 1 && log_T < 5 && gridDim.x >= 8;
+    const bool remap = PLAN == 0 && log_T < 5 && gridDim.x >= 8;
     uint32_t bx = remap ? (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
     uint32_t col_id = blockIdx.y;
     if constexpr (PLAN == 1) {
@@ -284,6 +284,22 @@ k_lde_mid(const uint32_t* __restrict__ evals, uint64_t in_col_stride, uint32_t* 
         const uint32_t ncols = gridDim.x >> 7;  // 2^(LOG_M - 5) = 128 tiles per column
         bx = (blockIdx.x & 31) + 32 * (blockIdx.x / (32 * ncols));  // < 128
         col_id = (blockIdx.x >> 5) % ncols;
+    }
+    if constexpr (PLAN == 2) {
+        // 1-D grid, n_tiles x ncols workgroups.  The scale table of this shape (n x 2^log_blowup
+        // words: 268 MB for 2^22 rows at log_blowup 4) no longer fits the Infinity Cache; with a
+        // (tiles, columns) grid every column swept the whole table from HBM (rocprofv3 FETCH_SIZE:
+        // 20.5 GB per proof against 1.2 GB of coefficients, profiles/r02_config4_pmc_traffic.json).
+        // Order: workgroup ids go round the 8 XCDs; XCD x owns a contiguous range of tile PAIRS and,
+        // for each pair, runs (tile 2p, col), (tile 2p+1, col) for all columns in turn -- the pair's
+        // 2 MB of table stay in that XCD's L2 for every column, and the two 64-byte halves of every
+        // output line (neighbouring tiles) are still written back to back on one XCD.
+        const uint32_t n_tiles = (uint32_t)(1u << LOG_M) >> log_T;
+        const uint32_t ncols = gridDim.x / n_tiles;
+        const uint32_t x = blockIdx.x & 7, k = blockIdx.x >> 3;
+        const uint32_t pair_local = k / (2 * ncols), r = k % (2 * ncols);
+        col_id = r >> 1;
+        bx = (x * (n_tiles >> 4) + pair_local) * 2 + (r & 1);
     }
     const uint32_t j2_0 = bx << log_T;
     const uint32_t* g = evals + (uint64_t)col_id * in_col_stride + j2_0;
@@ -433,19 +449,20 @@ void coset_lde(Context& ctx, uint32_t* evals, uint64_t in_col_stride, uint32_t n
         }
         StageTimer t_rest(&ctx, "lde: strided pass + forward NTT of the owned cosets");
         const dim3 grid(1u << (LOG_M - log_T), ncols);
+        const dim3 grid1((1u << (LOG_M - log_T)) * ncols);  // PLAN 2: 1-D, see the kernel
 #define TS_MID_ARGS                                                                            \
     (const uint32_t*)evals, in_col_stride, out, out_col_stride, log_n, sA, log_T, (unsigned)LOG_M, \
         beta0, n_beta, W, Winv, scale
         if (sA == 14)
             TS_LAUNCH(ctx, (k_lde_mid<0, 16384>), grid, dim3(NT_MID), 0, TS_MID_ARGS);
         else if (plan2 && plan2_tile == 8192)
-            TS_LAUNCH(ctx, (k_lde_mid<2, 8192>), grid, dim3(NT_MID), 0, TS_MID_ARGS);
+            TS_LAUNCH(ctx, (k_lde_mid<2, 8192>), grid1, dim3(NT_MID), 0, TS_MID_ARGS);
         else if (plan2 && plan2_tile == 16384 && plan2_threads == 1024)
-            TS_LAUNCH(ctx, (k_lde_mid<2, 16384, 1024>), grid, dim3(1024), 0, TS_MID_ARGS);
+            TS_LAUNCH(ctx, (k_lde_mid<2, 16384, 1024>), grid1, dim3(1024), 0, TS_MID_ARGS);
         else if (plan2 && plan2_tile == 16384)
-            TS_LAUNCH(ctx, (k_lde_mid<2, 16384>), grid, dim3(NT_MID), 0, TS_MID_ARGS);
+            TS_LAUNCH(ctx, (k_lde_mid<2, 16384>), grid1, dim3(NT_MID), 0, TS_MID_ARGS);
         else if (plan2)
-            TS_LAUNCH(ctx, (k_lde_mid<2, 32768, 1024>), grid, dim3(1024), 0, TS_MID_ARGS);
+            TS_LAUNCH(ctx, (k_lde_mid<2, 32768, 1024>), grid1, dim3(1024), 0, TS_MID_ARGS);
         else if (sA == 8 && log_T == 5)
             TS_LAUNCH(ctx, k_lde_mid<1>, dim3((1u << (LOG_M - 5)) * ncols), dim3(NT_MID), 0, (const uint32_t*)evals, in_col_stride,
                       out, out_col_stride, log_n, sA, log_T, (unsigned)LOG_M, beta0, n_beta, W, Winv,

@@ -36,6 +36,7 @@ pub struct ts_comm {
 pub struct ts_shard_options {
     pub min_local_log: u32,
     pub trace_replicated: u32,
+    pub column_sharded_inverse: u32,
 }
 
 extern "C" {

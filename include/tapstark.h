@@ -267,6 +267,9 @@ typedef struct {
     uint32_t min_local_log;    /* 0 = default (12) */
     uint32_t trace_replicated; /* 1: `trace_rows` is the WHOLE trace on every rank (e.g. made by
                                   ts_trace_* on each device); the trace all-gather is skipped */
+    uint32_t column_sharded_inverse; /* 1: transposes + the per-column stages of the inverse NTT run
+                                  on w/G columns per rank, followed by an all-gather of the
+                                  half-transformed columns */
 } ts_shard_options;
 ts_status ts_prove_sharded(ts_ctx* ctx, const ts_fri_config* cfg, const ts_comm* comm,
                            const ts_air* air, ts_challenger* chal, ts_matrix* trace_rows,

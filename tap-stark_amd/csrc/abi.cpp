@@ -692,6 +692,7 @@ ts_status ts_prove_sharded(ts_ctx* ctx, const ts_fri_config* cfg, const ts_comm*
             opt.min_local_log = options->min_local_log;
         }
         if (options) opt.trace_replicated = options->trace_replicated != 0;
+        if (options) opt.column_sharded_inverse = options->column_sharded_inverse != 0;
         ts::StageTimer t(&ctx->ctx, "prove");
         std::vector<uint32_t> proof;
         try {

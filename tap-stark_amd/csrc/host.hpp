@@ -168,6 +168,11 @@ struct ShardOptions {
     // true: every rank already holds the WHOLE trace (e.g. generated on each device by
     // ts_trace_*): the one bulk exchange, the all-gather of the trace rows, is skipped
     bool trace_replicated = false;
+    // true: transposes and the contiguous stages of the inverse NTT are done for w/G columns per
+    // rank and the half-transformed columns all-gathered (n w 4 bytes in all), instead of every
+    // rank repeating them for every column.  Trades ~1/4 of a rank's LDE arithmetic for one more
+    // bulk exchange: see DESIGN.md section 6 for when that pays.
+    bool column_sharded_inverse = false;
 };
 // rank g owns the bit-reversed LDE rows [g N/G, (g+1) N/G) (whole cosets,
 // G <= 2^log_blowup) of every committed matrix and the matching Merkle sub-trees, FRI slabs and

@@ -25,8 +25,9 @@ void launch_build_shift_tables(Context& ctx, uint32_t* lo, uint32_t* hi, uint32_
 // LDE applies to coefficient k before the forward transform of coset beta.  Cached per context.
 const uint32_t* coset_scale_table(Context& ctx, unsigned log_n, unsigned log_blowup, uint32_t shift);
 // src: row-major n x w (natural rows)  ->  dst: column-major, rows in bit-reversed order
+// src_width (0 = w): the row length of `src` when only w of its columns (starting at `src`) are taken
 void launch_transpose_bitrev(Context& ctx, const uint32_t* src, uint32_t* dst, unsigned log_n,
-                             uint32_t w, uint64_t dst_col_stride);
+                             uint32_t w, uint64_t dst_col_stride, uint32_t src_width = 0);
 // same without the bit reversal (rows stay where they are): BFMmcs::commit on given matrices
 void launch_transpose_plain(Context& ctx, const uint32_t* src, uint32_t* dst, uint64_t n, uint32_t w,
                             uint64_t dst_col_stride);
@@ -38,9 +39,13 @@ void launch_transpose_to_row_major(Context& ctx, const uint32_t* src, uint64_t c
 //   out: out[c][beta*n + t] = p_c(shift * w_N^bitrev(beta*n+t)),  N = n << log_blowup
 // With a coset range (beta0, n_beta > 0) only the row blocks beta0 .. beta0+n_beta-1 are produced,
 // at out[c][(beta - beta0)*n + t]: the slab of a rank that owns those cosets (sharded prover).
+// phase: LDE_ALL, or the two halves a sharded prover runs either side of its all-gather of the
+// half-transformed columns: LDE_INVERSE_CONTIG (the contiguous stages of the inverse, per column,
+// in place in `evals`; a no-op for n <= 4096) and LDE_REST (everything else).
+enum LdePhase { LDE_ALL = 0, LDE_INVERSE_CONTIG = 1, LDE_REST = 2 };
 void coset_lde(Context& ctx, uint32_t* evals, uint64_t in_col_stride, uint32_t ncols, unsigned log_n,
                unsigned log_blowup, uint32_t shift, uint32_t* out, uint64_t out_col_stride,
-               uint32_t beta0 = 0, uint32_t n_beta = 0);
+               uint32_t beta0 = 0, uint32_t n_beta = 0, LdePhase phase = LDE_ALL);
 
 // ---- merkle.hip ------------------------------------------------------------------------------
 constexpr int MAX_BATCH_MATS = 64;

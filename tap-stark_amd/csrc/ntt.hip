@@ -137,7 +137,8 @@ const uint32_t* coset_scale_table(Context& ctx, unsigned log_n, unsigned log_blo
 // ------------------------------------------------------------------ transposes
 // src row-major [n][w] natural  ->  dst[c][p] = src[bitrev(p)][c]
 __global__ void k_transpose_bitrev(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst,
-                                   unsigned log_n, uint32_t w, uint64_t dst_col_stride) {
+                                   unsigned log_n, uint32_t w, uint64_t dst_col_stride,
+                                   uint32_t src_width) {
     __shared__ uint32_t tile[64][65];
     const unsigned tr = log_n < 6 ? log_n : 6;  // log2 of tile rows
     const uint32_t rows = 1u << tr;
@@ -147,7 +148,7 @@ __global__ void k_transpose_bitrev(const uint32_t* __restrict__ src, uint32_t* _
     for (uint32_t i = ty; i < rows; i += 4) {
         uint32_t r = bitrev32(p0 + i, log_n);
         uint32_t c = c0 + tx;
-        if (c < w) tile[i][tx] = src[(uint64_t)r * w + c];
+        if (c < w) tile[i][tx] = src[(uint64_t)r * src_width + c];
     }
     __syncthreads();
     for (uint32_t cc = ty; cc < 64; cc += 4) {
@@ -157,10 +158,12 @@ __global__ void k_transpose_bitrev(const uint32_t* __restrict__ src, uint32_t* _
 }
 
 void launch_transpose_bitrev(Context& ctx, const uint32_t* src, uint32_t* dst, unsigned log_n,
-                             uint32_t w, uint64_t dst_col_stride) {
+                             uint32_t w, uint64_t dst_col_stride, uint32_t src_width) {
+    if (w == 0) return;
     unsigned tr = log_n < 6 ? log_n : 6;
     dim3 grid(1u << (log_n - tr), (w + 63) / 64);
-    TS_LAUNCH(ctx, k_transpose_bitrev, grid, dim3(256), 0, src, dst, log_n, w, dst_col_stride);
+    TS_LAUNCH(ctx, k_transpose_bitrev, grid, dim3(256), 0, src, dst, log_n, w, dst_col_stride,
+              src_width ? src_width : w);
     TS_HIP(hipGetLastError());
 }
 

@@ -400,7 +400,8 @@ k_lde_mid(const uint32_t* __restrict__ evals, uint64_t in_col_stride, uint32_t* 
 // ------------------------------------------------------------------ host driver
 void coset_lde(Context& ctx, uint32_t* evals, uint64_t in_col_stride, uint32_t ncols, unsigned log_n,
                unsigned log_blowup, uint32_t shift, uint32_t* out, uint64_t out_col_stride,
-               uint32_t beta0, uint32_t n_beta) {
+               uint32_t beta0, uint32_t n_beta, LdePhase phase) {
+    if (ncols == 0) return;
     TS_REQUIRE(log_n + log_blowup <= 27, TS_ERR_INVALID, "coset_lde: log_n + log_blowup > 27");
     TS_REQUIRE(ncols >= 1 && ncols <= 65535, TS_ERR_INVALID, "coset_lde: bad column count");
     const bool two_pass = log_n > (unsigned)LOG_M;
@@ -440,12 +441,16 @@ void coset_lde(Context& ctx, uint32_t* evals, uint64_t in_col_stride, uint32_t n
         // the vectorised chunk loads need 16-byte aligned columns
         TS_REQUIRE(in_col_stride % 4 == 0 && out_col_stride % 4 == 0, TS_ERR_INVALID,
                    "coset_lde: column strides must be multiples of 4 elements");
-        {
-            // (stage names: the sharded prover reports where a rank's time goes; this part is the
-            // one every rank repeats for all columns)
-            StageTimer t(&ctx, "lde: inverse NTT, contiguous stages (replicated when sharded)");
+        if (phase != LDE_REST) {
+            // (stage names: the sharded prover reports where a rank's time goes; this part is per
+            // column, so it can be sharded by columns -- ShardOptions::column_sharded_inverse)
+            StageTimer t(&ctx, "lde: inverse NTT, contiguous stages");
             TS_LAUNCH(ctx, k_intt_contig, dim3(1u << sA, ncols), dim3(NT), 0, evals, in_col_stride, log_n,
                       Winv);
+        }
+        if (phase == LDE_INVERSE_CONTIG) {
+            TS_HIP(hipGetLastError());
+            return;
         }
         StageTimer t_rest(&ctx, "lde: strided pass + forward NTT of the owned cosets");
         const dim3 grid(1u << (LOG_M - log_T), ncols);
@@ -473,7 +478,7 @@ void coset_lde(Context& ctx, uint32_t* evals, uint64_t in_col_stride, uint32_t n
                       scale);
         TS_LAUNCH(ctx, k_lde_fwd_contig, dim3(1u << sA, ncols, n_beta), dim3(NT), 0, out,
                   out_col_stride, log_n, W);
-    } else {
+    } else if (phase != LDE_INVERSE_CONTIG) {
         TS_LAUNCH(ctx, k_lde_mid<0>, dim3(1, ncols), dim3(NT_MID), 0, (const uint32_t*)evals,
                   in_col_stride, out, out_col_stride, log_n, log_n, 0u, 0u, beta0, n_beta, W, Winv, scale);
     }

@@ -31,6 +31,7 @@ struct Shard {
     const Comm& comm;
     uint32_t G, rank, log_G;
     uint32_t cosets, beta0;  // cosets per rank, first owned coset
+    bool column_sharded_inverse = false;
 };
 
 // what one rank keeps of a committed batch
@@ -75,14 +76,45 @@ std::unique_ptr<ShardedData> commit_sharded(Shard& sh, std::vector<DeviceMatrix>
                        "sharded commit: matrices of one height expected");
             DevBuf<uint32_t> colmajor;
             uint32_t* ev = m.buf.p;
-            if (m.layout == DeviceMatrix::ROW_MAJOR) {
-                colmajor = DevBuf<uint32_t>(&ctx, (size_t)m.width * n);
-                launch_transpose_bitrev(ctx, m.buf.p, colmajor.p, log_n, m.width, n);
-                ev = colmajor.p;
-            }
             DevBuf<uint32_t> lde(&ctx, (size_t)m.width * rows);
             const uint32_t shift = mul(GENERATOR, inv_canon(domain_shifts[i]));  // two_adic_pcs.rs:235
-            coset_lde(ctx, ev, n, m.width, log_n, sh.fri.log_blowup, shift, lde.p, rows, sh.beta0, sh.cosets);
+            if (sh.column_sharded_inverse && sh.G > 1 && log_n > 12) {
+                // the per-column part of the inverse transform (the
+                // transpose and the contiguous stages) is done for w/G columns per rank, then the
+                // half-transformed columns are all-gathered; the strided pass and the forward
+                // transforms of the owned cosets follow as usual.  Rank g's columns are
+                // [g cpr, (g+1) cpr) of a matrix padded to G cpr columns, so the gathered buffer IS
+                // the column-major matrix.
+                const uint32_t cpr = (m.width + sh.G - 1) / sh.G;
+                const uint32_t c0 = std::min(m.width, sh.rank * cpr), c1 = std::min(m.width, c0 + cpr);
+                DevBuf<uint32_t> mine(&ctx, (size_t)cpr * n);
+                {
+                    StageTimer t(&ctx, "lde: transpose + inverse contiguous stages of the rank's columns");
+                    if (m.layout == DeviceMatrix::ROW_MAJOR) {
+                        launch_transpose_bitrev(ctx, m.buf.p + c0, mine.p, log_n, c1 - c0, n, m.width);
+                    } else if (c1 > c0) {
+                        TS_HIP(hipMemcpyAsync(mine.p, m.buf.p + (size_t)c0 * n, (size_t)(c1 - c0) * n * 4,
+                                              hipMemcpyDeviceToDevice, ctx.stream));
+                    }
+                    coset_lde(ctx, mine.p, n, c1 - c0, log_n, sh.fri.log_blowup, shift, nullptr, rows, sh.beta0,
+                              sh.cosets, LDE_INVERSE_CONTIG);
+                }
+                colmajor = DevBuf<uint32_t>(&ctx, (size_t)cpr * sh.G * n);
+                {
+                    StageTimer t(&ctx, "all-gather half-transformed columns");
+                    sh.comm.all_gather(mine.p, colmajor.p, (size_t)cpr * n * 4, ctx.stream);
+                }
+                coset_lde(ctx, colmajor.p, n, m.width, log_n, sh.fri.log_blowup, shift, lde.p, rows, sh.beta0,
+                          sh.cosets, LDE_REST);
+            } else {
+                if (m.layout == DeviceMatrix::ROW_MAJOR) {
+                    StageTimer t(&ctx, "lde: transpose (every column on every rank)");
+                    colmajor = DevBuf<uint32_t>(&ctx, (size_t)m.width * n);
+                    launch_transpose_bitrev(ctx, m.buf.p, colmajor.p, log_n, m.width, n);
+                    ev = colmajor.p;
+                }
+                coset_lde(ctx, ev, n, m.width, log_n, sh.fri.log_blowup, shift, lde.p, rows, sh.beta0, sh.cosets);
+            }
             ColMat cm;
             cm.d = lde.p;
             cm.height = rows;
@@ -139,7 +171,7 @@ std::vector<uint32_t> prove_sharded(TwoAdicFriPcs& pcs, const Comm& comm, const 
                "prove_sharded: the number of ranks must be a power of two <= 2^log_blowup (whole "
                "cosets per rank); run independent proofs per GPU otherwise");
     Shard sh{ctx, fri, comm, G, (uint32_t)comm.rank, log2_strict(G), fri.blowup() / G,
-             (uint32_t)comm.rank * (fri.blowup() / G)};
+             (uint32_t)comm.rank * (fri.blowup() / G), opt.column_sharded_inverse};
     TS_REQUIRE(trace_rows.width == air.width, TS_ERR_INVALID, "prove: trace width != AIR width");
     TS_REQUIRE(trace_rows.layout == DeviceMatrix::ROW_MAJOR && trace_rows.buf.p, TS_ERR_INVALID,
                "prove_sharded: the trace slice must be an uploaded row-major matrix");

@@ -669,7 +669,8 @@ def prove(config: StarkConfig, air, challenger: BfChallenger, trace, public_valu
 
 
 def prove_sharded(config: StarkConfig, air, challenger: BfChallenger, trace_rows, public_values,
-                  comm, min_local_log: int = 0, trace_replicated: bool = False) -> Proof:
+                  comm, min_local_log: int = 0, trace_replicated: bool = False,
+                  column_sharded_inverse: bool = False) -> Proof:
     """One proof over ``comm.world`` GPUs (``ts_prove_sharded``).
 
     Every rank calls this with its own context, a challenger in the same state and its row slice
@@ -696,7 +697,7 @@ def prove_sharded(config: StarkConfig, air, challenger: BfChallenger, trace_rows
     n_words = C.c_size_t()
     cfg = pcs.fri._c()
     pis_p = _p(pis) if len(pis) else None
-    opts = _lib.ShardOptionsC(min_local_log, int(trace_replicated))
+    opts = _lib.ShardOptionsC(min_local_log, int(trace_replicated), int(column_sharded_inverse))
     rc = ctx._l.ts_prove_sharded(ctx.h, C.byref(cfg), C.byref(comm.c), air.h, challenger.h,
                                  trace_rows.h, pis_p, len(pis), C.byref(opts), _p(out), cap,
                                  C.byref(n_words))

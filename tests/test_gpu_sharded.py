@@ -175,9 +175,14 @@ def run_local_ranks(spec):
             config = ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(*spec["cfg"]), ctx))
             rows = trace if spec.get("replicated") else np.ascontiguousarray(trace[r * n // G:(r + 1) * n // G])
             ch = ts.BfChallenger()
+            if spec.get("timing"):
+                ctx.set_timing(True)
             p = ts.prove_sharded(config, air, ch, rows, pis, group.comm(r), spec["min_local_log"],
-                                 trace_replicated=bool(spec.get("replicated")))
+                                 trace_replicated=bool(spec.get("replicated")),
+                                 column_sharded_inverse=bool(spec.get("colshard")))
             proofs[r], bits[r] = p.words, ch.sample_bits(20)
+            if spec.get("timing"):
+                spec.setdefault("stages", {})[r] = ctx.take_timings()
         except BaseException as e:  # noqa: BLE001
             errors[r] = e
 
@@ -199,6 +204,28 @@ LOCAL_CASES = [
     ("fib", 11, (3, 9, 8), 8, 1, False),
     ("mul64", 11, (2, 28, 8), 4, 4, False),    # the headline config's FRI parameters over 4 ranks
 ]
+
+
+@pytest.mark.parametrize("air,log_n,cfg,world,repl", [
+    ("mul64", 13, (4, 16, 8), 8, True),    # config 4's split; 64 columns -> 8 per rank, 8 chunk columns -> 1 per rank
+    ("mul64", 14, (2, 28, 8), 4, False),   # row-sliced input: rows all-gathered, then columns sharded
+    ("mul7", 13, (3, 7, 8), 8, True),      # 7 columns over 8 ranks: one rank owns no trace column
+], ids=["config4-split", "sliced", "fewer-columns-than-ranks"])
+def test_sharded_column_sharded_inverse(ctx, orc, air, log_n, cfg, world, repl):
+    # transposes and the per-column stages of the inverse NTT on
+    # w/G columns per rank + an all-gather of the half-transformed columns; same proof, and the
+    # stage that every rank used to repeat for all columns is gone from its timings
+    spec = {"air": air, "log_n": log_n, "cfg": list(cfg), "world": world, "min_local_log": 8,
+            "replicated": repl, "colshard": True, "timing": True}
+    want, want_bits, _ = single_gpu_proof(ctx, spec)
+    proofs, bits, errors = run_local_ranks(spec)
+    for r in range(world):
+        assert errors[r] is None, f"rank {r}: {errors[r]!r}"
+        assert (proofs[r] == want.words).all(), f"rank {r}: {int((proofs[r] != want.words).sum())} words differ"
+        assert bits[r] == want_bits
+        names = [k for k, _ in spec["stages"][r]]
+        assert "all-gather half-transformed columns" in names
+        assert "lde: transpose (every column on every rank)" not in names
 
 
 @pytest.mark.parametrize("air,log_n,cfg,world,mll,repl", LOCAL_CASES,

@@ -384,6 +384,16 @@ def main():
         ts.prove(config, cair, ts.BfChallenger(), make_trace(ctx), pis)
         stages = ctx.take_timings()
         ctx.set_timing(False)
+        # one proof alone on the GPU, no timers inside (the stage timers synchronise at every stage
+        # boundary): host wall clock around ts_prove, which returns with the proof on the host
+        lat = []
+        for _ in range(5):
+            m_ = make_trace(ctx)
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            ts.prove(config, cair, ts.BfChallenger(), m_, pis)
+            lat.append(1e3 * (time.perf_counter() - t0))
+        single_latency = sorted(lat)[len(lat) // 2]
         stage_sum = {}
         for k, v in stages:  # a stage name can occur twice (trace commit, quotient commit)
             stage_sum[k] = round(stage_sum.get(k, 0.0) + v, 3)
@@ -530,7 +540,8 @@ def main():
             "proofs_per_sec": res["steps_per_sec"],
             # one proof alone on the GPU, HIP events around ts_prove (the `value` above keeps
             # several in flight; this is the latency a single caller sees)
-            "single_proof_latency_ms": stage_sum.get("prove"),
+            "single_proof_latency_ms": round(single_latency, 4),
+            "single_proof_latency_with_stage_timers_ms": stage_sum.get("prove"),
             "roofline": roofline, "roofline_stage": roofline_stage, "roofline_whole": roofline_whole,
             "alu_ceiling": alu_ceiling, "h2d_inclusive": h2d, "cpu_baseline": cpu,
             "stages_ms": stage_sum,

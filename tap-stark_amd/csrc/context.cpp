@@ -1,5 +1,7 @@
 #include "context.hpp"
 
+#include <string.h>
+
 #include "kernels.hpp"
 
 namespace ts {
@@ -28,6 +30,7 @@ Context::~Context() {
     for (auto& kv : free_blocks) hipFree(kv.second);
     for (auto& kv : live_blocks) hipFree(kv.first);
     if (h_pinned) hipHostFree(h_pinned);
+    if (h_arena) hipHostFree(h_arena);
     if (stream) hipStreamDestroy(stream);
 }
 
@@ -89,6 +92,28 @@ uint32_t* Context::ticket() {
         TS_HIP(hipMemsetAsync(d_ticket, 0, 64 * 17, stream));
     }
     return d_ticket;
+}
+
+const void* Context::stage(const void* src, size_t bytes) {
+    const size_t need = (bytes + 63) & ~(size_t)63;
+    if (need > h_arena_bytes / 2) {  // (re)allocate: rare, at most a few times per context
+        sync();
+        if (h_arena) (void)hipHostFree(h_arena);
+        h_arena = nullptr;
+        size_t sz = 1 << 20;
+        while (sz / 2 < need) sz <<= 1;
+        TS_HIP(hipHostMalloc((void**)&h_arena, sz, hipHostMallocDefault));
+        h_arena_bytes = sz;
+        h_arena_off = 0;
+    }
+    if (h_arena_off + need > h_arena_bytes) {  // wrap: everything staged so far must have been consumed
+        sync();
+        h_arena_off = 0;
+    }
+    void* p = h_arena + h_arena_off;
+    memcpy(p, src, bytes);
+    h_arena_off += need;
+    return p;
 }
 
 void* Context::pinned(size_t bytes) {

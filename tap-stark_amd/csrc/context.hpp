@@ -83,6 +83,12 @@ struct Context {
     // pinned host staging
     void* h_pinned = nullptr;
     size_t h_pinned_bytes = 0;
+    // page-locked bump arena for small host->device uploads (challenge powers, index lists,
+    // pointer tables): the bytes are copied here first, so the async copy never reads a caller's
+    // stack or vector and no sync is needed to protect them.  When full: one sync, then reuse.
+    char* h_arena = nullptr;
+    size_t h_arena_bytes = 0, h_arena_off = 0;
+    const void* stage(const void* src, size_t bytes);
 
     // optional per-stage timing (bench.py): name -> accumulated ms, measured with HIP events on
     // `stream`

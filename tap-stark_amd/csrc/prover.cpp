@@ -15,8 +15,14 @@
 
 namespace ts {
 
+// small uploads go through the context's page-locked arena: truly asynchronous, and the caller's
+// buffer (a stack temporary, a vector about to die) is free as soon as this returns
+// (uploads above 1 MiB -- lock-script tables, script blobs -- go straight from the caller's buffer,
+// which the caller keeps alive until its next blocking call)
 void h2d(Context& ctx, void* dst, const void* src, size_t bytes) {
-    if (bytes) TS_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx.stream));
+    if (!bytes) return;
+    const void* from = bytes <= (1u << 20) ? ctx.stage(src, bytes) : src;
+    TS_HIP(hipMemcpyAsync(dst, from, bytes, hipMemcpyHostToDevice, ctx.stream));
 }
 void d2h_sync(Context& ctx, void* dst, const void* src, size_t bytes) {
     if (bytes) TS_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx.stream));
@@ -248,9 +254,7 @@ std::vector<DeviceMatrix> TwoAdicFriPcs::quotient_chunks_slab(const ColMat& lde_
         launch_quotient(ctx_, air, lde, log_n, lqd, d_consts.p, d_apow.p, sel.p, sel.p + qn, sel.p + 2 * qn,
                         qo, row_begin, row_end);
     }
-    // the pageable staging vectors must outlive the async copies
-    ctx_.sync();
-    return chunks;
+    return chunks;  // (the staged uploads live in the context's pinned arena: no sync needed)
 }
 
 // ------------------------------------------------------------------ open
@@ -368,7 +372,6 @@ DevBuf<Ef> TwoAdicFriPcs::open_reduce_slab(const PcsData& trace_data, const PcsD
         }
         launch_reduce_fused(ctx_, tr, log_N, d_apow.p, a, ro.p);
     }
-    ctx_.sync();  // pageable apow must outlive its async copy
     return ro;
 }
 
@@ -404,7 +407,6 @@ void fri_commit_begin(Context& ctx, const FriConfig& fri, unsigned log_max_heigh
     challenger.export_dev(hc);
     st.d_chal = DevBuf<uint32_t>(&ctx, sizeof(DevChallenger) / 4);
     h2d(ctx, st.d_chal.p, &hc, sizeof hc);
-    ctx.sync();  // `hc` is a stack temporary
     st.d_roots = DevBuf<uint32_t>(&ctx, std::max<size_t>(8 * (size_t)st.R_total, 8));
     st.d_betas = DevBuf<Ef>(&ctx, std::max<size_t>(st.R_total, 1));
     st.d_final = DevBuf<Ef>(&ctx, fri.blowup());
@@ -741,8 +743,6 @@ std::vector<uint32_t> TwoAdicFriPcs::open(const std::vector<OpenRound>& rounds, 
             }
         }
     }
-    ctx_.sync();  // pageable apow must outlive its async copy
-
     // :389-393 fri_input: the reduced openings by descending height
     std::vector<DevBuf<Ef>> inputs;
     std::vector<unsigned> log_lens;

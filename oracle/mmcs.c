@@ -29,7 +29,62 @@ struct ts_or_mmcs_data {
     uint32_t** mats;
     unsigned log_max_h;
     uint32_t** layers; /* layers[l] has (max_h >> l) digests of 8 words */
+    /* taptree mode (below): Q trees of (2 max_h - 1) x 32 bytes each, and the Q roots as words */
+    uint32_t tap_q;
+    uint8_t* tap_nodes;
+    uint32_t* tap_roots;
 };
+
+/* ------------------------------------------------------------------ taptree mode
+ * The reference's real BFMmcs (basic/src/mmcs/taptree_mmcs.rs:24-119): num_queries taptrees per
+ * commitment (taptree.c).  While the mode is on, ts_or_mmcs_commit / _open / _verify speak taptree:
+ *   - commit k (in call order) takes lock scripts [cursor, cursor + Q (1 + n_evals)) of the table,
+ *     n_evals = total width / u32_size, u32_size as last set by ts_or_mmcs_tap_u32 (1 for BabyBear
+ *     matrices, 4 for the EF4 matrices of the FRI commit phase: tcs/mod.rs:239-246);
+ *   - open/verify use tree `cur_q` (taptree_mmcs.rs:46-75: open_batch(query_times_index, ...));
+ *   - a digest is 8 words = its 32 bytes read as little-endian u32 (chan_field.rs:87-95 u256_to_u32). */
+static __thread struct {
+    uint32_t Q;
+    const uint8_t* bytes;
+    const uint64_t* offsets;
+    size_t cursor;       /* next lock script of the table (prover side) */
+    uint32_t u32_size;
+    uint32_t cur_q;
+    size_t verify_base;  /* first lock script of the commitment being verified */
+} g_tap;
+
+void ts_or_mmcs_set_taptree(uint32_t Q, const uint8_t* lock_bytes, const uint64_t* lock_offsets) {
+    g_tap.Q = Q;
+    g_tap.bytes = lock_bytes;
+    g_tap.offsets = lock_offsets;
+    g_tap.cursor = 0;
+    g_tap.u32_size = 1;
+    g_tap.cur_q = 0;
+    g_tap.verify_base = 0;
+}
+uint32_t ts_or_mmcs_tap_queries(void) { return g_tap.Q; }
+void ts_or_mmcs_tap_u32(uint32_t u32_size) { g_tap.u32_size = u32_size; }
+void ts_or_mmcs_tap_select(uint32_t q) { g_tap.cur_q = q; }
+void ts_or_mmcs_tap_verify_base(size_t first_lock) { g_tap.verify_base = first_lock; }
+uint32_t ts_or_mmcs_n_roots(const ts_or_mmcs_data* d) { return d->tap_q ? d->tap_q : 1; }
+const uint32_t* ts_or_mmcs_root(const ts_or_mmcs_data* d, uint32_t q) {
+    return d->tap_q ? d->tap_roots + 8 * (size_t)q : d->layers[d->log_max_h];
+}
+static void bytes_to_words(const uint8_t* b, uint32_t* w) {
+    for (int k = 0; k < 8; k++)
+        w[k] = (uint32_t)b[4 * k] | (uint32_t)b[4 * k + 1] << 8 | (uint32_t)b[4 * k + 2] << 16 |
+               (uint32_t)b[4 * k + 3] << 24;
+}
+static void words_to_bytes(const uint32_t* w, uint8_t* b) {
+    for (int k = 0; k < 8; k++)
+        for (int j = 0; j < 4; j++) b[4 * k + j] = (uint8_t)(w[k] >> (8 * j));
+}
+static void tap_locks(size_t first, uint32_t n, const uint8_t** ptrs, size_t* lens) {
+    for (uint32_t s = 0; s < n; s++) {
+        ptrs[s] = g_tap.bytes + g_tap.offsets[first + s];
+        lens[s] = (size_t)(g_tap.offsets[first + s + 1] - g_tap.offsets[first + s]);
+    }
+}
 
 static void compress2(const uint32_t* l, const uint32_t* r, uint32_t out[8]) {
     uint32_t buf[16];
@@ -74,6 +129,29 @@ ts_or_mmcs_data* ts_or_mmcs_commit(int n_mats, const uint32_t* const* mats, cons
         if (heights[i] > max_h) max_h = heights[i];
     }
     d->log_max_h = ts_log2_strict(max_h);
+    if (g_tap.Q) { /* tcs/mod.rs:284-292 commit_poly_with_query_times: Q x commit_polys */
+        size_t total = 0;
+        for (int i = 0; i < n_mats; i++) total += widths[i];
+        uint32_t n_evals = (uint32_t)(total / g_tap.u32_size);
+        size_t nodes_per = (2 * max_h - 1) * 32;
+        d->tap_q = g_tap.Q;
+        d->tap_nodes = (uint8_t*)malloc(nodes_per * g_tap.Q);
+        d->tap_roots = (uint32_t*)malloc(32 * (size_t)g_tap.Q);
+        const uint8_t** lp = (const uint8_t**)malloc((n_evals + 1) * sizeof(void*));
+        size_t* ll = (size_t*)malloc((n_evals + 1) * sizeof(size_t));
+        for (uint32_t q = 0; q < g_tap.Q; q++) {
+            tap_locks(g_tap.cursor, n_evals + 1, lp, ll);
+            g_tap.cursor += n_evals + 1;
+            ts_or_tap_commit_polys(n_mats, (const uint32_t* const*)d->mats, d->heights, d->widths,
+                                   g_tap.u32_size, lp, ll, d->tap_nodes + nodes_per * q);
+            bytes_to_words(d->tap_nodes + nodes_per * q + nodes_per - 32, d->tap_roots + 8 * (size_t)q);
+        }
+        free(lp);
+        free(ll);
+        d->layers = (uint32_t**)calloc(d->log_max_h + 1, sizeof(uint32_t*));
+        memcpy(root, d->tap_roots, 32);
+        return d;
+    }
     d->layers = (uint32_t**)malloc((d->log_max_h + 1) * sizeof(uint32_t*));
     d->layers[0] = (uint32_t*)malloc(max_h * 32);
 #pragma omp parallel for schedule(static) if (max_h > 4096)
@@ -102,6 +180,8 @@ void ts_or_mmcs_free(ts_or_mmcs_data* d) {
     if (!d) return;
     for (int i = 0; i < d->n_mats; i++) free(d->mats[i]);
     for (unsigned l = 0; l <= d->log_max_h; l++) free(d->layers[l]);
+    free(d->tap_nodes);
+    free(d->tap_roots);
     free(d->mats);
     free(d->layers);
     free(d->heights);
@@ -128,6 +208,14 @@ void ts_or_mmcs_open(const ts_or_mmcs_data* d, size_t index, uint32_t* rows_out,
         memcpy(rows_out + off, d->mats[i] + r * d->widths[i], d->widths[i] * 4);
         off += d->widths[i];
     }
+    if (d->tap_q) {
+        size_t max_h = (size_t)1 << d->log_max_h;
+        uint8_t* pb = (uint8_t*)malloc(32 * (size_t)d->log_max_h + 32);
+        ts_or_taptree_path(max_h, d->tap_nodes + (2 * max_h - 1) * 32 * (size_t)g_tap.cur_q, index, pb);
+        for (unsigned l = 0; l < d->log_max_h; l++) bytes_to_words(pb + 32 * l, path_out + 8 * l);
+        free(pb);
+        return;
+    }
     for (unsigned l = 0; l < d->log_max_h; l++)
         memcpy(path_out + 8 * l, d->layers[l] + 8 * ((index >> l) ^ 1), 32);
 }
@@ -141,6 +229,32 @@ int ts_or_mmcs_verify(int n_mats, const size_t* heights, const size_t* widths, s
     unsigned log_max_h = ts_log2_strict(max_h);
     if (path_len != log_max_h) return 0;
     if (index >> log_max_h) return 0;
+    if (g_tap.Q) {
+        /* taptree_mmcs.rs:77-99 verify_batch -> tcs/mod.rs:425-436: rebuild the leaf from the opened
+         * values (they must come tallest matrix first, taptree_mmcs.rs:68-72), check its inclusion
+         * under root `cur_q` of the commitment (`root` points at the Q roots).  Script execution
+         * against a witness (tcs/mod.rs:143-147) is not restated. */
+        size_t total = 0;
+        for (int i = 0; i < n_mats; i++) {
+            if (i && heights[i] > heights[i - 1]) return 0;
+            total += widths[i];
+        }
+        uint32_t n_evals = (uint32_t)(total / g_tap.u32_size);
+        const uint8_t** lp = (const uint8_t**)malloc((n_evals + 1) * sizeof(void*));
+        size_t* ll = (size_t*)malloc((n_evals + 1) * sizeof(size_t));
+        tap_locks(g_tap.verify_base + (size_t)g_tap.cur_q * (n_evals + 1), n_evals + 1, lp, ll);
+        size_t len = ts_or_tap_leaf_script(lp, ll, index, rows, n_evals, g_tap.u32_size, NULL, 0);
+        uint8_t* sc = (uint8_t*)malloc(len + 1);
+        ts_or_tap_leaf_script(lp, ll, index, rows, n_evals, g_tap.u32_size, sc, len);
+        uint8_t leaf[32], rb[32];
+        ts_or_tapleaf_hash(sc, len, 0xc0, leaf);
+        uint8_t* pb = (uint8_t*)malloc(32 * path_len + 32);
+        for (size_t l = 0; l < path_len; l++) words_to_bytes(path + 8 * l, pb + 32 * l);
+        words_to_bytes(root + 8 * (size_t)g_tap.cur_q, rb);
+        int ok = ts_or_taptree_verify_inclusion(rb, leaf, pb, path_len);
+        free(pb); free(sc); free(lp); free(ll);
+        return ok;
+    }
     /* row pointers into the concatenated opened rows (each "matrix" has one row here) */
     const uint32_t** rp = (const uint32_t**)malloc(n_mats * sizeof(uint32_t*));
     size_t* one_h = (size_t*)malloc(n_mats * sizeof(size_t));

@@ -200,6 +200,15 @@ int64_t ts_or_fri_prove(const ts_or_fri_config* cfg, ts_or_challenger* chal, int
 int ts_or_fri_verify(const ts_or_fri_config* cfg, ts_or_challenger* chal, const uint32_t* proof,
                      size_t n_words);
 
+/* taptree mode of the MMCS (mmcs.c): see there.  Q = 0 switches it off. */
+void ts_or_mmcs_set_taptree(uint32_t Q, const uint8_t* lock_bytes, const uint64_t* lock_offsets);
+uint32_t ts_or_mmcs_tap_queries(void);
+void ts_or_mmcs_tap_u32(uint32_t u32_size);
+void ts_or_mmcs_tap_select(uint32_t q);
+void ts_or_mmcs_tap_verify_base(size_t first_lock);
+uint32_t ts_or_mmcs_n_roots(const ts_or_mmcs_data* d);
+const uint32_t* ts_or_mmcs_root(const ts_or_mmcs_data* d, uint32_t q);
+
 /* ------------------------------------------------------------------ taptree commitment (taptree.c)
  * reference basic/src/tcs/{mod,builder,complete_taptree}.rs; hashing per BIP-340/341 */
 void ts_or_sha256(const uint8_t* in, size_t len, uint8_t out[32]);

@@ -489,3 +489,35 @@ def tap_commit_polys(mats, locks, u32_size: int = 1) -> OracleTaptree:
     n_evals = ys.shape[1] // u32_size
     assert len(locks) == 1 + n_evals
     return OracleTaptree.from_scripts([tap_leaf_script(locks, i, ys[i], u32_size) for i in range(ys.shape[0])])
+
+
+# ------------------------------------------------- whole proofs over the taptree MMCS (TSPF v2)
+class _TapMode:
+    """Context manager: the oracle's MMCS speaks taptree (mmcs.c) with `locks` = the flat table of
+    lock scripts in commit order -- trace: Q (1 + w); quotient chunks: Q (1 + 4 qd); every FRI round:
+    Q (1 + 2) -- while the block runs."""
+
+    def __init__(self, num_queries: int, locks):
+        self.q = num_queries
+        self.blob = b"".join(locks)
+        self.offs = np.zeros(len(locks) + 1, dtype=np.uint64)
+        self.offs[1:] = np.cumsum([len(x) for x in locks])
+
+    def __enter__(self):
+        lib().ts_or_mmcs_set_taptree(self.q, self.blob, self.offs.ctypes.data_as(C.POINTER(C.c_uint64)))
+        return self
+
+    def __exit__(self, *a):
+        lib().ts_or_mmcs_set_taptree(0, None, None)
+
+
+def prove_tap(cfg: FriConfig, tape, trace, pis, locks, chal: OracleChallenger | None = None,
+              cap_words: int = 1 << 24) -> np.ndarray:
+    """prove() with `TapTreeMmcs` (basic/src/mmcs/taptree_mmcs.rs) as both MMCSs: TSPF v2 words."""
+    with _TapMode(cfg.num_queries, locks):
+        return prove(cfg, tape, trace, pis, chal, cap_words)
+
+
+def verify_tap(cfg: FriConfig, tape, proof, pis, locks, chal: OracleChallenger | None = None) -> int:
+    with _TapMode(cfg.num_queries, locks):
+        return verify(cfg, tape, proof, pis, chal)

@@ -39,6 +39,19 @@ static void wb_push_ef(ts_or_wbuf* b, ef4 e) { wb_push_n(b, e.c, 4); }
 
 static ef4 ef4_load(const uint32_t* p) { ef4 r = {{p[0], p[1], p[2], p[3]}}; return r; }
 
+/* roots per commitment: 1 (Blake3 Merkle MMCS) or num_queries (taptree mode, mmcs.c) */
+static uint32_t n_roots(void) {
+    uint32_t q = ts_or_mmcs_tap_queries();
+    return q ? q : 1;
+}
+/* CanObserve<Vec<[PF; N]>> (basic/src/challenger/mod.rs:211-223): every root of the commitment */
+static void observe_roots(ts_or_challenger* c, const uint32_t* roots) {
+    for (uint32_t q = 0; q < n_roots(); q++) ts_or_chal_observe_digest(c, roots + 8 * (size_t)q);
+}
+static void copy_roots(const ts_or_mmcs_data* d, uint32_t* out) {
+    for (uint32_t q = 0; q < n_roots(); q++) memcpy(out + 8 * (size_t)q, ts_or_mmcs_root(d, q), 32);
+}
+
 static ef4 chal_sample_ef(ts_or_challenger* c) {
     ef4 r;
     ts_or_chal_sample(c, r.c);
@@ -318,15 +331,19 @@ static int bf_prove(const ts_or_fri_config* cfg, int n_inputs, ef4* const* input
     int next_in = 1;
     int max_rounds = (int)log_max_height + 1;
     ts_or_mmcs_data** data = (ts_or_mmcs_data**)calloc(max_rounds, sizeof(void*));
-    uint32_t(*commits)[8] = (uint32_t(*)[8])malloc(max_rounds * 32);
+    const size_t cw = 8 * (size_t)n_roots(); /* words per commitment */
+    uint32_t* commits = (uint32_t*)malloc(max_rounds * cw * 4);
     ef4 betas[40];
     int R = 0;
     /* commit phase :111-127 */
+    ts_or_mmcs_tap_u32(4); /* the commit-phase matrices hold EF4 elements (ChallengeMmcs) */
     while (len > blowup) {
         const uint32_t* leaves = (const uint32_t*)folded; /* RowMajorMatrix(folded, 2) as h x 8 base */
         size_t h = len / 2, w8 = 8;
-        data[R] = ts_or_mmcs_commit(1, &leaves, &h, &w8, commits[R]);
-        ts_or_chal_observe_digest(chal, commits[R]);
+        uint32_t first_root[8];
+        data[R] = ts_or_mmcs_commit(1, &leaves, &h, &w8, first_root);
+        copy_roots(data[R], commits + cw * R);
+        observe_roots(chal, commits + cw * R);
         ef4 beta = chal_sample_ef(chal);
         betas[R] = beta;
         ef4* nf = (ef4*)malloc(h * sizeof(ef4));
@@ -340,6 +357,7 @@ static int bf_prove(const ts_or_fri_config* cfg, int n_inputs, ef4* const* input
             next_in++;
         }
     }
+    ts_or_mmcs_tap_u32(1);
     /* :129-134 */
     int rc = 0;
     if (len != blowup) rc = -5;
@@ -351,7 +369,7 @@ static int bf_prove(const ts_or_fri_config* cfg, int n_inputs, ef4* const* input
     if (rc == 0 && ts_or_chal_grind(chal, cfg->proof_of_work_bits, &pow_witness)) rc = -4;
 
     wb_push(b, (uint32_t)R);
-    for (int r = 0; r < R; r++) wb_push_n(b, commits[r], 8);
+    for (int r = 0; r < R; r++) wb_push_n(b, commits + cw * r, cw);
     wb_push(b, cfg->num_queries);
     g_tr_len = 12;
     g_tr[g_tr_len++] = (uint32_t)R;
@@ -362,6 +380,7 @@ static int bf_prove(const ts_or_fri_config* cfg, int n_inputs, ef4* const* input
         for (uint32_t q = 0; q < cfg->num_queries; q++) { /* :45-59 */
             size_t index = (size_t)ts_or_chal_sample_bits(chal, log_max_height);
             if (g_tr_len < sizeof g_tr / 4) g_tr[g_tr_len++] = (uint32_t)index;
+            ts_or_mmcs_tap_select(q); /* open_batch(query_times_index = q, ...), fri/src/prover.rs:50-56 */
             if (pass_through) {
                 wb_push(b, (uint32_t)n_inputs);
                 for (int k = 0; k < n_inputs; k++) {
@@ -454,9 +473,13 @@ int64_t ts_or_prove(const ts_or_fri_config* cfg, const uint32_t* tape, size_t n_
 
     /* :50-53 commit to trace */
     dom_t td = {log_n, 1};
-    uint32_t trace_root[8], quot_root[8];
-    ts_or_mmcs_data* tdata = pcs_commit(cfg, 1, &td, &trace, &w, trace_root);
-    ts_or_chal_observe_digest(chal, trace_root); /* :60 */
+    const size_t cw = 8 * (size_t)n_roots();
+    uint32_t first_root[8];
+    uint32_t* trace_root = (uint32_t*)malloc(cw * 4);
+    uint32_t* quot_root = (uint32_t*)malloc(cw * 4);
+    ts_or_mmcs_data* tdata = pcs_commit(cfg, 1, &td, &trace, &w, first_root);
+    copy_roots(tdata, trace_root);
+    observe_roots(chal, trace_root); /* :60 */
     ef4 alpha = chal_sample_ef(chal);            /* :63 */
     memcpy(g_tr, alpha.c, 16);
 
@@ -477,21 +500,32 @@ int64_t ts_or_prove(const ts_or_fri_config* cfg, const uint32_t* tape, size_t n_
         qev[c] = chunks + c * n * 4;
         qw[c] = 4;
     }
-    ts_or_mmcs_data* qdata = pcs_commit(cfg, (int)qd, qdoms, qev, qw, quot_root); /* :82-83 */
+    ts_or_mmcs_data* qdata = pcs_commit(cfg, (int)qd, qdoms, qev, qw, first_root); /* :82-83 */
     free(chunks);
-    ts_or_chal_observe_digest(chal, quot_root); /* :84 */
+    copy_roots(qdata, quot_root);
+    observe_roots(chal, quot_root); /* :84 */
     ef4 zeta = chal_sample_ef(chal);            /* :91 */
     memcpy(g_tr + 4, zeta.c, 16);
     ef4 zeta_next = ef4_mul_base(zeta, bb_two_adic_generator(log_n)); /* :92 */
 
     /* header + commitments */
     wb_push(&b, TSPF_MAGIC);
-    wb_push(&b, 1);
-    wb_push(&b, log_n);
-    wb_push(&b, (uint32_t)w);
-    wb_push(&b, (uint32_t)qd);
-    wb_push_n(&b, trace_root, 8);
-    wb_push_n(&b, quot_root, 8);
+    if (ts_or_mmcs_tap_queries()) { /* TSPF v2: taptree commitments, num_queries roots each */
+        wb_push(&b, 2);
+        wb_push(&b, log_n);
+        wb_push(&b, (uint32_t)w);
+        wb_push(&b, (uint32_t)qd);
+        wb_push(&b, ts_or_mmcs_tap_queries());
+    } else {
+        wb_push(&b, 1);
+        wb_push(&b, log_n);
+        wb_push(&b, (uint32_t)w);
+        wb_push(&b, (uint32_t)qd);
+    }
+    wb_push_n(&b, trace_root, cw);
+    wb_push_n(&b, quot_root, cw);
+    free(trace_root);
+    free(quot_root);
 
     /* :94-104 open */
     ef4 tpts[2] = {zeta, zeta_next};
@@ -569,12 +603,22 @@ static int fri_verify(const ts_or_fri_config* cfg, int n_rounds, const round_cla
     /* verify_shape_and_sample_challenges, verifier.rs:20-60 */
     uint32_t R = rb_get(rb);
     if (rb->bad || R > 31) return 9;
-    const uint32_t* commits = rb_take(rb, (size_t)R * 8);
+    const size_t cw = 8 * (size_t)n_roots();
+    const uint32_t* commits = rb_take(rb, (size_t)R * cw);
     if (rb->bad) return 9;
     ef4 betas[32];
     for (uint32_t r = 0; r < R; r++) {
-        ts_or_chal_observe_digest(chal, commits + 8 * r);
+        observe_roots(chal, commits + cw * r);
         betas[r] = chal_sample_ef(chal);
+    }
+    /* taptree mode: where each commitment's lock scripts start in the table (commit order: the
+     * input rounds, then the FRI rounds with 1 + 2 scripts per tree) */
+    size_t lock_base[64], fri_lock_base = 0;
+    for (int r = 0; r < n_rounds && r < 64; r++) {
+        size_t tw = 0;
+        for (int i = 0; i < rounds[r].n_mats; i++) tw += rounds[r].mats[i].width;
+        lock_base[r] = fri_lock_base;
+        fri_lock_base += (size_t)n_roots() * (1 + tw);
     }
     uint32_t Q = rb_get(rb);
     if (rb->bad) return 9;
@@ -608,6 +652,7 @@ static int fri_verify(const ts_or_fri_config* cfg, int n_rounds, const round_cla
     int rc = 0;
     for (uint32_t q = 0; q < Q && rc == 0; q++) { /* verify_challenges :62-98 */
         size_t index = indices[q];
+        ts_or_mmcs_tap_select(q); /* verify_batch(query_times_index = q, ...) */
         ef4 ro_by_lh[32];
         int has_ro[32];
         memset(has_ro, 0, sizeof has_ro);
@@ -659,6 +704,8 @@ static int fri_verify(const ts_or_fri_config* cfg, int n_rounds, const round_cla
                 unsigned log_bmh = ts_log2_strict(max_h);
                 unsigned bits_reduced = log_max_height - log_bmh;
                 size_t reduced_index = index >> bits_reduced;
+                ts_or_mmcs_tap_u32(1);
+                ts_or_mmcs_tap_verify_base(lock_base[r]);
                 if (!ts_or_mmcs_verify((int)nm, heights, widths, reduced_index, rows, path, plen,
                                        rounds[r].commit)) { free(rows); rc = 4; break; }
                 off = 0;
@@ -704,7 +751,11 @@ static int fri_verify(const ts_or_fri_config* cfg, int n_rounds, const round_cla
                 if (!ef4_eq(folded_eval, committed)) { rc = 8; break; } /* :139-141 */
             }
             size_t h = (size_t)1 << log_folded_height, w8 = 8;
-            if (!ts_or_mmcs_verify(1, &h, &w8, index_pair, vals, path, plen, commits + 8 * r)) {
+            ts_or_mmcs_tap_u32(4);
+            ts_or_mmcs_tap_verify_base(fri_lock_base + (size_t)r * n_roots() * 3);
+            int mm_ok = ts_or_mmcs_verify(1, &h, &w8, index_pair, vals, path, plen, commits + cw * r);
+            ts_or_mmcs_tap_u32(1);
+            if (!mm_ok) {
                 rc = 5;
                 break;
             }
@@ -726,24 +777,28 @@ int ts_or_verify(const ts_or_fri_config* cfg, const uint32_t* tape, size_t n_tap
     ts_or_tape t;
     if (ts_or_tape_parse(tape, n_tape, &t)) return 9;
     rbuf rb = {proof, n_words, 0, 0};
-    if (rb_get(&rb) != TSPF_MAGIC || rb_get(&rb) != 1) return 9;
+    if (rb_get(&rb) != TSPF_MAGIC) return 9;
+    const uint32_t version = rb_get(&rb);
+    if (version != (ts_or_mmcs_tap_queries() ? 2u : 1u)) return 9;
     unsigned degree_bits = rb_get(&rb);
     uint32_t pw = rb_get(&rb), pqd = rb_get(&rb);
+    if (version == 2 && rb_get(&rb) != ts_or_mmcs_tap_queries()) return 1;
     if (rb.bad || degree_bits > 27) return 9;
+    const size_t cw = 8 * (size_t)n_roots();
     unsigned lqd = (unsigned)ts_or_air_log_quotient_degree(tape, n_tape);
     size_t qd = (size_t)1 << lqd, w = t.width;
     if (pw != w || pqd != qd) return 1; /* verifier.rs:49-59 valid_shape */
-    const uint32_t* trace_root = rb_take(&rb, 8);
-    const uint32_t* quot_root = rb_take(&rb, 8);
+    const uint32_t* trace_root = rb_take(&rb, cw);
+    const uint32_t* quot_root = rb_take(&rb, cw);
     const ef4* trace_local = (const ef4*)rb_take(&rb, w * 4);
     const ef4* trace_next = (const ef4*)rb_take(&rb, w * 4);
     const ef4* qchunks = (const ef4*)rb_take(&rb, qd * 16);
     if (rb.bad) return 9;
 
     /* :69-75 */
-    ts_or_chal_observe_digest(chal, trace_root);
+    observe_roots(chal, trace_root);
     ef4 alpha = chal_sample_ef(chal);
-    ts_or_chal_observe_digest(chal, quot_root);
+    observe_roots(chal, quot_root);
     ef4 zeta = chal_sample_ef(chal);
     uint32_t gn = bb_two_adic_generator(degree_bits);
     ef4 zeta_next = ef4_mul_base(zeta, gn);

@@ -386,6 +386,25 @@ ts_status ts_tap_mmcs_verify_batch(const uint8_t* lock_scripts, const uint64_t* 
                                    const uint8_t root[32], int* ok);
 void ts_tap_mmcs_free(ts_tap_mmcs_data* d);
 
+/* uni_stark::prove / verify with TapTreeMmcs as the MMCS of the PCS and of FRI -- the reference's
+ * own configuration (uni-stark/tests/fib_air.rs:117-131): every commitment is cfg->num_queries
+ * taptrees, the challenger observes all their roots (basic/src/challenger/mod.rs:211-223), query q
+ * opens in tree q (fri/src/prover.rs:50-56).  The lock scripts are one flat table in the order the
+ * reference's bit-commitment manager hands them out (tcs/mod.rs:251-260), i.e. commit order:
+ *   trace: Q (1 + width); quotient chunks: Q (1 + 4 quotient_degree); each of the log2(n) FRI rounds:
+ *   Q (1 + 2)  -- per tree: the index lock first, then one lock per evaluation
+ * (n_scripts entries, n_scripts + 1 offsets).  Proof = TSPF v2: v1 with a sixth header word
+ * (num_queries) and num_queries x 8 words per commitment, a digest being its 32 bytes read as
+ * little-endian words.  ts_verify_tap is host only; verdict codes as ts_verify. */
+ts_status ts_prove_tap(ts_ctx* ctx, const ts_fri_config* cfg, const ts_air* air, ts_challenger* chal,
+                       ts_matrix* trace, const uint32_t* public_values, uint32_t n_public,
+                       const uint8_t* lock_scripts, const uint64_t* lock_offsets, size_t n_scripts,
+                       uint32_t* proof_out, size_t cap_words, size_t* n_words_out);
+ts_status ts_verify_tap(const ts_fri_config* cfg, const ts_air* air, ts_challenger* chal,
+                        const uint32_t* proof, size_t n_words, const uint32_t* public_values,
+                        uint32_t n_public, const uint8_t* lock_scripts, const uint64_t* lock_offsets,
+                        size_t n_scripts, int* verdict);
+
 /* Measurement aid: the whole-chip rate of NTT butterflies (kind 0) or Blake3 compressions (kind 1)
  * with no memory traffic, using the library's own arithmetic -- the integer-ALU ceiling bench.py
  * reports beside the achieved rates. */

@@ -708,6 +708,57 @@ ts_status ts_prove_sharded(ts_ctx* ctx, const ts_fri_config* cfg, const ts_comm*
     });
 }
 
+// ------------------------------------------------------------------ prove / verify over taptrees
+ts_status ts_prove_tap(ts_ctx* ctx, const ts_fri_config* cfg, const ts_air* air, ts_challenger* chal,
+                       ts_matrix* trace, const uint32_t* public_values, uint32_t n_public,
+                       const uint8_t* lock_scripts, const uint64_t* lock_offsets, size_t n_scripts,
+                       uint32_t* proof_out, size_t cap_words, size_t* n_words_out) {
+    if (!ctx || !air || !chal || !trace || !proof_out || !n_words_out || !lock_scripts || !lock_offsets)
+        return TS_ERR_INVALID;
+    *n_words_out = 0;
+    return guard(ctx, [&] {
+        ts::TwoAdicFriPcs pcs(ctx->ctx, load_cfg(cfg));
+        TS_REQUIRE(trace->m.buf.p, ts::TS_ERR_INVALID, "prove: trace matrix was already consumed");
+        std::vector<uint32_t> pis;
+        if (n_public) {
+            TS_REQUIRE(public_values, ts::TS_ERR_INVALID, "null public values");
+            pis.assign(public_values, public_values + n_public);
+        }
+        ts::TapLocks locks;
+        locks.bytes = lock_scripts;
+        locks.offsets = lock_offsets;
+        locks.n_scripts = n_scripts;
+        ts::StageTimer t(&ctx->ctx, "prove");
+        std::vector<uint32_t> proof = ts::prove_tap(pcs, air->prog, chal->c, std::move(trace->m), pis, locks);
+        *n_words_out = proof.size();
+        TS_REQUIRE(proof.size() <= cap_words, ts::TS_ERR_BUFFER, "proof buffer too small");
+        memcpy(proof_out, proof.data(), proof.size() * 4);
+    });
+}
+
+ts_status ts_verify_tap(const ts_fri_config* cfg, const ts_air* air, ts_challenger* chal,
+                        const uint32_t* proof, size_t n_words, const uint32_t* public_values,
+                        uint32_t n_public, const uint8_t* lock_scripts, const uint64_t* lock_offsets,
+                        size_t n_scripts, int* verdict) {
+    if (!air || !chal || !proof || !verdict || !lock_scripts || !lock_offsets) return TS_ERR_INVALID;
+    *verdict = -1;
+    return guard(nullptr, [&] {
+        ts::FriConfig f = load_cfg(cfg);
+        std::vector<uint32_t> pis;
+        if (n_public) {
+            TS_REQUIRE(public_values, ts::TS_ERR_INVALID, "null public values");
+            pis.assign(public_values, public_values + n_public);
+        }
+        for (size_t i = 0; i < n_scripts; i++)
+            TS_REQUIRE(lock_offsets[i + 1] >= lock_offsets[i], ts::TS_ERR_INVALID, "bad lock script offsets");
+        ts::TapLocks locks;
+        locks.bytes = lock_scripts;
+        locks.offsets = lock_offsets;
+        locks.n_scripts = n_scripts;
+        *verdict = ts::verify_tap(f, air->prog, chal->c, proof, n_words, pis, locks);
+    });
+}
+
 // ------------------------------------------------------------------ check_constraints
 ts_status ts_check_constraints(ts_ctx* ctx, const ts_air* air, const ts_matrix* trace,
                                const uint32_t* public_values, uint32_t n_public,

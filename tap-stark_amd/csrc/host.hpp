@@ -96,9 +96,10 @@ public:
     const FriConfig& fri() const { return fri_; }
     Context& ctx() const { return ctx_; }
 
-    // two_adic_pcs.rs:227-245.  Consumes the matrices.
+    // two_adic_pcs.rs:227-245.  Consumes the matrices.  build_tree = false stops after the LDE
+    // (a caller with another MMCS -- the taptree one -- commits to data->ldes itself).
     std::unique_ptr<PcsData> commit(std::vector<DeviceMatrix>& evals,
-                                    const std::vector<uint32_t>& domain_shifts);
+                                    const std::vector<uint32_t>& domain_shifts, bool build_tree = true);
 
     // two_adic_pcs.rs:247-258 + uni-stark prover.rs:122-194,78-80
     std::vector<DeviceMatrix> quotient_chunks(const PcsData& trace_data, const AirProgram& air,
@@ -182,6 +183,30 @@ struct ShardOptions {
 std::vector<uint32_t> prove_sharded(TwoAdicFriPcs& pcs, const Comm& comm, const AirProgram& air,
                                     BfChallenger& challenger, DeviceMatrix trace_rows,
                                     const std::vector<uint32_t>& public_values, const ShardOptions& opt);
+
+// ------------------------------------------------------------------ prove / verify over taptrees
+// The reference's own configuration: `TapTreeMmcs` (basic/src/mmcs/taptree_mmcs.rs:24-119) as the
+// MMCS of the PCS and of FRI (uni-stark/tests/fib_air.rs:117-131): every commitment is num_queries
+// taptrees, the challenger observes all their roots, query q opens in tree q.  `TapLocks` is the flat
+// table of lock scripts in commit order -- trace: Q (1 + w); quotient chunks: Q (1 + 4 qd); each of
+// the log2(n) FRI rounds: Q (1 + 2) -- i.e. the order in which the reference's bit-commitment
+// manager hands them out (tcs/mod.rs:251-260).  Proof = TSPF v2.
+struct TapLocks {
+    const uint8_t* bytes = nullptr;
+    const uint64_t* offsets = nullptr;  // n_scripts + 1 entries
+    size_t n_scripts = 0;
+};
+std::vector<uint32_t> prove_tap(TwoAdicFriPcs& pcs, const AirProgram& air, BfChallenger& challenger,
+                                DeviceMatrix trace, const std::vector<uint32_t>& public_values,
+                                const TapLocks& locks);
+int verify_tap(const FriConfig& fri, const AirProgram& air, BfChallenger& challenger,
+               const uint32_t* proof, size_t n_words, const std::vector<uint32_t>& public_values,
+               const TapLocks& locks);
+// verify_batch on words (taptree.cpp): leaf rebuilt from `locks[first .. first + n_evals]`, the index
+// and the opened values; digests as 8 words = their bytes read little-endian
+bool tap_verify_words(const TapLocks& locks, size_t first, uint32_t n_evals, uint32_t u32_size,
+                      uint64_t index, const uint32_t* values, const uint32_t* path_words, size_t depth,
+                      const uint32_t root_words[8]);
 
 // ------------------------------------------------------------------ verify (host only)
 // uni-stark/src/verifier.rs:19-161.  0 = accept; 1 InvalidProofShape, 2 InvalidOpeningArgument

@@ -125,7 +125,7 @@ void mmcs_commit(Context& ctx, PcsData& data) {
 // the tree itself is build-defined, see merkle.hip): leaves hash the rows of the tallest matrices,
 // and the rows of the matrices of height h are compressed into the level that has h nodes.
 std::unique_ptr<PcsData> TwoAdicFriPcs::commit(std::vector<DeviceMatrix>& evals,
-                                               const std::vector<uint32_t>& domain_shifts) {
+                                               const std::vector<uint32_t>& domain_shifts, bool build_tree) {
     TS_REQUIRE(!evals.empty() && evals.size() <= (size_t)MAX_BATCH_MATS, TS_ERR_INVALID,
                "commit: between 1 and MAX_BATCH_MATS (64) matrices per batch");
     TS_REQUIRE(evals.size() == domain_shifts.size(), TS_ERR_INVALID, "commit: one domain per matrix");
@@ -171,7 +171,7 @@ std::unique_ptr<PcsData> TwoAdicFriPcs::commit(std::vector<DeviceMatrix>& evals,
             m.buf.reset();  // consumed
         }
     }
-    mmcs_commit(ctx_, *data);
+    if (build_tree) mmcs_commit(ctx_, *data);
     return data;
 }
 

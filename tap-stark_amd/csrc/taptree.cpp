@@ -481,55 +481,103 @@ std::unique_ptr<TapMmcsData> tap_mmcs_commit(Context& ctx, std::vector<DeviceMat
         d->storage.push_back(std::move(cmaj));
         m.buf.reset();
     }
+    d->cols = DevBuf<const uint32_t*>(&ctx, cols.size());  // (kept for callers that walk the columns)
+    h2d(ctx, d->cols.p, cols.data(), cols.size() * sizeof(const uint32_t*));
+    TapLocks tl;
+    tl.bytes = d->lock_bytes.data();
+    tl.offsets = d->lock_offsets.data();
+    tl.n_scripts = d->lock_offsets.size() - 1;
+    d->trees = tap_build_trees(ctx, cols, shifts, 1, d->log_height, u32_size, num_queries, tl, 0, d->roots);
+    // the ABI of the stand-alone MMCS hands out digests as bytes: keep the state words here
+    for (auto& w : d->roots) w = __builtin_bswap32(w);
+    return d;
+}
+
+DevBuf<uint32_t> tap_build_trees(Context& ctx, const std::vector<const uint32_t*>& cols,
+                                 const std::vector<uint8_t>& shifts, uint32_t elem_stride,
+                                 unsigned log_height, uint32_t u32_size, uint32_t num_queries,
+                                 const TapLocks& locks, size_t first_lock, std::vector<uint32_t>& roots_words) {
+    const uint64_t N = 1ull << log_height;
+    const uint32_t n_evals = (uint32_t)(cols.size() / u32_size);
+    const size_t n_seg = 1 + (size_t)n_evals;
+    TS_REQUIRE(cols.size() % u32_size == 0 && cols.size() == shifts.size(), TS_ERR_INVALID, "tap trees: columns");
+    TS_REQUIRE(locks.offsets && first_lock + (size_t)num_queries * n_seg <= locks.n_scripts, TS_ERR_INVALID,
+               "tap trees: the lock-script table is too short for this commitment");
     // segments as big-endian words
     std::vector<uint32_t> seg_words;
     std::vector<uint64_t> seg_word_off((size_t)num_queries * n_seg), const_len(num_queries, 0);
     std::vector<uint32_t> seg_len((size_t)num_queries * n_seg);
     for (size_t s = 0; s < (size_t)num_queries * n_seg; s++) {
+        const uint64_t o0 = locks.offsets[first_lock + s], o1 = locks.offsets[first_lock + s + 1];
+        TS_REQUIRE(o1 >= o0 && o1 - o0 < (1ull << 24), TS_ERR_INVALID, "tap trees: bad lock script offsets");
         seg_word_off[s] = seg_words.size();
-        seg_len[s] = (uint32_t)(d->lock_offsets[s + 1] - d->lock_offsets[s]);
+        seg_len[s] = (uint32_t)(o1 - o0);
         const_len[s / n_seg] += seg_len[s];
-        pack_words(d->lock_bytes.data() + d->lock_offsets[s], seg_len[s], seg_words);
+        pack_words(locks.bytes + o0, seg_len[s], seg_words);
     }
     seg_words.push_back(0);
-    d->cols = DevBuf<const uint32_t*>(&ctx, cols.size());
+    DevBuf<const uint32_t*> d_cols(&ctx, cols.size());
     DevBuf<uint8_t> d_shift(&ctx, shifts.size());
     DevBuf<uint32_t> d_seg_words(&ctx, seg_words.size()), d_seg_len(&ctx, seg_len.size());
     DevBuf<uint64_t> d_seg_off(&ctx, seg_word_off.size()), d_const(&ctx, const_len.size());
-    h2d(ctx, d->cols.p, cols.data(), cols.size() * sizeof(const uint32_t*));
+    h2d(ctx, d_cols.p, cols.data(), cols.size() * sizeof(const uint32_t*));
     h2d(ctx, d_shift.p, shifts.data(), shifts.size());
     h2d(ctx, d_seg_words.p, seg_words.data(), seg_words.size() * 4);
     h2d(ctx, d_seg_len.p, seg_len.data(), seg_len.size() * 4);
     h2d(ctx, d_seg_off.p, seg_word_off.data(), seg_word_off.size() * 8);
     h2d(ctx, d_const.p, const_len.data(), const_len.size() * 8);
     const uint64_t stride = 2 * N - 1;
-    d->trees = DevBuf<uint32_t>(&ctx, (size_t)num_queries * stride * 8);
+    DevBuf<uint32_t> trees(&ctx, (size_t)num_queries * stride * 8);
     TapTemplate t;
     t.seg_words = d_seg_words.p;
     t.seg_word_off = d_seg_off.p;
     t.seg_len = d_seg_len.p;
     t.const_len = d_const.p;
-    t.cols = d->cols.p;
+    t.cols = d_cols.p;
     t.shift = d_shift.p;
-    t.n_evals = d->n_evals;
+    t.n_evals = n_evals;
     t.u32_size = u32_size;
+    t.elem_stride = elem_stride;
     t.tree_stride = stride;
     {
         StageTimer tm(&ctx, "taptree leaves");
-        launch_tapleaf_template(ctx, t, N, num_queries, tap_mid(), d->trees.p);
+        launch_tapleaf_template(ctx, t, N, num_queries, tap_mid(), trees.p);
     }
     {
         StageTimer tm(&ctx, "taptree branches");
-        launch_tapbranch_levels(ctx, d->trees.p, stride, d->log_height, num_queries, tap_mid());
+        launch_tapbranch_levels(ctx, trees.p, stride, log_height, num_queries, tap_mid());
     }
     // roots: the last digest of every tree
     DevBuf<uint32_t> d_roots(&ctx, (size_t)num_queries * 8);
     for (uint32_t q = 0; q < num_queries; q++)
-        TS_HIP(hipMemcpyAsync(d_roots.p + 8 * (size_t)q, d->trees.p + ((size_t)q * stride + stride - 1) * 8, 32,
+        TS_HIP(hipMemcpyAsync(d_roots.p + 8 * (size_t)q, trees.p + ((size_t)q * stride + stride - 1) * 8, 32,
                               hipMemcpyDeviceToDevice, ctx.stream));
-    d->roots.resize((size_t)num_queries * 8);
-    d2h_sync(ctx, d->roots.data(), d_roots.p, d->roots.size() * 4);  // also covers the pageable tables
-    return d;
+    roots_words.resize((size_t)num_queries * 8);
+    d2h_sync(ctx, roots_words.data(), d_roots.p, roots_words.size() * 4);  // also covers the pageable tables
+    for (auto& w : roots_words) w = __builtin_bswap32(w);  // state word -> its bytes read little-endian
+    return trees;
+}
+
+// verify_batch on words: leaf rebuilt from the lock scripts, the index and the opened values
+bool tap_verify_words(const TapLocks& locks, size_t first, uint32_t n_evals, uint32_t u32_size,
+                      uint64_t index, const uint32_t* values, const uint32_t* path_words, size_t depth,
+                      const uint32_t root_words[8]) {
+    if (!locks.offsets || first + n_evals + 1 > locks.n_scripts || depth > 128) return false;
+    for (uint32_t c = 0; c < n_evals * u32_size; c++)
+        if (values[c] >= P) return false;
+    std::vector<std::pair<const uint8_t*, size_t>> ls;
+    for (uint32_t s = 0; s <= n_evals; s++) {
+        const uint64_t o0 = locks.offsets[first + s], o1 = locks.offsets[first + s + 1];
+        if (o1 < o0) return false;
+        ls.push_back({locks.bytes + o0, (size_t)(o1 - o0)});
+    }
+    const std::vector<uint8_t> script = tap_leaf_script(ls, index, values, n_evals, u32_size);
+    uint32_t leaf[8], root[8];
+    tapleaf_hash(script.data(), script.size(), leaf);
+    std::vector<uint32_t> pw(8 * depth);
+    for (size_t k = 0; k < 8 * depth; k++) pw[k] = __builtin_bswap32(path_words[k]);
+    for (int k = 0; k < 8; k++) root[k] = __builtin_bswap32(root_words[k]);
+    return taptree_verify_inclusion(root, leaf, pw.data(), depth);
 }
 
 // open_batch (taptree_mmcs.rs:46-75): the rows at index >> bits_reduced, the leaf's sibling path in

@@ -160,7 +160,7 @@ k_tapleaf_template(TapTemplate t, uint64_t n_leaves, TapMid mid, uint32_t* __res
     // pass 1: the script length (it is hashed first, as a compact size)
     uint64_t len = t.const_len[q] + tap_push_int_len((uint32_t)idx) + 1;
     for (uint32_t c = 0; c < t.n_evals * t.u32_size; c++)
-        len += tap_push_int_len(t.cols[c][idx >> t.shift[c]]) + 1;
+        len += tap_push_int_len(t.cols[c][(idx >> t.shift[c]) * t.elem_stride]) + 1;
     len += 1;  // OP_1
     Stream s;
 #pragma unroll
@@ -175,7 +175,7 @@ k_tapleaf_template(TapTemplate t, uint64_t n_leaves, TapMid mid, uint32_t* __res
         s.put_segment(t.seg_words + seg_off[1 + j], seg_len[1 + j]);
         for (uint32_t l = t.u32_size; l-- > 0;) {
             const uint32_t c = j * t.u32_size + l;
-            s.put_push_int(t.cols[c][idx >> t.shift[c]]);
+            s.put_push_int(t.cols[c][(idx >> t.shift[c]) * t.elem_stride]);
             s.put_byte(0x88);
         }
     }

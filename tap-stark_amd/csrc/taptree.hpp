@@ -36,6 +36,8 @@ struct TapTemplate {
     const uint32_t* const* cols;       // [n_evals * u32_size] column base pointers of the padded row
     const uint8_t* shift;              // [n_evals * u32_size] row = leaf index >> shift
     uint32_t n_evals, u32_size;
+    uint32_t elem_stride;              // words between consecutive rows of a column (1: column-major;
+                                       // 8: an array of EF4 pairs, the FRI commit-phase matrices)
     uint64_t tree_stride;              // digests per tree (2 N - 1)
 };
 
@@ -50,5 +52,16 @@ void launch_tapbranch_levels(Context& ctx, uint32_t* trees, uint64_t tree_stride
 void launch_tap_gather_paths(Context& ctx, const uint32_t* trees, uint64_t tree_stride,
                              unsigned log_leaves, const uint32_t* tree_of, const uint64_t* index,
                              uint32_t n, uint32_t* out);
+
+// host (taptree.cpp): Q taptrees over N = 2^log_height leaves whose padded row is described by
+// `cols` / `shifts` / `elem_stride`; the lock scripts of tree q are scripts
+// [first_lock + q (1 + n_evals), ...) of the table.  Returns the trees ([Q][2N-1][8] state words);
+// roots_words receives Q x 8 words, each digest as its bytes read little-endian.
+struct TapLocks;
+DevBuf<uint32_t> tap_build_trees(Context& ctx, const std::vector<const uint32_t*>& cols,
+                                 const std::vector<uint8_t>& shifts, uint32_t elem_stride,
+                                 unsigned log_height, uint32_t u32_size, uint32_t num_queries,
+                                 const TapLocks& locks, size_t first_lock, std::vector<uint32_t>& roots_words);
+const TapMid& tap_mid();
 
 }  // namespace ts

@@ -134,9 +134,11 @@ void eval_tape_ext(const AirProgram& air, const Ef* local, const Ef* next,
 // verify_challenges / verify_query of fri/src/verifier.rs:20-165, for any rounds x matrices x points.
 // `words` = the FriProof (TSPF v1 order, from the commit-phase round count on).  Returns 0 or the
 // error code of include/tapstark.h ts_verify.
+// `tap` != nullptr: every commitment is num_queries taptree roots (8 words each, `root` points at
+// the first) and the MMCS checks are TapTreeMmcs::verify_batch in tree q (taptree_mmcs.rs:77-99)
 static int fri_verify_impl(const FriConfig& fri, BfChallenger& challenger,
                            const std::vector<PcsRoundClaim>& rounds, bool pass_through,
-                           const uint32_t* words, size_t n_words);
+                           const uint32_t* words, size_t n_words, const TapLocks* tap = nullptr);
 
 int pcs_verify(const FriConfig& fri, BfChallenger& challenger, const std::vector<PcsRoundClaim>& rounds,
                const uint32_t* words, size_t n_words) {
@@ -149,7 +151,8 @@ int fri_verify_pass_through(const FriConfig& fri, BfChallenger& challenger, cons
 
 static int fri_verify_impl(const FriConfig& fri, BfChallenger& challenger,
                            const std::vector<PcsRoundClaim>& rounds, bool pass_through,
-                           const uint32_t* words, size_t n_words) {
+                           const uint32_t* words, size_t n_words, const TapLocks* tap) {
+    const size_t n_roots = tap ? fri.num_queries : 1, cw = 8 * n_roots;
     Reader rb{words, n_words};
     unsigned log_global_max_height = 0;  // two_adic_pcs.rs:447-455
     for (auto& r : rounds)
@@ -163,13 +166,23 @@ static int fri_verify_impl(const FriConfig& fri, BfChallenger& challenger,
     const Ef batch_alpha = pass_through ? c_one() : challenger.sample();  // :443
     const uint32_t R = rb.get();
     if (rb.bad || R > 31) return 9;
-    const uint32_t* commits = rb.take(8 * (size_t)R);
+    const uint32_t* commits = rb.take(cw * (size_t)R);
     if (rb.bad) return 9;
     std::vector<Ef> betas(R);
     for (uint32_t r = 0; r < R; r++) {  // fri/src/verifier.rs:32-39
-        challenger.observe_commitment(commits + 8 * r);
+        for (size_t k = 0; k < n_roots; k++) challenger.observe_commitment(commits + cw * r + 8 * k);
         betas[r] = challenger.sample();
     }
+    // taptree: first lock script of every commitment (commit order: input rounds, then FRI rounds)
+    std::vector<size_t> lock_base(rounds.size());
+    size_t fri_lock_base = 0;
+    for (size_t r = 0; r < rounds.size(); r++) {
+        size_t tw = 0;
+        for (auto& m : rounds[r].mats) tw += m.width;
+        lock_base[r] = fri_lock_base;
+        fri_lock_base += n_roots * (1 + tw);
+    }
+    if (tap && tap->n_scripts < fri_lock_base + (size_t)R * n_roots * 3) return 1;
     const uint32_t Q = rb.get();
     if (rb.bad) return 9;
     if (Q != fri.num_queries) return 2;  // :39-41 InvalidProofShape
@@ -260,8 +273,19 @@ static int fri_verify_impl(const FriConfig& fri, BfChallenger& challenger,
             if (rb.bad) return 9;
             // :470-486 reduced_index = index >> (log_global_max_height - log_batch_max_height)
             const uint64_t reduced_index = index >> (log_global_max_height - log_batch_max);
-            if (!mmcs_verify(heights, widths, reduced_index, rows.data(), path, plen, round.root))
+            if (tap) {
+                // taptree_mmcs.rs:68-72: the opened rows must come tallest matrix first
+                for (size_t i = 1; i < heights.size(); i++)
+                    if (heights[i] > heights[i - 1]) return 4;
+                const size_t ri = (size_t)(&round - rounds.data());
+                const uint32_t n_evals = (uint32_t)rows.size();
+                if (plen != log_batch_max ||
+                    !tap_verify_words(*tap, lock_base[ri] + (size_t)q * (1 + n_evals), n_evals, 1, reduced_index,
+                                      rows.data(), path, plen, round.root + 8 * (size_t)q))
+                    return 4;
+            } else if (!mmcs_verify(heights, widths, reduced_index, rows.data(), path, plen, round.root)) {
                 return 4;  // InputError
+            }
             size_t off = 0;
             for (uint32_t i = 0; i < nm; i++) {  // :490-523
                 const PcsMatClaim& m = round.mats[i];
@@ -303,7 +327,14 @@ static int fri_verify_impl(const FriConfig& fri, BfChallenger& challenger,
             if (!ef_eq(folded_eval, committed)) return 8;
             std::vector<uint64_t> hh{1ull << log_folded_height};
             std::vector<uint32_t> ww{8};
-            if (!mmcs_verify(hh, ww, index_pair, vals, path, plen, commits + 8 * r)) return 5;  // :143-146
+            if (tap) {
+                if (plen != log_folded_height ||
+                    !tap_verify_words(*tap, fri_lock_base + ((size_t)r * n_roots + q) * 3, 2, 4, index_pair, vals,
+                                      path, plen, commits + cw * r + 8 * (size_t)q))
+                    return 5;
+            } else if (!mmcs_verify(hh, ww, index_pair, vals, path, plen, commits + 8 * r)) {
+                return 5;  // :143-146
+            }
             query_index = index_pair;
             folded_eval = fold_row(query_index, log_folded_height, betas[r], e0, e1);  // :149-154
         }
@@ -313,20 +344,37 @@ static int fri_verify_impl(const FriConfig& fri, BfChallenger& challenger,
 }
 
 // 0 = accept; otherwise the reference's error (see include/tapstark.h ts_verify)
+static int verify_impl(const FriConfig& fri, const AirProgram& air, BfChallenger& challenger,
+                       const uint32_t* proof, size_t n_words, const std::vector<uint32_t>& pis,
+                       const TapLocks* tap);
+
 int verify(const FriConfig& fri, const AirProgram& air, BfChallenger& challenger,
            const uint32_t* proof, size_t n_words, const std::vector<uint32_t>& pis) {
+    return verify_impl(fri, air, challenger, proof, n_words, pis, nullptr);
+}
+int verify_tap(const FriConfig& fri, const AirProgram& air, BfChallenger& challenger,
+               const uint32_t* proof, size_t n_words, const std::vector<uint32_t>& pis,
+               const TapLocks& locks) {
+    return verify_impl(fri, air, challenger, proof, n_words, pis, &locks);
+}
+
+static int verify_impl(const FriConfig& fri, const AirProgram& air, BfChallenger& challenger,
+                       const uint32_t* proof, size_t n_words, const std::vector<uint32_t>& pis,
+                       const TapLocks* tap) {
     if (pis.size() != air.n_public) return 1;
     Reader rb{proof, n_words};
-    if (rb.get() != 0x46505354u || rb.get() != 1) return 9;
+    if (rb.get() != 0x46505354u || rb.get() != (tap ? 2u : 1u)) return 9;
     const unsigned degree_bits = rb.get();
     const uint32_t pw = rb.get(), pqd = rb.get();
+    if (tap && rb.get() != fri.num_queries) return 1;  // TSPF v2: roots per commitment
     if (rb.bad || degree_bits > 27) return 9;
+    const size_t n_roots = tap ? fri.num_queries : 1, cw = 8 * n_roots;
     const unsigned lqd = air.log_quotient_degree;
     const uint32_t qd = 1u << lqd, w = air.width;
     // verifier.rs:49-59 valid_shape
     if (pw != w || pqd != qd) return 1;
-    const uint32_t* trace_root = rb.take(8);
-    const uint32_t* quot_root = rb.take(8);
+    const uint32_t* trace_root = rb.take(cw);
+    const uint32_t* quot_root = rb.take(cw);
     const Ef* trace_local = reinterpret_cast<const Ef*>(rb.take(4 * (size_t)w));
     const Ef* trace_next = reinterpret_cast<const Ef*>(rb.take(4 * (size_t)w));
     const Ef* qchunks = reinterpret_cast<const Ef*>(rb.take(16 * (size_t)qd));
@@ -339,9 +387,9 @@ int verify(const FriConfig& fri, const AirProgram& air, BfChallenger& challenger
                 if (e.c[k] >= P) return 9;
 
     // verifier.rs:69-75
-    challenger.observe_commitment(trace_root);
+    for (size_t k = 0; k < n_roots; k++) challenger.observe_commitment(trace_root + 8 * k);
     const Ef alpha = challenger.sample();
-    challenger.observe_commitment(quot_root);
+    for (size_t k = 0; k < n_roots; k++) challenger.observe_commitment(quot_root + 8 * k);
     const Ef zeta = challenger.sample();
     const uint32_t gn = two_adic_generator(degree_bits);
     const Ef zeta_next = c_mul_base(zeta, gn);
@@ -356,7 +404,7 @@ int verify(const FriConfig& fri, const AirProgram& air, BfChallenger& challenger
         r1.mats.push_back(PcsMatClaim{degree_bits + fri.log_blowup, 4, {zeta}, {vals}});
     }
     Reader fr{proof + rb.pos, n_words - rb.pos};
-    const int rc = pcs_verify(fri, challenger, {r0, r1}, fr.w, fr.len);
+    const int rc = fri_verify_impl(fri, challenger, {r0, r1}, false, fr.w, fr.len, tap);
     if (rc) return rc;
 
     // ---- verifier.rs:103-132 quotient recombination

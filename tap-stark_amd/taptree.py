@@ -189,3 +189,71 @@ class TapTreeMmcs:
                                                    (C.c_uint8 * max(len(pb), 1))(*pb), len(path),
                                                    (C.c_uint8 * 32)(*root), C.byref(ok)), "verify_batch")
         return bool(ok.value)
+
+
+# ------------------------------------------------------------------ prove / verify over taptrees
+def lock_table_shapes(width: int, quotient_degree: int, log_n: int):
+    """(n_evals, u32_size) of every commitment of one proof, in commit order: trace, quotient chunks,
+    then the log2(n) FRI rounds (rows of two EF4 elements)."""
+    return [(width, 1), (4 * quotient_degree, 1)] + [(2, 4)] * log_n
+
+
+def make_lock_table(num_queries: int, width: int, quotient_degree: int, log_n: int, lock_for):
+    """The flat lock-script table ``ts_prove_tap`` takes: for every commitment, for every tree q, the
+    index lock then one lock per evaluation.  ``lock_for(commit, q, slot, u32_count) -> bytes`` plays
+    the reference's bit-commitment manager (tcs/mod.rs:251-260 ``assign_bc``)."""
+    locks = []
+    for ci, (n_evals, u32) in enumerate(lock_table_shapes(width, quotient_degree, log_n)):
+        for q in range(num_queries):
+            for s in range(1 + n_evals):
+                locks.append(lock_for(ci, q, s, 1 if s == 0 else u32))
+    return locks
+
+
+def prove_tap(config, air, challenger, trace, public_values, locks):
+    """``uni_stark::prove`` with ``TapTreeMmcs`` as both MMCSs (``ts_prove_tap``); returns the
+    TSPF v2 words."""
+    from .air import BaseAir, air_tape
+    from .stark import CompiledAir
+
+    pcs = config.pcs
+    ctx = pcs.ctx
+    pis = _u32(public_values)
+    if isinstance(air, BaseAir):
+        air = CompiledAir(ctx, air_tape(air, len(pis)))
+    if not isinstance(trace, DeviceMatrix):
+        trace = DeviceMatrix.upload(ctx, trace)
+    n, w = trace.dims()
+    log_n = n.bit_length() - 1
+    log_N = log_n + pcs.fri.log_blowup
+    qd = 1 << air.log_quotient_degree
+    Q = pcs.fri.num_queries
+    cap = 64 + 8 * w + 16 * qd + 16 * Q + 8 * Q * log_n + Q * (16 + w + 5 * qd + 16 * log_N + log_n * (9 + 8 * log_N))
+    out = np.zeros(cap, dtype=np.uint32)
+    n_words = C.c_size_t()
+    cfg = pcs.fri._c()
+    blob, offs = _pack(locks)
+    ctx.check(ctx._l.ts_prove_tap(ctx.h, C.byref(cfg), air.h, challenger.h, trace.h,
+                                  _p(pis) if len(pis) else None, len(pis), blob,
+                                  offs.ctypes.data_as(C.POINTER(C.c_uint64)), len(locks), _p(out), cap,
+                                  C.byref(n_words)))
+    return out[: n_words.value].copy()
+
+
+def verify_tap(config, air, challenger, proof_words, public_values, locks) -> int:
+    """``uni_stark::verify`` for a TSPF v2 proof (host only): 0 = accept, else the verdict code."""
+    from .air import BaseAir, air_tape
+    from .stark import CompiledAir
+
+    pis = _u32(public_values)
+    if isinstance(air, BaseAir):
+        air = CompiledAir(None, air_tape(air, len(pis)))
+    words = _u32(proof_words)
+    cfg = config.pcs.fri._c()
+    blob, offs = _pack(locks)
+    verdict = C.c_int(-1)
+    _check(_lib.lib().ts_verify_tap(C.byref(cfg), air.h, challenger.h, _p(words), len(words),
+                                    _p(pis) if len(pis) else None, len(pis), blob,
+                                    offs.ctypes.data_as(C.POINTER(C.c_uint64)), len(locks), C.byref(verdict)),
+           "ts_verify_tap")
+    return int(verdict.value)

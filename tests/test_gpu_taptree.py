@@ -167,3 +167,59 @@ def test_taptree_mmcs_refuses_what_the_reference_panics_on(ctx):
     assert e.value.code == 5
     with pytest.raises(TsError):  # width not a multiple of U32_SIZE
         tt.TapTreeMmcs(1, lambda q, n: locks_for(q, n, 4), u32_size=4, ctx=ctx).commit([np.zeros((4, 6), dtype=np.uint32)])
+
+
+# ------------------------------------------------------------------ prove() over taptrees
+def _lock_for(ci, q, s, u32):
+    return tt.winternitz_lock_script(bytes([ci, q, s & 0xFF, s >> 8]), u32)
+
+
+TAP_PROOFS = [
+    # uni-stark/tests/fib_air.rs:117-149 (test_public_value): Fibonacci 2^3, log_blowup 2, 28 queries, 8 PoW bits
+    ("fib8_q28", "fib", 3, (2, 28, 8)),
+    ("fib8_q6", "fib", 3, (2, 6, 8)),     # fib_air.rs:151-192 uses 6 queries
+    ("fib2p7_b1", "fib", 7, (1, 5, 8)),
+    ("mul7_2p5_b3", "mul7", 5, (3, 4, 4)),   # quotient degree 2: two chunk matrices in one commitment
+    ("mul64_2p6", "mul64", 6, (2, 3, 8)),    # 65 lock scripts per trace leaf
+]
+
+
+@pytest.mark.parametrize("name,air_name,log_n,cfg", TAP_PROOFS, ids=[c[0] for c in TAP_PROOFS])
+def test_prove_over_taptrees_bit_identical_to_oracle(ctx, orc, name, air_name, log_n, cfg):
+    from tapstark_amd.airs import (FibonacciAir, SynthMulAir, fibonacci_public_values,
+                                   generate_fibonacci_trace, generate_synth_mul_trace)
+
+    n = 1 << log_n
+    if air_name == "fib":
+        air, trace = FibonacciAir(), generate_fibonacci_trace(0, 1, n)
+        pis = fibonacci_public_values(trace)
+    else:
+        w = int(air_name[3:])
+        air, trace, pis = SynthMulAir(w), generate_synth_mul_trace(n, w), np.zeros(0, dtype=np.uint32)
+    tape = ts.air_tape(air, len(pis))
+    qd = 1 << ts.get_log_quotient_degree(air, len(pis))
+    locks = tt.make_lock_table(cfg[1], trace.shape[1], qd, log_n, _lock_for)
+    config = ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(*cfg), ctx))
+    ch = ts.BfChallenger()
+    proof = tt.prove_tap(config, air, ch, trace, pis, locks)
+    ocfg = orc.FriConfig(*cfg)
+    och = orc.OracleChallenger()
+    want = orc.prove_tap(ocfg, tape, trace, pis, locks, och)
+    assert orc.verify_tap(ocfg, tape, proof, pis, locks) == 0, "oracle verifier rejects the GPU proof"
+    assert tt.verify_tap(config, air, ts.BfChallenger(), proof, pis, locks) == 0  # prove, then verify afresh
+    assert len(proof) == len(want)
+    assert (proof == want).all(), f"{int((proof != want).sum())} proof words differ"
+    assert ch.sample_bits(20) == och.sample_bits(20)  # the caller's challenger ends in the same state
+    bad = proof.copy()
+    bad[len(bad) // 2] ^= 1
+    assert tt.verify_tap(config, air, ts.BfChallenger(), bad, pis, locks) != 0
+
+
+def test_prove_over_taptrees_refuses_a_short_lock_table(ctx):
+    from tapstark_amd.airs import FibonacciAir, fibonacci_public_values, generate_fibonacci_trace
+
+    trace = generate_fibonacci_trace(0, 1, 8)
+    locks = tt.make_lock_table(4, 2, 1, 3, _lock_for)
+    config = ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(2, 4, 8), ctx))
+    with pytest.raises(TsError):
+        tt.prove_tap(config, FibonacciAir(), ts.BfChallenger(), trace, fibonacci_public_values(trace), locks[:-1])

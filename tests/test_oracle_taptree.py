@@ -226,3 +226,60 @@ def test_winternitz_lock_script_stand_in(lib):
     assert s.endswith(bytes([0x6C, 0x63, 0x8F, 0x68]))  # u32_compress: OP_FROMALTSTACK OP_IF OP_NEGATE OP_ENDIF
     s4 = tt.winternitz_lock_script(secret, 4)
     assert len(s4) == 4 * (len(s) + 1) + 4 and s4.endswith(bytes([0x6C]) * 4)
+
+
+# ------------------------------------------------------------------ prove/verify over taptrees (host side)
+def _lock_for(ci, q, s, u32):
+    return tt.winternitz_lock_script(bytes([ci, q, s & 0xFF, s >> 8]), u32)
+
+
+def _tap_case(name, log_n, cfg):
+    import tapstark_amd as ts
+    from tapstark_amd.airs import (FibonacciAir, SynthMulAir, fibonacci_public_values,
+                                   generate_fibonacci_trace, generate_synth_mul_trace)
+
+    n = 1 << log_n
+    if name == "fib":
+        air, trace = FibonacciAir(), generate_fibonacci_trace(0, 1, n)
+        pis = fibonacci_public_values(trace)
+    else:
+        air, trace, pis = SynthMulAir(7), generate_synth_mul_trace(n, 7), np.zeros(0, dtype=np.uint32)
+    tape = ts.air_tape(air, len(pis))
+    qd = 1 << ts.get_log_quotient_degree(air, len(pis))
+    locks = tt.make_lock_table(cfg[1], trace.shape[1], qd, log_n, _lock_for)
+    return air, trace, pis, tape, locks
+
+
+@pytest.mark.parametrize("name,log_n,cfg", [("fib", 3, (2, 4, 8)), ("fib", 5, (1, 3, 4)), ("mul7", 4, (2, 3, 8))],
+                         ids=["fib8-q4", "fib32-b1", "mul7-16"])
+def test_native_verify_tap_on_oracle_proofs(orc, lib, name, log_n, cfg):
+    # the reference's own configuration (uni-stark/tests/fib_air.rs:117-149: TapTreeMmcs as both
+    # MMCSs): prover = oracle in taptree mode, verifier = the product's host code; verdicts on
+    # tampered proofs must agree with the oracle's verifier
+    import tapstark_amd as ts
+
+    air, trace, pis, tape, locks = _tap_case(name, log_n, cfg)
+    ocfg = orc.FriConfig(*cfg)
+    proof = orc.prove_tap(ocfg, tape, trace, pis, locks)
+    assert proof[1] == 2 and proof[5] == cfg[1]  # TSPF v2, num_queries roots per commitment
+    assert orc.verify_tap(ocfg, tape, proof, pis, locks) == 0
+    config = ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(*cfg), host_only=True))
+    assert tt.verify_tap(config, air, ts.BfChallenger(), proof, pis, locks) == 0
+    # a v2 proof is not a v1 proof and vice versa
+    with pytest.raises(ts.VerificationError):
+        ts.verify(config, air, ts.BfChallenger(), proof, pis)
+    rng = np.random.default_rng(3)
+    rejected = 0
+    for pos in [6, 6 + 8 * cfg[1] + 3, len(proof) - 1, len(proof) - 3] + [int(x) for x in rng.integers(6, len(proof), 12)]:
+        bad = proof.copy()
+        bad[pos] = (int(bad[pos]) + 1) % P if bad[pos] < P else int(bad[pos]) ^ 1
+        want = orc.verify_tap(ocfg, tape, bad, pis, locks)
+        got = tt.verify_tap(config, air, ts.BfChallenger(), bad, pis, locks)
+        assert (got == 0) == (want == 0) and (got == want or {got, want} <= {4, 5, 8, 9, 1}), (pos, got, want)
+        rejected += want != 0
+    assert rejected >= 12
+    # another prover's bit commitments: the leaves do not rebuild
+    other = list(locks)
+    other[3] = other[3][:-2] + b"\x51\x51"
+    assert tt.verify_tap(config, air, ts.BfChallenger(), proof, pis, other) != 0
+    assert orc.verify_tap(ocfg, tape, proof, pis, other) != 0

@@ -481,7 +481,7 @@ def main():
             return sum(v["ms_per_proof"] for k, v in per_kernel.items() if any(x in k for x in names))
         bf_peak, b3_peak = ctx.alu_ceiling(0), ctx.alu_ceiling(1)
         ntt_ms = ms_of("k_intt_contig", "k_lde_mid", "k_lde_fwd_contig")
-        b3_ms = ms_of("k_leaf_hash", "k_merkle_level", "k_merkle_top", "k_merkle_subtree")
+        b3_ms = ms_of("k_leaf_hash", "k_merkle_level", "k_merkle_top", "k_merkle_subtree")  # (matches _lds too)
         alu_ceiling = {
             "butterflies_per_s_peak": round(bf_peak), "butterflies_per_proof": butterflies,
             "ntt_kernels_ms": round(ntt_ms, 4), "ntt_ms_at_peak": round(butterflies / bf_peak * 1e3, 4),

@@ -494,7 +494,7 @@ def main():
         # ---- the rate a caller sees who hands over HOST traces (never `value`): pinned buffer,
         # asynchronous upload on each lane's stream, the upload of one lane overlapping the proofs of the others
         h2d = None
-        if not sharded and not args.host_traces and args.workload in ("config3", "config2") and S > 1:
+        if env.world == 1 and not sharded and not args.host_traces and args.workload in ("config3", "config2") and S > 1:
             try:
                 pin = ts.PinnedHostMatrix(n, w)
                 pin.array[:] = make_trace(ctx).download()
@@ -516,7 +516,8 @@ def main():
                                "region (hipMemcpyAsync on the lane's stream); PCIe Gen5 x16 bounds it"}
             except Exception as e:  # never let the extra leg take the headline down
                 h2d = {"error": repr(e)}
-        cpu = None if args.no_cpu_baseline else cpu_baseline()
+        # (the contract: timed on rank 0 at N = 1 only)
+        cpu = None if (args.no_cpu_baseline or env.world > 1) else cpu_baseline()
         proof = last["proof"]
         out = {
             "metric": "trace cells/sec (proofs/sec alongside), 2^20x64 BabyBear trace",

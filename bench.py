@@ -199,6 +199,11 @@ def main():
                     help="independent proofs in flight per GPU (one context = one HIP stream and one "
                          "host thread each); the K timed steps are shared among them")
     args = ap.parse_args()
+    # Native libraries print to stdout on their own (RCCL's version banner at communicator creation):
+    # everything but the one JSON line goes to stderr, the line itself to the real stdout at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     if args.log_n is None:
         args.log_n = 22 if args.workload == "config4" else 20
     sharded = args.mode == "sharded"
@@ -554,7 +559,8 @@ def main():
         dist.destroy_process_group()
     env.close()
     if out is not None:
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
 
 
 if __name__ == "__main__":

@@ -67,9 +67,9 @@ struct ByteWriter {
         for (int i = 0; i < 8; i++)
             for (int k = 0; k < 4; k++) b.push_back((uint8_t)(d[i] >> (8 * k)));
     }
-    void commitment(const uint32_t* d) {
-        varint(1);
-        digest(d);
+    void commitment(const uint32_t* d, uint32_t n_roots = 1) {  // Vec<[[u8; 4]; 8]>
+        varint(n_roots);
+        for (uint32_t k = 0; k < n_roots; k++) digest(d + 8 * (size_t)k);
     }
 };
 
@@ -112,9 +112,15 @@ struct ByteReader {
             out.push_back(w);
         }
     }
-    void commitment(std::vector<uint32_t>& out) {
-        if (varint() != 1) bad = true;
-        digest(out);
+    // a commitment with exactly `n_roots` roots (0: read the count and return it)
+    uint64_t commitment(std::vector<uint32_t>& out, uint64_t n_roots = 1) {
+        const uint64_t n = varint();
+        if (n_roots ? n != n_roots : (n == 0 || n > 4096)) {
+            bad = true;
+            return 0;
+        }
+        for (uint64_t k = 0; k < n && !bad; k++) digest(out);
+        return n;
     }
 };
 
@@ -127,15 +133,20 @@ constexpr uint64_t MAX_COUNT = 1u << 24;
 bool tspf_to_postcard(const uint32_t* words, size_t n_words, std::vector<uint8_t>& out) {
     WordReader r{words, n_words};
     ByteWriter w{out};
-    if (r.get() != TSPF_MAGIC || r.get() != 1) return false;
+    if (r.get() != TSPF_MAGIC) return false;
+    const uint32_t version = r.get();
+    if (version != 1 && version != 2) return false;
     const uint32_t degree_bits = r.get(), width = r.get(), qd = r.get();
-    if (r.bad || qd > 64) return false;
+    // TSPF v2 (proofs over the taptree MMCS): num_queries roots per commitment, as the reference's
+    // `Commitment = Vec<TreeRoot>` (basic/src/mmcs/taptree_mmcs.rs:43)
+    const uint32_t n_roots = version == 2 ? r.get() : 1;
+    if (r.bad || qd > 64 || n_roots == 0 || n_roots > 4096) return false;
     // commitments
-    const uint32_t* tc = r.take(8);
-    const uint32_t* qc = r.take(8);
+    const uint32_t* tc = r.take(8 * (size_t)n_roots);
+    const uint32_t* qc = r.take(8 * (size_t)n_roots);
     if (r.bad) return false;
-    w.commitment(tc);
-    w.commitment(qc);
+    w.commitment(tc, n_roots);
+    w.commitment(qc, n_roots);
     // opened_values
     for (int k = 0; k < 2; k++) {  // trace_local, trace_next
         const uint32_t* v = r.take(4 * (size_t)width);
@@ -155,9 +166,9 @@ bool tspf_to_postcard(const uint32_t* words, size_t n_words, std::vector<uint8_t
     if (r.bad || R > 64) return false;
     w.varint(R);
     for (uint32_t i = 0; i < R; i++) {
-        const uint32_t* d = r.take(8);
+        const uint32_t* d = r.take(8 * (size_t)n_roots);
         if (r.bad) return false;
-        w.commitment(d);
+        w.commitment(d, n_roots);
     }
     const uint32_t Q = r.get();
     if (r.bad || Q > MAX_COUNT) return false;
@@ -209,9 +220,10 @@ bool tspf_to_postcard(const uint32_t* words, size_t n_words, std::vector<uint8_t
 // a shape TSPF cannot hold, trailing bytes).
 bool postcard_to_tspf(const uint8_t* bytes, size_t n_bytes, std::vector<uint32_t>& out) {
     ByteReader r{bytes, n_bytes};
-    std::vector<uint32_t> body;  // everything after the 5 header words
-    r.commitment(body);
-    r.commitment(body);
+    std::vector<uint32_t> body;  // everything after the header words
+    const uint64_t n_roots = r.commitment(body, 0);  // 1: TSPF v1; more: v2
+    if (r.bad) return false;
+    r.commitment(body, n_roots);
     uint64_t width = 0;
     for (int k = 0; k < 2; k++) {
         const uint64_t wd = r.varint();
@@ -229,7 +241,7 @@ bool postcard_to_tspf(const uint8_t* bytes, size_t n_bytes, std::vector<uint32_t
     const uint64_t R = r.varint();
     if (r.bad || R > 64) return false;
     body.push_back((uint32_t)R);
-    for (uint64_t i = 0; i < R; i++) r.commitment(body);
+    for (uint64_t i = 0; i < R && !r.bad; i++) r.commitment(body, n_roots);
     const uint64_t Q = r.varint();
     if (r.bad || Q > MAX_COUNT || !r.fits(Q, 1)) return false;
     body.push_back((uint32_t)Q);
@@ -273,10 +285,11 @@ bool postcard_to_tspf(const uint8_t* bytes, size_t n_bytes, std::vector<uint32_t
     out.clear();
     out.reserve(5 + body.size());
     out.push_back(TSPF_MAGIC);
-    out.push_back(1);
+    out.push_back(n_roots == 1 ? 1 : 2);
     out.push_back((uint32_t)degree_bits);
     out.push_back((uint32_t)width);
     out.push_back((uint32_t)qd);
+    if (n_roots != 1) out.push_back((uint32_t)n_roots);
     out.insert(out.end(), body.begin(), body.end());
     return true;
 }

@@ -607,15 +607,22 @@ class Proof:
             return out
 
         magic, version, degree_bits, width, qd = (int(x) for x in take(5))
-        if magic != TSPF_MAGIC or version != 1:
-            raise ValueError("not a TSPF v1 proof")
-        d = {"degree_bits": degree_bits, "query_proofs": []}
-        d["trace_commit"], d["quotient_commit"] = take(8), take(8)
+        if magic != TSPF_MAGIC or version not in (1, 2):
+            raise ValueError("not a TSPF v1/v2 proof")
+        # v2 (proofs over the taptree MMCS, ts_prove_tap): num_queries roots per commitment, the
+        # commitment fields are (num_queries, 8) arrays
+        nr = int(take(1)[0]) if version == 2 else 1
+        d = {"degree_bits": degree_bits, "query_proofs": [], "version": version}
+        if version == 1:
+            d["trace_commit"], d["quotient_commit"] = take(8), take(8)
+        else:
+            d["trace_commit"], d["quotient_commit"] = take(8 * nr).reshape(nr, 8), take(8 * nr).reshape(nr, 8)
         d["trace_local"] = take(4 * width).reshape(width, 4)
         d["trace_next"] = take(4 * width).reshape(width, 4)
         d["quotient_chunks"] = take(16 * qd).reshape(qd, 4, 4)
         R = int(take(1)[0])
-        d["commit_phase_commits"] = take(8 * R).reshape(R, 8)
+        d["commit_phase_commits"] = (take(8 * R).reshape(R, 8) if version == 1
+                                     else take(8 * nr * R).reshape(R, nr, 8))
         Q = int(take(1)[0])
         for _ in range(Q):
             nb = int(take(1)[0])

@@ -283,3 +283,19 @@ def test_native_verify_tap_on_oracle_proofs(orc, lib, name, log_n, cfg):
     other[3] = other[3][:-2] + b"\x51\x51"
     assert tt.verify_tap(config, air, ts.BfChallenger(), proof, pis, other) != 0
     assert orc.verify_tap(ocfg, tape, proof, pis, other) != 0
+
+
+def test_postcard_round_trip_of_a_proof_over_taptrees(orc, lib):
+    # TSPF v2 <-> postcard: Commitment = Vec<[[u8; 4]; 8]> with num_queries roots
+    # (basic/src/mmcs/taptree_mmcs.rs:43); everything else as for v1
+    import tapstark_amd as ts
+
+    cfg = (2, 4, 8)
+    air, trace, pis, tape, locks = _tap_case("fib", 3, cfg)
+    proof = orc.prove_tap(orc.FriConfig(*cfg), tape, trace, pis, locks)
+    data = ts.Proof(words=proof).to_postcard()
+    assert data[0] == 4 and data[1:33] == proof[6:14].astype("<u4").tobytes()  # varint(Q) then the first root
+    back = ts.Proof.from_postcard(data)
+    assert (back.words == proof).all()
+    config = ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(*cfg), host_only=True))
+    assert tt.verify_tap(config, air, ts.BfChallenger(), back.words, pis, locks) == 0

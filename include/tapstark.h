@@ -405,8 +405,8 @@ ts_status ts_verify_tap(const ts_fri_config* cfg, const ts_air* air, ts_challeng
                         uint32_t n_public, const uint8_t* lock_scripts, const uint64_t* lock_offsets,
                         size_t n_scripts, int* verdict);
 
-/* Measurement aid: the whole-chip rate of NTT butterflies (kind 0) or Blake3 compressions (kind 1)
- * with no memory traffic, using the library's own arithmetic -- the integer-ALU ceiling bench.py
+/* Measurement aid: the whole-chip rate of NTT butterflies (kind 0), Blake3 compressions (kind 1) or
+ * SHA-256 compressions (kind 2) with no memory traffic, using the library's own arithmetic -- the integer-ALU ceiling bench.py
  * reports beside the achieved rates. */
 ts_status ts_bench_alu(ts_ctx* ctx, int kind, double* units_per_second);
 

@@ -5,6 +5,7 @@
 // HBM-bound" is a measured statement of the same run rather than a derivation.
 #include "blake3.hpp"
 #include "kernels.hpp"
+#include "sha256.hpp"
 
 namespace ts {
 
@@ -56,11 +57,29 @@ __global__ void __launch_bounds__(256) k_alu_blake3(uint32_t* __restrict__ out, 
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+constexpr int SHA_ITER = 32;
+__global__ void __launch_bounds__(256) k_alu_sha256(uint32_t* __restrict__ out, uint32_t seed) {
+    uint32_t m[16], h[8];
+    sha::iv(h);
+#pragma unroll
+    for (int i = 0; i < 16; i++) m[i] = seed * (i + 1) + threadIdx.x + blockIdx.x * 977;
+    for (int it = 0; it < SHA_ITER; it++) {
+        sha::compress(h, m);
+#pragma unroll
+        for (int i = 0; i < 8; i++) m[i] ^= h[i];
+    }
+    uint32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) s ^= h[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 }  // namespace
 
-// kind 0: NTT butterflies per second; kind 1: Blake3 compressions per second (whole chip)
+// kind 0: NTT butterflies per second; kind 1: Blake3 compressions per second; kind 2: SHA-256
+// compressions per second (whole chip)
 double alu_ceiling(Context& ctx, int kind) {
-    TS_REQUIRE(kind == 0 || kind == 1, TS_ERR_INVALID, "alu_ceiling: kind is 0 (butterflies) or 1 (blake3)");
+    TS_REQUIRE(kind >= 0 && kind <= 2, TS_ERR_INVALID, "alu_ceiling: kind is 0 (butterflies), 1 (blake3) or 2 (sha256)");
     const int blocks = ctx.num_cus * 16, threads = 256, reps = 5;
     DevBuf<uint32_t> out(&ctx, (size_t)blocks * threads);
     hipEvent_t e0, e1;
@@ -69,8 +88,10 @@ double alu_ceiling(Context& ctx, int kind) {
     auto launch = [&] {
         if (kind == 0)
             hipLaunchKernelGGL(k_alu_butterflies, dim3(blocks), dim3(threads), 0, ctx.stream, out.p, 12345u);
-        else
+        else if (kind == 1)
             hipLaunchKernelGGL(k_alu_blake3, dim3(blocks), dim3(threads), 0, ctx.stream, out.p, 12345u);
+        else
+            hipLaunchKernelGGL(k_alu_sha256, dim3(blocks), dim3(threads), 0, ctx.stream, out.p, 12345u);
     };
     launch();  // warm-up (code object load, clocks)
     TS_HIP(hipEventRecord(e0, ctx.stream));
@@ -82,7 +103,7 @@ double alu_ceiling(Context& ctx, int kind) {
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     const double per = (double)ms / reps * 1e-3;
-    const double units = kind == 0 ? (double)BF_ITER * BF_ILP : (double)B3_ITER;
+    const double units = kind == 0 ? (double)BF_ITER * BF_ILP : kind == 1 ? (double)B3_ITER : (double)SHA_ITER;
     return units * blocks * threads / per;
 }
 

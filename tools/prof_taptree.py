@@ -50,6 +50,7 @@ def main():
         "leaf_script_bytes": script_len, "compressions_per_leaf": compress_per_leaf,
         "k_tapleaf_template_ms": round(leaf_ms, 4),
         "sha256_compressions_per_s": round(leaves * compress_per_leaf / (leaf_ms * 1e-3), 0),
+        "sha256_compressions_per_s_alu_peak": round(ctx.alu_ceiling(2), 0),
         "leaf_script_GB_per_s": round(leaves * script_len / (leaf_ms * 1e-3) / 1e9, 2),
         "k_tapbranch_levels_ms": round(branch_ms, 4),
         "commit_wall_ms": round(wall * 1e3, 3),

@@ -54,8 +54,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
             continue
         if src.endswith(".hip"):
             cmd = [hipcc, f"--offload-arch={ARCH}", "-x", "hip", *common, "-c", sp, "-o", op]
-        else:
-            cmd = [hipcc, *common, "-c", sp, "-o", op]
+        else:  # host sources include HIP headers: same single target, no stray default-arch device code
+            cmd = [hipcc, f"--offload-arch={ARCH}", *common, "-c", sp, "-o", op]
         jobs.append(cmd)
 
     def run(cmd):

@@ -10,9 +10,8 @@ use std::rc::Rc;
 
 use p3_air::Air;
 use p3_field::{Field, PrimeField32};
-use uni_stark::symbolic_builder::{get_symbolic_constraints, SymbolicAirBuilder};
-use uni_stark::symbolic_expression::SymbolicExpression;
-use uni_stark::symbolic_variable::Entry;
+// (uni-stark keeps its modules private and re-exports their items at the crate root, src/lib.rs:24-35)
+use uni_stark::{get_symbolic_constraints, Entry, SymbolicAirBuilder, SymbolicExpression};
 
 const TAPE_MAGIC: u32 = 0x5441_5354;
 const OP_CONST: u32 = 0;

@@ -7,7 +7,7 @@ use p3_air::Air;
 use p3_field::PrimeField32;
 use p3_matrix::dense::RowMajorMatrix;
 use p3_matrix::Matrix;
-use uni_stark::symbolic_builder::SymbolicAirBuilder;
+use uni_stark::SymbolicAirBuilder;
 
 use crate::context::{DeviceMatrix, GpuChallenger, GpuContext};
 use crate::ffi::*;

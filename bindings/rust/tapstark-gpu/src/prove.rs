@@ -10,7 +10,7 @@ use p3_commit::PolynomialSpace;
 use p3_field::{AbstractField, PrimeField32};
 use p3_matrix::dense::RowMajorMatrix;
 use p3_matrix::Matrix;
-use uni_stark::symbolic_builder::SymbolicAirBuilder;
+use uni_stark::SymbolicAirBuilder;
 
 use basic::bf_pcs::Pcs;
 

@@ -1,6 +1,11 @@
 //! `impl Pcs<Challenge, GpuChallenger> for GpuFriPcs` -- the reference's PCS trait
 //! (basic/src/bf_pcs.rs:19-88) over the library: `ProverData` is a device handle, the LDE never
 //! leaves HBM.  Mirrors `TwoAdicFriPcs` (fri/src/two_adic_pcs.rs:203-535).
+//!
+//! `StarkGenericConfig::Pcs` additionally demands `PcsExpr` (uni-stark/src/config.rs:35-41: the
+//! Bitcoin-script form of the verifier, out of scope here), so `GpuFriPcs` cannot be the `Pcs` of
+//! the reference's `StarkConfig` as it stands; `prove_gpu` / `prove_gpu_stepwise` (prove.rs) take
+//! it directly and return the same `Proof` fields.
 use std::ptr;
 
 use basic::bf_pcs::{OpenedValues as PcsOpenedValues, Pcs};

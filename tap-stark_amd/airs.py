@@ -117,6 +117,33 @@ def generate_synth_mul_trace(n: int, width: int = 64, seed: int = SPLITMIX_SEED)
     return t.astype(np.uint32)
 
 
+class HighDegreeAir(BaseAir):
+    """Build-defined two-column AIR whose one constraint has degree ``degree``: ``a^(degree-1) * b = 0``
+    with b = 0 (so quotient_degree = 2^ceil(log2(degree - 1)): 32 for degree 33) plus the transition
+    ``a + 1 = a'``.  Exercises quotient degrees above 16 (``log_quotient_degree <= log_blowup``)."""
+
+    def __init__(self, degree: int = 33):
+        self.degree = degree
+
+    def width(self) -> int:
+        return 2
+
+    def eval(self, builder) -> None:
+        main = builder.main()
+        local, nxt = main.row_slice(0), main.row_slice(1)
+        acc = local[0]
+        for _ in range(self.degree - 2):
+            acc = acc * local[0]
+        builder.assert_zero(acc * local[1])
+        builder.when_transition().assert_eq(local[0] + 1, nxt[0])
+
+
+def generate_high_degree_trace(n: int) -> np.ndarray:
+    t = np.zeros((n, 2), dtype=np.uint32)
+    t[:, 0] = (np.arange(n, dtype=np.uint64) + np.uint64(5)) % np.uint64(P)
+    return t
+
+
 class SynthExtAir(BaseAir):
     """Build-defined "SynthExt-w" stand-in for the RISC0-recursion-style config (SURVEY.md
     section 8(d) config 5): columns are ``groups`` triples of EF4 elements (x, y, z: 12 base

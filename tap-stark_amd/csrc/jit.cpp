@@ -75,8 +75,8 @@ __device__ __forceinline__ u64 lazy_fix(u64 acc) {
     return ((u64)hi << 32) | (u32)acc;
 }
 __device__ __forceinline__ u32 lazy_finish(u64 acc) { return mont_reduce(lazy_fix(acc)); }
-struct QC { u32 inv_zh[16]; };
-struct QO { u32* chunk[16]; };
+struct QC { u32 inv_zh[64]; };  // = QuotConsts
+struct QO { u32* chunk[64]; };  // = QuotOut, MAX_QUOTIENT_CHUNKS
 extern "C" __global__ void __launch_bounds__(256)
 k_quotient_jit(const u32* __restrict__ lde, u64 col_stride, unsigned log_n, unsigned log_qd,
                const u32* __restrict__ C, const u32* __restrict__ AP, const u32* __restrict__ isf,

@@ -98,8 +98,9 @@ void launch_selectors(Context& ctx, unsigned log_n, unsigned log_qd, uint32_t* i
                       uint32_t* is_last, uint32_t* is_transition);
 // quotient chunks, each written column-major (4 columns x n) with bit-reversed rows:
 // coefficient k of chunk c at chunk[c][k * n + pos]
+constexpr int MAX_QUOTIENT_CHUNKS = 64;  // quotient_degree <= 64 (log_quotient_degree <= log_blowup <= 8)
 struct QuotOut {
-    uint32_t* chunk[16];
+    uint32_t* chunk[MAX_QUOTIENT_CHUNKS];
 };
 // Rows [row_begin, row_end) of the quotient domain only (row_end = 0: all); trace_lde.d must then
 // be such that d[c * col_stride + r] is valid for those rows r and their `next` rows (a sharded
@@ -140,9 +141,9 @@ struct FusedReduceArgs {
     Ef z_mont[2];
     Ef off_t[2];   // alpha^0, alpha^w            (Montgomery)
     Ef rys_t[2];   // reduced opened values       (canonical)
-    Ef off_c[16];  // alpha^(2w + 4c)
-    Ef rys_c[16];
-    const uint32_t* chunk[16];
+    Ef off_c[MAX_QUOTIENT_CHUNKS];  // alpha^(2w + 4c)
+    Ef rys_c[MAX_QUOTIENT_CHUNKS];
+    const uint32_t* chunk[MAX_QUOTIENT_CHUNKS];
     uint64_t chunk_stride;
     uint32_t n_chunks;
     // slab of a sharded prover: global rows [row0, row0 + rows) live at local rows [0, rows) of

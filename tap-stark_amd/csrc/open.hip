@@ -364,7 +364,7 @@ k_reduce_fused(const uint32_t* __restrict__ trace, uint64_t trace_stride, uint32
 
 void launch_reduce_fused(Context& ctx, const ColMat& trace, unsigned log_h,
                          const uint32_t* d_alpha_pows_mont, const FusedReduceArgs& args, Ef* ro) {
-    TS_REQUIRE(args.n_chunks <= 16, TS_ERR_INVALID, "reduce_fused: too many chunks");
+    TS_REQUIRE(args.n_chunks <= (uint32_t)MAX_QUOTIENT_CHUNKS, TS_ERR_INVALID, "reduce_fused: too many chunks");
     ctx.ensure_twiddles(log_h == 0 ? 1 : log_h);
     FusedReduceArgs a = args;
     if (a.rows == 0) {

@@ -347,7 +347,7 @@ DevBuf<Ef> TwoAdicFriPcs::open_reduce_slab(const PcsData& trace_data, const PcsD
     {
         // offsets follow two_adic_pcs.rs:371,383: num_reduced grows by the width after every
         // (matrix, point); all matrices share log_height here
-        TS_REQUIRE(qd <= 16, TS_ERR_UNSUPPORTED, "open: more than 16 quotient chunks");
+        TS_REQUIRE(qd <= (uint32_t)MAX_QUOTIENT_CHUNKS, TS_ERR_UNSUPPORTED, "open: more than 64 quotient chunks");
         FusedReduceArgs a;
         memset(&a, 0, sizeof a);
         a.z_mont[0] = pts_mont[0];

@@ -20,7 +20,7 @@ namespace ts {
 constexpr int SEL_BATCH = 8;
 
 struct SelConsts {
-    uint32_t zh_mont[16];  // Z_H on the qd cosets: 31^n * omega_qd^c - 1  (Montgomery)
+    uint32_t zh_mont[MAX_QUOTIENT_CHUNKS];  // Z_H on the qd cosets: 31^n * omega_qd^c - 1  (Montgomery)
 };
 
 __global__ void __launch_bounds__(256)
@@ -74,7 +74,7 @@ k_selectors(unsigned L, unsigned log_qd, const uint32_t* __restrict__ W, uint32_
 void launch_selectors(Context& ctx, unsigned log_n, unsigned log_qd, uint32_t* is_first,
                       uint32_t* is_last, uint32_t* is_transition) {
     const unsigned L = log_n + log_qd;
-    TS_REQUIRE(log_qd <= 4, TS_ERR_UNSUPPORTED, "quotient degree > 16 not supported");
+    TS_REQUIRE((1u << log_qd) <= (unsigned)MAX_QUOTIENT_CHUNKS, TS_ERR_UNSUPPORTED, "quotient degree > 64 not supported");
     ctx.ensure_twiddles(L == 0 ? 1 : L);
     SelConsts sc;
     const uint32_t s_pow_n = pow_canon(GENERATOR, 1ull << log_n);
@@ -90,7 +90,7 @@ void launch_selectors(Context& ctx, unsigned log_n, unsigned log_qd, uint32_t* i
 
 // ------------------------------------------------------------------ interpreter
 struct QuotConsts {
-    uint32_t inv_zh_canonical[16];  // 1/Z_H per coset, CANONICAL: acc(Mont) * it -> canonical
+    uint32_t inv_zh_canonical[MAX_QUOTIENT_CHUNKS];  // 1/Z_H per coset, CANONICAL: acc(Mont) * it -> canonical
 };
 
 template <int NTHREADS>

@@ -162,6 +162,11 @@ PROOF_CASES = [
     # oracle prover finishes in seconds
     ("ext163_2p8_b4", lambda: (SynthExtAir(163), generate_synth_ext_trace(1 << 8, 163)), False, (4, 16, 8)),
     ("ext163_2p11_b4", lambda: (SynthExtAir(163), generate_synth_ext_trace(1 << 11, 163)), False, (4, 16, 8)),
+    # a constraint of degree 33: quotient_degree 32 (was refused above 16), needs log_blowup >= 5
+    ("deg33_2p6_b5", lambda: (__import__("tapstark_amd").airs.HighDegreeAir(33),
+                              __import__("tapstark_amd").airs.generate_high_degree_trace(1 << 6)), False, (5, 6, 4)),
+    ("deg50_2p4_b6", lambda: (__import__("tapstark_amd").airs.HighDegreeAir(50),
+                              __import__("tapstark_amd").airs.generate_high_degree_trace(1 << 4)), False, (6, 3, 4)),
 ]
 
 

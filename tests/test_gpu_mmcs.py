@@ -119,3 +119,10 @@ def test_commit_longest_trace_2pow26(ctx, orc):
         assert orc.lib().ts_or_mmcs_verify(1, hs, ws, ts.stark.C.c_size_t(r), ts.stark._p(rows),
                                            ts.stark._p(path), ts.stark.C.c_size_t(path.shape[0]),
                                            ts.stark._p(root))
+
+
+def test_alu_ceiling_probe(ctx):
+    # bench.py's alu_ceiling block: whole-chip rates of the library's own butterfly / Blake3 /
+    # SHA-256 loops; on an MI355X they are of the order of 10^12, 10^10 and 10^10 per second
+    bf, b3, sha = ctx.alu_ceiling(0), ctx.alu_ceiling(1), ctx.alu_ceiling(2)
+    assert 1e11 < bf < 2e13 and 5e9 < b3 < 5e11 and 2e9 < sha < 2e11

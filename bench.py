@@ -549,7 +549,8 @@ def main():
             "single_proof_latency_ms": round(single_latency, 4),
             "single_proof_latency_with_stage_timers_ms": stage_sum.get("prove"),
             "roofline": roofline, "roofline_stage": roofline_stage, "roofline_whole": roofline_whole,
-            "alu_ceiling": alu_ceiling, "h2d_inclusive": h2d, "cpu_baseline": cpu,
+            "alu_ceiling": alu_ceiling, "h2d_inclusive": h2d,
+            "h2d_inclusive_ms_per_step": (h2d or {}).get("ms_per_step"), "cpu_baseline": cpu,
             "stages_ms": stage_sum,
             "shard_stages_ms_per_rank": shard_stages,
             "kernels": per_kernel,

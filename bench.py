@@ -78,21 +78,23 @@ def algorithmic_bytes_per_proof(n: int, w: int, b: int, qd: int) -> dict:
     each array counted once per launch that must read or write it."""
     N = n << b
     wall = w + 4 * qd  # every committed column (trace + quotient chunks)
-    fri_elems = 2 * N  # sum over rounds of the folded vector lengths (N + N/2 + ...)
-    # Merkle parents (64 B read + 32 B written each): two N-leaf trees + FRI trees (N/2 + N/4 + ..);
-    # levels with > 2^16 children go through k_merkle_level, the rest through k_merkle_top
+    # Merkle parents (64 B read + 32 B written each): two N-leaf trees + FRI trees (N/2 + N/4 + ..).
+    # Levels with > 2^17 children take one k_merkle_level launch each; the last 17 levels of a tree
+    # are one k_merkle_tree launch; a FRI round with <= 2^17 leaves is one k_fri_round launch (fold
+    # of the previous vector + leaf hashes + the whole tree), the rounds above keep fold / levels.
+    TREE = 17
     parents_all = 3 * N  # N - 1 per N-leaf tree, and N/2 + N/4 + ... over the FRI trees
-    # per-level launches take the levels with >= 2^16 parents (two parents per thread from 2^18 up)
+    fri_leaves = [N >> r for r in range(1, 40) if (N >> r) > 1024 // 2]
     lvl2 = lvl1 = 0
-    for leaves in [N, N] + [N >> r for r in range(1, 40) if (N >> r) > (1 << 16)]:
+    for leaves in [N, N] + [h for h in fri_leaves if h > (1 << TREE)]:
         p = leaves // 2
-        while p >= (1 << 16):
-            if p >= (1 << 18):
-                lvl2 += p
-            else:
-                lvl1 += p
+        while p >= (1 << TREE):
+            lvl1 += p
             p //= 2
-    small = max(parents_all - lvl1 - lvl2, 0)
+    fused = [h for h in fri_leaves if h <= (1 << TREE)]
+    fused_bytes = sum((64 + 8 + 32 + 32 + 96) * h for h in fused)  # prev, twiddles, cur, leaf digests, parents
+    small = max(parents_all - lvl1 - lvl2 - sum(fused), 0)
+    big_fri_elems = sum(2 * h for h in fri_leaves if h > (1 << TREE))
     return {
         "k_transpose_bitrev": 8 * n * w,
         "k_intt_contig": 8 * n * wall,
@@ -107,7 +109,8 @@ def algorithmic_bytes_per_proof(n: int, w: int, b: int, qd: int) -> dict:
         "k_leaf_hash_ef_pairs": 16 * N + 16 * N,
         "k_merkle_level<2>": 96 * lvl2,
         "k_merkle_level<1>": 96 * lvl1,
-        "k_merkle_top": 96 * small,
+        "k_merkle_tree": 96 * small,
+        "k_fri_round<true>": fused_bytes,
         "k_selectors": 12 * n * qd,
         "k_quotient_jit": 4 * n * qd * w + 12 * n * qd + 16 * n * qd,
         "k_quotient<256>": 4 * n * qd * w + 12 * n * qd + 16 * n * qd,
@@ -115,7 +118,7 @@ def algorithmic_bytes_per_proof(n: int, w: int, b: int, qd: int) -> dict:
         "(k_bary_dots<2, 64>)": 4 * n * w + 32 * n,
         "(k_bary_dots<1, 8>)": qd * (16 * n + 16 * n),
         "k_reduce_fused": 4 * N * wall + 16 * N,
-        "k_fri_fold_pairs": 16 * fri_elems + 8 * fri_elems + 8 * fri_elems,
+        "k_fri_fold_pairs": 16 * big_fri_elems + 8 * big_fri_elems + 8 * big_fri_elems,
     }
 
 
@@ -486,7 +489,7 @@ def main():
             return sum(v["ms_per_proof"] for k, v in per_kernel.items() if any(x in k for x in names))
         bf_peak, b3_peak = ctx.alu_ceiling(0), ctx.alu_ceiling(1)
         ntt_ms = ms_of("k_intt_contig", "k_lde_mid", "k_lde_fwd_contig")
-        b3_ms = ms_of("k_leaf_hash", "k_merkle_level", "k_merkle_top", "k_merkle_subtree")  # (matches _lds too)
+        b3_ms = ms_of("k_leaf_hash", "k_merkle_level", "k_merkle_tree", "k_fri_round")
         alu_ceiling = {
             "butterflies_per_s_peak": round(bf_peak), "butterflies_per_proof": butterflies,
             "ntt_kernels_ms": round(ntt_ms, 4), "ntt_ms_at_peak": round(butterflies / bf_peak * 1e3, 4),

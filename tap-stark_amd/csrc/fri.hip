@@ -10,6 +10,7 @@
 #include "blake3_quad.hpp"
 #include "chal_dev.hpp"
 #include "kernels.hpp"
+#include "merkle_tree.hpp"
 
 namespace ts {
 
@@ -97,6 +98,89 @@ void launch_fri_fold(Context& ctx, const Ef* in, uint64_t h, Ef beta, Ef* out,
     TS_HIP(hipMemcpyAsync(d_beta.p, &beta, sizeof(Ef), hipMemcpyHostToDevice, ctx.stream));
     ctx.sync();  // `beta` is a stack temporary
     launch_fri_fold_dev(ctx, in, h, d_beta.p, out, next_digests);
+}
+
+// ---- one commit-phase round in one launch (merkle_tree.hpp) ------------------------------------
+// leaf i of the round's matrix = (cur[2i], cur[2i+1]).  FOLD: cur is not in memory yet: it is the
+// fold of the previous round's vector with the challenge that round's kernel left in device memory
+// (cur[k] = fold(prev[2k], prev[2k+1])), computed, stored and hashed by the thread that owns the leaf.
+static_assert(FRI_ROUND_MAX_LOG == mt::MAX_LOG_TREE, "kernels.hpp and merkle_tree.hpp disagree");
+
+template <bool FOLD>
+struct FriLeaves {
+    const Ef* prev;
+    const uint32_t* tw;   // tw[k] = g^-bitrev(k), the twiddle of output k of the fold
+    Ef half_beta_mont;
+    Ef* cur;
+    uint32_t* level0;     // the tree's leaf digests
+    __device__ __forceinline__ void fill(uint32_t* in, uint64_t node0, uint32_t count) {
+        for (uint32_t n = threadIdx.x; n < count; n += mt::NTH) {
+            const uint64_t i = node0 + n;
+            Ef a, b;
+            if (FOLD) {
+                a = fold_one(load_ef(prev + 4 * i), load_ef(prev + 4 * i + 1), tw[2 * i], half_beta_mont, HALF_MONT);
+                b = fold_one(load_ef(prev + 4 * i + 2), load_ef(prev + 4 * i + 3), tw[2 * i + 1], half_beta_mont,
+                             HALF_MONT);
+                store_ef(cur + 2 * i, a);
+                store_ef(cur + 2 * i + 1, b);
+            } else {
+                a = load_ef(cur + 2 * i);
+                b = load_ef(cur + 2 * i + 1);
+            }
+            uint32_t m[16] = {a.c[0], a.c[1], a.c[2], a.c[3], b.c[0], b.c[1], b.c[2], b.c[3],
+                              0, 0, 0, 0, 0, 0, 0, 0};
+            uint32_t cv[8];
+            b3::iv(cv);
+            b3::compress(cv, m, 32, b3::CHUNK_START | b3::CHUNK_END | b3::ROOT);
+            uint4* o = reinterpret_cast<uint4*>(level0 + 8 * i);
+            o[0] = make_uint4(cv[0], cv[1], cv[2], cv[3]);
+            o[1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
+#pragma unroll
+            for (int k = 0; k < 8; k++) in[k * mt::CH + n] = cv[k];
+        }
+        b3::lds_barrier();
+    }
+};
+
+template <bool FOLD>
+__global__ void __launch_bounds__(mt::NTH)
+k_fri_round(const Ef* __restrict__ prev, const uint32_t* __restrict__ tw, const Ef* __restrict__ beta_prev,
+            Ef* __restrict__ cur, uint32_t* __restrict__ tree, unsigned log_leaves,
+            uint32_t* __restrict__ ticket, DevChallenger* __restrict__ ch, uint32_t* __restrict__ root_out,
+            Ef* __restrict__ beta_out) {
+    __shared__ mt::Lds lds;
+    __shared__ uint32_t s_last;
+    const mt::Levels lv{tree, 0, (uint64_t)1 << log_leaves};
+    FriLeaves<FOLD> prod{prev, tw, ef_zero(), cur, tree};
+    if (FOLD) prod.half_beta_mont = ef_mul_base(ef_to_mont(load_ef(beta_prev)), HALF_MONT);
+    mt::tree_body(lds, s_last, prod, lv, log_leaves, ticket, ch, root_out, beta_out);
+}
+
+unsigned fri_round_max_log() {
+    static const unsigned v = [] {
+        const char* e = getenv("TS_FRI_ROUND_LOG");  // 0: never; up to 22
+        const int x = e ? atoi(e) : 17;
+        return (unsigned)(x < 0 ? 0 : x > (int)FRI_ROUND_MAX_LOG ? (int)FRI_ROUND_MAX_LOG : x);
+    }();
+    return v;
+}
+
+void launch_fri_round(Context& ctx, const Ef* prev, const Ef* d_beta_prev, Ef* cur, uint64_t h,
+                      uint32_t* tree, DevChallenger* ch, uint32_t* root_out, Ef* beta_out) {
+    unsigned log_h = 0;
+    while ((1ull << log_h) < h) log_h++;
+    TS_REQUIRE((1ull << log_h) == h && log_h <= FRI_ROUND_MAX_LOG, TS_ERR_INVALID,
+               "fri_round: leaf count not a power of two <= 2^22");
+    const dim3 grid(1u << (log_h - mt::block_log(log_h)));
+    if (prev != nullptr) {
+        ctx.ensure_twiddles(log_h + 2);  // the fold's output has 2h elements: twiddles of order 4h
+        TS_LAUNCH(ctx, k_fri_round<true>, grid, dim3(mt::NTH), 0, prev, ctx.d_twiddle_inv + 2 * h, d_beta_prev,
+                  cur, tree, log_h, ctx.ticket(), ch, root_out, beta_out);
+    } else {
+        TS_LAUNCH(ctx, k_fri_round<false>, grid, dim3(mt::NTH), 0, prev, (const uint32_t*)nullptr,
+                  (const Ef*)nullptr, cur, tree, log_h, ctx.ticket(), ch, root_out, beta_out);
+    }
+    TS_HIP(hipGetLastError());
 }
 
 // acc[i] += other[i]   (reference fri/src/prover.rs:124-126)

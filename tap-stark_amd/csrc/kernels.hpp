@@ -163,6 +163,14 @@ void launch_fri_fold(Context& ctx, const Ef* in, uint64_t h, Ef beta_canonical, 
 // rows (h_global = 0: the whole vector, h_global = h, row0 = 0)
 void launch_fri_fold_dev(Context& ctx, const Ef* in, uint64_t h, const Ef* d_beta, Ef* out,
                          uint32_t* next_digests, uint64_t h_global = 0, uint64_t row0 = 0);
+// One commit-phase round in one launch: leaves (cur[2i], cur[2i+1]) hashed, the whole tree built,
+// the root observed and the next challenge sampled.  prev != nullptr: cur (2h elements) is first
+// computed as the fold of prev (4h elements) with the challenge at d_beta_prev, and stored.
+constexpr unsigned FRI_ROUND_MAX_LOG = 22;  // = mt::MAX_LOG_TREE (merkle_tree.hpp)
+void launch_fri_round(Context& ctx, const Ef* prev, const Ef* d_beta_prev, Ef* cur, uint64_t h,
+                      uint32_t* tree, DevChallenger* ch, uint32_t* root_out, Ef* beta_out);
+unsigned merkle_tree_max_log();  // trees up to this many levels are one launch (TS_TREE_MAX_LOG)
+unsigned fri_round_max_log();    // commit rounds up to this many levels are one launch (TS_FRI_ROUND_LOG)
 // device-resident transcript (chal_dev.hpp): observe the root at `root`, sample beta
 struct DevChallenger;
 void launch_chal_round(Context& ctx, DevChallenger* ch, const uint32_t* root, uint32_t* root_out,

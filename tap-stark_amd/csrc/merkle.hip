@@ -8,6 +8,7 @@
 
 #include "blake3.hpp"
 #include "blake3_quad.hpp"
+#include "merkle_tree.hpp"
 #include "chal_dev.hpp"
 #include "kernels.hpp"
 
@@ -252,143 +253,40 @@ void launch_shard_top(Context& ctx, const uint32_t* subroots, uint32_t G, uint32
     TS_HIP(hipGetLastError());
 }
 
-// The last <= 16 levels of a tree in ONE launch.  Workgroup g reduces the subtree of S = 2^log_s
-// consecutive nodes of level `first_level` to its root (log_s levels); the workgroup that finishes
-// LAST (a ticket counter in device memory) then reduces the n_sub sub-roots to the tree root, and
-// runs the challenger step if asked.  Every level is stored in the tree.
-//   * a level is staged through LDS as [word][node] (bank-conflict free for both access patterns);
-//   * four lanes share one compression (blake3_quad.hpp): these levels are latency-bound -- fewer
-//     nodes than lanes, a chain of dependent compressions -- and the quad form cuts the chain by ~3.5x.
-constexpr int SUB_NTH = 256;
-constexpr int SUB_S = 256;  // nodes a workgroup takes in (2^8)
-
-struct SubLds {
-    uint32_t in[8 * SUB_S];  // stride SUB_S in all three images, so that one set of offsets serves
-    uint32_t a[8 * SUB_S];
-    uint32_t b[8 * SUB_S];
-};
-
-// reduces `count` (a power of two <= SUB_S) nodes lying in lds.in to one; level l of the result
-// (count >> (l+1) nodes) goes to tree + 8 * (level_off[l] + node0 >> (l+1) ...).  Returns the LDS
-// image holding the root (node 0).
-__device__ __forceinline__ const uint32_t* reduce_in_lds(SubLds& lds, uint32_t count, uint32_t* tree,
-                                                         uint64_t first_parent_off,
-                                                         uint64_t parents_in_level, uint64_t node0,
-                                                         const uint32_t moff[28], bool publish_root) {
-    const uint32_t j = threadIdx.x & 3;
-    const uint32_t* src = lds.in;
-    uint64_t par_off = first_parent_off, n_level = parents_in_level, p0 = node0 >> 1;
-    unsigned l = 0;
-    for (uint32_t n_par = count >> 1; n_par >= 1; n_par >>= 1, l++) {
-        uint32_t* dst = (l & 1) ? lds.b : lds.a;
-        for (uint32_t t = threadIdx.x; t < 4 * n_par; t += SUB_NTH) {
-            const uint32_t i = t >> 2;
-            const uint32_t* base = src + 2 * i;
-            uint32_t lo, hi;
-            b3::compress_quad(j, b3::iv_word(j), b3::iv_word(4 + j),
-                              [&](int k) { return base[moff[k]]; }, 64,
-                              b3::CHUNK_START | b3::CHUNK_END | b3::ROOT, lo, hi);
-            dst[j * SUB_S + i] = lo;
-            dst[(4 + j) * SUB_S + i] = hi;
-            {
-                uint32_t* o = tree + 8 * (par_off + p0 + i);
-                if (publish_root && n_par == 1) {
-                    // the sub-root another workgroup will read: written through (sc1), see k_merkle_top
-                    __hip_atomic_store(o + j, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(o + 4 + j, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                } else {
-                    o[j] = lo;
-                    o[4 + j] = hi;
-                }
-            }
-        }
-        b3::lds_barrier();  // the level's global stores stay in flight
-        src = dst;
-        par_off += n_level;
-        n_level >>= 1;
-        p0 >>= 1;
-    }
-    return src;
-}
-
-template <bool SC1>
-__device__ __forceinline__ void stage_nodes(SubLds& lds, const uint32_t* nodes, uint32_t count) {
-    // count nodes x 8 words, coalesced read, transposed into [word][node]
-    for (uint32_t e = threadIdx.x; e < 8 * count; e += SUB_NTH)
-        lds.in[(e & 7) * SUB_S + (e >> 3)] =
-            SC1 ? __hip_atomic_load(nodes + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : nodes[e];
-    __syncthreads();  // (waits for the loads: their values are what goes to LDS)
-}
-
-__global__ void __launch_bounds__(SUB_NTH)
-k_merkle_top(uint32_t* __restrict__ tree, unsigned log_leaves, unsigned first_level, unsigned log_s,
-             uint32_t* __restrict__ ticket, DevChallenger* __restrict__ ch,
-             uint32_t* __restrict__ root_out, Ef* __restrict__ beta_out) {
-    __shared__ SubLds lds;
+// Up to 2^22 first-level nodes: the whole tree in ONE launch (merkle_tree.hpp).  Taller trees run
+// their first levels one launch per level (bandwidth-bound there, ~3.7 TB/s of digest traffic).
+__global__ void __launch_bounds__(mt::NTH)
+k_merkle_tree(uint32_t* __restrict__ tree, unsigned log_leaves, unsigned first_level,
+              uint32_t* __restrict__ ticket, DevChallenger* __restrict__ ch,
+              uint32_t* __restrict__ root_out, Ef* __restrict__ beta_out) {
+    __shared__ mt::Lds lds;
     __shared__ uint32_t s_last;
-    uint32_t moff[28];
-    {
-        uint32_t idx[28];
-        b3::quad_schedule(threadIdx.x & 3, idx);
-#pragma unroll
-        for (int k = 0; k < 28; k++) moff[k] = (idx[k] & 7) * SUB_S + (idx[k] >> 3);
-    }
     uint64_t off = 0;
     for (unsigned l = 0; l < first_level; l++) off += (uint64_t)1 << (log_leaves - l);
-    const uint64_t n_level = (uint64_t)1 << (log_leaves - first_level);
-    const uint32_t S = 1u << log_s;
-    const uint32_t n_sub = (uint32_t)(n_level >> log_s);
-    const uint64_t sub0 = (uint64_t)blockIdx.x * S;
-    stage_nodes<false>(lds, tree + 8 * (off + sub0), S);
-    const uint32_t* top = reduce_in_lds(lds, S, tree, off + n_level, n_level >> 1, sub0, moff, n_sub > 1);
-    bool finisher = n_sub == 1;
-    if (n_sub > 1) {
-        // Hand-off between workgroups.  Per-XCD L2s are not coherent with each other and a CU's L1
-        // is never refreshed by another CU's stores, so (MI355X_MICROARCH.md, "Valid forms" and its
-        // table of measured hand-offs): every handed-off byte -- the 32-byte sub-root -- is stored
-        // sc1 (written through, dropped from the XCD's L2) and loaded sc1 (bypassing L1); the
-        // storing wave drains its stores, the workgroup meets, ONE lane adds to the ticket counter
-        // at agent scope; the workgroup whose add came last loads after a barrier behind that add.
-        // No release/acquire fence: those cost 2-6 us each here, more than the levels themselves.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            // (counting in groups of 16 workgroups on separate lines, to spare the one word 256
-            // adds from eight XCDs, measured 26.9 against 27.7 us per 2^16-leaf tree: not worth it)
-            const uint32_t tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_last = tk == n_sub - 1 ? 1u : 0u;
-        }
-        __syncthreads();
-        if (s_last) {
-            uint64_t off2 = off;
-            for (unsigned l = 0; l < log_s; l++) off2 += (uint64_t)1 << (log_leaves - first_level - l);
-            stage_nodes<true>(lds, tree + 8 * off2, n_sub);
-            top = reduce_in_lds(lds, n_sub, tree, off2 + n_sub, n_sub >> 1, 0, moff, false);
-            if (threadIdx.x == 0)  // ready for the next launch on this stream
-                __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            finisher = true;
-        }
-    }
-    // device-resident transcript (fri/src/prover.rs:114-116): the workgroup that produced the root
-    // observes it and samples the next challenge, saving a kernel launch per FRI round
-    if (finisher && ch != nullptr && threadIdx.x == 0) {
-        uint32_t root[8];
-        for (int k = 0; k < 8; k++) {
-            root[k] = top[k * SUB_S];
-            root_out[k] = root[k];
-        }
-        const Ef beta = dc_observe_root_and_sample(ch, root);
-        *reinterpret_cast<uint4*>(beta_out) = make_uint4(beta.c[0], beta.c[1], beta.c[2], beta.c[3]);
-    }
+    const unsigned remaining = log_leaves - first_level;
+    const mt::Levels lv{tree, off, (uint64_t)1 << remaining};
+    mt::StagedNodes<false> prod{lv.at(0, 0)};
+    mt::tree_body(lds, s_last, prod, lv, remaining, ticket, ch, root_out, beta_out);
 }
 
-// Levels with more than 2^16 children: one launch per level (bandwidth-bound, ~3.7 TB/s of digest
-// traffic).  The last <= 16 levels are latency-bound: one launch of k_merkle_top.
+// Measured (tools/time_tree.py, us per tree above the leaves, one launch / per-level launches down to
+// 2^16): 2^17 34 / 33, 2^18 60 / 44, 2^20 89 / 71, 2^22 216 / 152.  In one launch the bulk levels run
+// as four-lane compressions out of LDS between workgroup barriers at 3 workgroups per CU, ~19 G
+// compressions/s; k_merkle_level streams them at ~34 G/s.  So the single launch takes over at 2^17.
+unsigned merkle_tree_max_log() {
+    static const unsigned v = [] {
+        const char* e = getenv("TS_TREE_MAX_LOG");  // up to 22, for A/B runs
+        const int x = e ? atoi(e) : 17;
+        return (unsigned)(x < 1 ? 1 : x > (int)mt::MAX_LOG_TREE ? (int)mt::MAX_LOG_TREE : x);
+    }();
+    return v;
+}
+
 bool launch_merkle_levels(Context& ctx, uint32_t* tree, unsigned log_leaves, DevChallenger* ch,
                           uint32_t* root_out, Ef* beta_out) {
     unsigned level = 0;
     uint64_t off = 0;
-    while (log_leaves - level > 16) {
+    while (log_leaves - level > merkle_tree_max_log()) {
         const uint64_t n_children = (uint64_t)1 << (log_leaves - level);
         const uint64_t n_parents = n_children / 2;
         launch_level(ctx, tree + 8 * off, tree + 8 * (off + n_children), n_parents);
@@ -397,10 +295,8 @@ bool launch_merkle_levels(Context& ctx, uint32_t* tree, unsigned log_leaves, Dev
     }
     const unsigned remaining = log_leaves - level;
     if (remaining == 0) return false;
-    // first phase: workgroups of 2^a nodes; second phase (last workgroup): 2^(remaining - a) sub-roots
-    const unsigned a = remaining <= 8 ? remaining : 8;
-    TS_LAUNCH(ctx, k_merkle_top, dim3(1u << (remaining - a)), dim3(SUB_NTH), 0, tree, log_leaves, level, a,
-              ctx.ticket(), ch, root_out, beta_out);
+    TS_LAUNCH(ctx, k_merkle_tree, dim3(1u << (remaining - mt::block_log(remaining))), dim3(mt::NTH), 0, tree,
+              log_leaves, level, ctx.ticket(), ch, root_out, beta_out);
     TS_HIP(hipGetLastError());
     return ch != nullptr;
 }

@@ -416,9 +416,10 @@ void fri_commit_rounds(Context& ctx, const FriConfig& fri, DevBuf<Ef> folded, ui
                        std::vector<DevBuf<Ef>>& inputs, const std::vector<unsigned>& log_lens,
                        size_t next_in, FriCommit& st) {
     DevChallenger* dch = st.dch();
-    DevBuf<uint32_t> next_tree;
-    bool leaves_ready = false;
-    // rounds done with one launch set each; the rest goes to the tail kernel
+    // != nullptr: `folded` is not in memory yet -- it is the fold of this vector (the last round's)
+    // with the last round's challenge, and the next round's kernel computes it while hashing
+    const Ef* prev = nullptr;
+    // rounds done with one launch each; the rest goes to the tail kernel
     auto big = [&](uint64_t l) {
         return l > fri.blowup() && (l > (1ull << FRI_TAIL_LOG) || next_in < inputs.size());
     };
@@ -426,38 +427,42 @@ void fri_commit_rounds(Context& ctx, const FriConfig& fri, DevBuf<Ef> folded, ui
         FriRound r;
         const uint64_t h = len / 2;
         r.log_leaves = log2_strict(h);
-        DevBuf<uint32_t> tree;
-        if (leaves_ready) {
-            tree = std::move(next_tree);  // leaves were hashed by the previous fold
-        } else {
-            tree = DevBuf<uint32_t>(&ctx, merkle_total_digests(r.log_leaves) * 8);
-            launch_leaf_hash_ef_pairs(ctx, reinterpret_cast<const uint32_t*>(folded.p), h, tree.p);
-        }
         const size_t ri = st.rounds.size();
+        DevBuf<uint32_t> tree(&ctx, merkle_total_digests(r.log_leaves) * 8);
+        if (prev) folded = DevBuf<Ef>(&ctx, len);
         // :113 commit_matrix, :114-116 observe + sample (in the kernel that makes the root)
-        if (!launch_merkle_levels(ctx, tree.p, r.log_leaves, dch, st.d_roots.p + 8 * ri, st.d_betas.p + ri))
-            launch_chal_round(ctx, dch, tree.p + 8 * (merkle_total_digests(r.log_leaves) - 1),
-                              st.d_roots.p + 8 * ri, st.d_betas.p + ri);
-        DevBuf<Ef> out(&ctx, h);
-        const bool add_pending = next_in < inputs.size() && (1ull << log_lens[next_in]) == h;
-        uint32_t* nd = nullptr;
-        leaves_ready = false;
-        if (!add_pending && big(h)) {  // the next round's leaves can be hashed by this fold
-            next_tree = DevBuf<uint32_t>(&ctx, merkle_total_digests(r.log_leaves - 1) * 8);
-            nd = next_tree.p;
-            leaves_ready = true;
+        if (fri_round_max_log() != 0 && r.log_leaves <= fri_round_max_log()) {
+            launch_fri_round(ctx, prev, prev ? st.d_betas.p + ri - 1 : nullptr, folded.p, h, tree.p, dch,
+                             st.d_roots.p + 8 * ri, st.d_betas.p + ri);
+        } else {
+            if (prev)  // the fold hashes its output pairs, i.e. this round's leaves, in the same pass
+                launch_fri_fold_dev(ctx, prev, len, st.d_betas.p + ri - 1, folded.p, tree.p);
+            else
+                launch_leaf_hash_ef_pairs(ctx, reinterpret_cast<const uint32_t*>(folded.p), h, tree.p);
+            if (!launch_merkle_levels(ctx, tree.p, r.log_leaves, dch, st.d_roots.p + 8 * ri, st.d_betas.p + ri))
+                launch_chal_round(ctx, dch, tree.p + 8 * (merkle_total_digests(r.log_leaves) - 1),
+                                  st.d_roots.p + 8 * ri, st.d_betas.p + ri);
         }
-        launch_fri_fold_dev(ctx, folded.p, h, st.d_betas.p + ri, out.p, nd);  // :119 fold_matrix
-        if (add_pending) {  // :124-126 izip!(&mut folded, v).for_each(|(c, x)| *c += x)
-            launch_vec_add(ctx, out.p, inputs[next_in].p, h);
-            st.keep_vecs.push_back(std::move(inputs[next_in]));
-            next_in++;
-        }
+        prev = nullptr;
         r.vec = folded.p;
         r.tree = tree.p;
-        st.keep_vecs.push_back(std::move(folded));
+        const bool add_pending = next_in < inputs.size() && (1ull << log_lens[next_in]) == h;
+        if (add_pending || !big(h)) {
+            // the next vector is needed in memory now: an input is added to it, or the tail takes it
+            DevBuf<Ef> out(&ctx, h);
+            launch_fri_fold_dev(ctx, folded.p, h, st.d_betas.p + ri, out.p, nullptr);  // :119 fold_matrix
+            if (add_pending) {  // :124-126 izip!(&mut folded, v).for_each(|(c, x)| *c += x)
+                launch_vec_add(ctx, out.p, inputs[next_in].p, h);
+                st.keep_vecs.push_back(std::move(inputs[next_in]));
+                next_in++;
+            }
+            st.keep_vecs.push_back(std::move(folded));
+            folded = std::move(out);
+        } else {
+            prev = folded.p;  // :119 happens inside the next round's launch
+            st.keep_vecs.push_back(std::move(folded));
+        }
         st.keep_trees.push_back(std::move(tree));
-        folded = std::move(out);
         st.rounds.push_back(r);
         len = h;
     }

@@ -126,3 +126,23 @@ def test_alu_ceiling_probe(ctx):
     # SHA-256 loops; on an MI355X they are of the order of 10^12, 10^10 and 10^10 per second
     bf, b3, sha = ctx.alu_ceiling(0), ctx.alu_ceiling(1), ctx.alu_ceiling(2)
     assert 1e11 < bf < 2e13 and 5e9 < b3 < 5e11 and 2e9 < sha < 2e11
+
+
+@pytest.mark.parametrize("tree_log,round_log", [(16, 0), (22, 22), (19, 20)])
+def test_tree_launch_shapes_agree(ctx, tree_log, round_log):
+    # how many levels one launch takes (whole trees up to 2^22 leaves in one launch, several LDS
+    # chunks per workgroup, 1024 sub-roots; FRI commit rounds with the fold fused in) is a tuning
+    # knob read once per process: every setting must give the same roots, paths and proof bytes as
+    # the default one in this process
+    import subprocess
+    import sys
+
+    sys.path.insert(0, os.path.dirname(__file__))
+    import _tree_shapes_probe as probe
+
+    here = probe.probe()
+    env = dict(os.environ, TS_TREE_MAX_LOG=str(tree_log), TS_FRI_ROUND_LOG=str(round_log))
+    r = subprocess.run([sys.executable, probe.__file__], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("PROBE ")][-1]
+    assert json.loads(line[6:]) == here

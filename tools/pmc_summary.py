@@ -48,7 +48,7 @@ def main():
     kernels = {}
     for k in sorted(fetch, key=lambda k: -(fetch[k] + write.get(k, 0))):
         a = (alg.get(k) or alg.get(f"({k})") or (alg["k_lde_mid<1>"] if "k_lde_mid" in k else None)
-             or (alg["k_merkle_top"] if "k_merkle_top" in k else None))
+             or (alg["k_merkle_tree"] if "k_merkle_tree" in k else None))
         kernels[k] = {"launches_per_proof": cnt[k] / n_proofs,
                       "fetch_bytes_per_proof_corrected": 2 * 1024 * fetch[k] / n_proofs,
                       "write_bytes_per_proof": 1024 * write.get(k, 0.0) / n_proofs,

@@ -2,7 +2,10 @@
 ranks as G threads of this process on the one GPU of the box (ts_comm_local_*).  The ranks share the
 card, so absolute times are ~G x what a rank alone on its GPU would take and the collectives are
 device-to-device copies, not xGMI; what the table shows is the SPLIT of a rank's GPU time over the
-stages, for both ways of doing the per-column part of the inverse NTT.
+stages, for both ways of doing the per-column part of the inverse NTT.  A stage that ends in a
+collective (Merkle commits, quotient broadcast, FRI rounds, the query phase's all-gather of answers)
+includes the wait for the slowest rank, which on a shared card is scheduling skew: e.g. a query
+phase of 8 ms on some ranks and 0.5 ms on the others is 0.5 ms of work.
 
     python tools/shard_stages.py [log_n] [G] > profiles/r02_config4_shard_stages.json
 """
@@ -30,8 +33,11 @@ def run(log_n, G, colshard, cfg=(4, 16, 8)):
             ctx = ts.Context(0)
             config = ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(*cfg), ctx))
             cair = ts.CompiledAir(ctx, ts.air_tape(air, 0))
-            for timed in (False, True):  # the first proof builds tables and grows the pool
+            # the first proof builds tables and grows the pool, the second does the same with the
+            # stage timers on (they synchronise at stage boundaries); the third is the one reported
+            for timed in (False, True, True):
                 ctx.set_timing(timed)
+                ctx.take_timings()
                 p = ts.prove_sharded(config, cair, ts.BfChallenger(), ts.DeviceMatrix.synth_mul(ctx, n, 64), [],
                                      group.comm(r), trace_replicated=True, column_sharded_inverse=colshard)
             st = {}

@@ -20,18 +20,18 @@ Context::Context(int dev) : device(dev) {
 }
 
 Context::~Context() {
-    hipSetDevice(device);
-    if (stream) hipStreamSynchronize(stream);
-    if (d_twiddle_fwd) hipFree(d_twiddle_fwd);
-    if (d_twiddle_inv) hipFree(d_twiddle_inv);
-    for (auto& t : scale_tables) hipFree(t.d);
-    if (d_selectors) hipFree(d_selectors);
-    if (d_ticket) hipFree(d_ticket);
-    for (auto& kv : free_blocks) hipFree(kv.second);
-    for (auto& kv : live_blocks) hipFree(kv.first);
-    if (h_pinned) hipHostFree(h_pinned);
-    if (h_arena) hipHostFree(h_arena);
-    if (stream) hipStreamDestroy(stream);
+    (void)hipSetDevice(device);
+    if (stream) (void)hipStreamSynchronize(stream);
+    if (d_twiddle_fwd) (void)hipFree(d_twiddle_fwd);
+    if (d_twiddle_inv) (void)hipFree(d_twiddle_inv);
+    for (auto& t : scale_tables) (void)hipFree(t.d);
+    if (d_selectors) (void)hipFree(d_selectors);
+    if (d_ticket) (void)hipFree(d_ticket);
+    for (auto& kv : free_blocks) (void)hipFree(kv.second);
+    for (auto& kv : live_blocks) (void)hipFree(kv.first);
+    if (h_pinned) (void)hipHostFree(h_pinned);
+    if (h_arena) (void)hipHostFree(h_arena);
+    if (stream) (void)hipStreamDestroy(stream);
 }
 
 static size_t round_block(size_t bytes) {
@@ -78,9 +78,9 @@ void Context::free(void* p) {
 }
 
 void Context::release_cache() {
-    if (stream) hipStreamSynchronize(stream);
+    if (stream) (void)hipStreamSynchronize(stream);
     for (auto& kv : free_blocks) {
-        hipFree(kv.second);
+        (void)hipFree(kv.second);
         bytes_reserved -= kv.first;
     }
     free_blocks.clear();
@@ -120,7 +120,7 @@ void* Context::pinned(size_t bytes) {
     if (bytes > h_pinned_bytes) {
         if (h_pinned) {
             sync();
-            hipHostFree(h_pinned);
+            (void)hipHostFree(h_pinned);
         }
         size_t sz = 1 << 16;
         while (sz < bytes) sz <<= 1;
@@ -135,12 +135,12 @@ std::map<std::string, std::pair<uint64_t, double>> Context::take_kernel_timings(
     sync();
     for (auto& ev : kernel_events) {
         float ms = 0;
-        hipEventElapsedTime(&ms, ev.e0, ev.e1);
+        (void)hipEventElapsedTime(&ms, ev.e0, ev.e1);
         auto& slot = out[ev.name];
         slot.first += 1;
         slot.second += ms;
-        hipEventDestroy(ev.e0);
-        hipEventDestroy(ev.e1);
+        (void)hipEventDestroy(ev.e0);
+        (void)hipEventDestroy(ev.e1);
     }
     kernel_events.clear();
     return out;
@@ -150,8 +150,8 @@ void Context::ensure_twiddles(unsigned log_size) {
     if (log_size <= twiddle_log && d_twiddle_fwd) return;
     TS_REQUIRE(log_size <= 27, TS_ERR_INVALID, "two-adicity of BabyBear is 27");
     sync();
-    if (d_twiddle_fwd) hipFree(d_twiddle_fwd);
-    if (d_twiddle_inv) hipFree(d_twiddle_inv);
+    if (d_twiddle_fwd) (void)hipFree(d_twiddle_fwd);
+    if (d_twiddle_inv) (void)hipFree(d_twiddle_inv);
     d_twiddle_fwd = d_twiddle_inv = nullptr;
     const size_t n = (size_t)1 << log_size;
     TS_HIP(hipMalloc((void**)&d_twiddle_fwd, n * 4));

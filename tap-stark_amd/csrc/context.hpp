@@ -154,14 +154,14 @@ struct KernelTimer {
     KernelTimer(Context* c, const char* name) : ctx(c), on(c->kernel_timing) {
         if (on) {
             ev.name = name;
-            hipEventCreate(&ev.e0);
-            hipEventCreate(&ev.e1);
-            hipEventRecord(ev.e0, ctx->stream);
+            (void)hipEventCreate(&ev.e0);
+            (void)hipEventCreate(&ev.e1);
+            (void)hipEventRecord(ev.e0, ctx->stream);
         }
     }
     ~KernelTimer() {
         if (on) {
-            hipEventRecord(ev.e1, ctx->stream);
+            (void)hipEventRecord(ev.e1, ctx->stream);
             ctx->kernel_events.push_back(ev);
         }
     }
@@ -179,20 +179,20 @@ struct StageTimer {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     StageTimer(Context* c, const char* n) : ctx(c), name(n) {
         if (ctx->timing) {
-            hipEventCreate(&e0);
-            hipEventCreate(&e1);
-            hipEventRecord(e0, ctx->stream);
+            (void)hipEventCreate(&e0);
+            (void)hipEventCreate(&e1);
+            (void)hipEventRecord(e0, ctx->stream);
         }
     }
     ~StageTimer() {
         if (ctx->timing && e0) {
-            hipEventRecord(e1, ctx->stream);
-            hipEventSynchronize(e1);
+            (void)hipEventRecord(e1, ctx->stream);
+            (void)hipEventSynchronize(e1);
             float ms = 0;
-            hipEventElapsedTime(&ms, e0, e1);
+            (void)hipEventElapsedTime(&ms, e0, e1);
             ctx->stage_ms.emplace_back(name, ms);
-            hipEventDestroy(e0);
-            hipEventDestroy(e1);
+            (void)hipEventDestroy(e0);
+            (void)hipEventDestroy(e1);
         }
     }
 };

@@ -182,7 +182,7 @@ bool jit_compile_quotient(const AirProgram& air, const char* arch, JitKernel& ou
     }
     hipFunction_t fn = nullptr;
     if (hipModuleGetFunction(&fn, mod, "k_quotient_jit") != hipSuccess) {
-        hipModuleUnload(mod);
+        (void)hipModuleUnload(mod);
         log += " hipModuleGetFunction failed";
         return false;
     }
@@ -192,7 +192,7 @@ bool jit_compile_quotient(const AirProgram& air, const char* arch, JitKernel& ou
 }
 
 void jit_release(JitKernel& k) {
-    if (k.module) hipModuleUnload((hipModule_t)k.module);
+    if (k.module) (void)hipModuleUnload((hipModule_t)k.module);
     k.module = nullptr;
     k.fn = nullptr;
 }

@@ -21,10 +21,6 @@
 
 namespace ts {
 
-constexpr int LOG_M = 12;          // contiguous chunk = 4096 elements
-constexpr int CHUNK = 1 << LOG_M;
-constexpr int NT = 256;            // threads per workgroup
-constexpr int TILE_ELEMS = 8192;   // strided tile
 constexpr int SHIFT_LO_BITS = 10;  // coset scale s^k = hi[k >> 10] * lo[k & 1023]
 
 __device__ __forceinline__ uint32_t pad(uint32_t i) { return i + (i >> 4); }

@@ -137,7 +137,6 @@ std::unique_ptr<PcsData> TwoAdicFriPcs::commit(std::vector<DeviceMatrix>& evals,
     }
     const unsigned log_N = log2_strict(max_n) + fri_.log_blowup;
     TS_REQUIRE(log_N <= 27, TS_ERR_INVALID, "commit: LDE larger than the two-adic subgroup");
-    const uint64_t N = 1ull << log_N;
     ctx_.ensure_twiddles(std::max(1u, log_N));
 
     auto data = std::make_unique<PcsData>();

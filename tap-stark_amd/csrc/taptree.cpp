@@ -19,6 +19,7 @@
 // Executing the leaf script against a Winternitz witness (tcs/mod.rs:143-147 verify_proof) needs
 // a Bitcoin script interpreter and is out of scope: verify_batch checks that the leaf rebuilt from
 // the opened values and the lock scripts is in the tree.
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -451,7 +452,6 @@ std::unique_ptr<TapMmcsData> tap_mmcs_commit(Context& ctx, std::vector<DeviceMat
     }
     d->log_height = log2_strict(max_h);
     d->n_evals = total_w / u32_size;
-    const uint64_t N = max_h;
     const size_t n_seg = 1 + (size_t)d->n_evals;
     TS_REQUIRE(lock_scripts && lock_offsets, TS_ERR_INVALID, "tap mmcs: lock scripts missing");
     d->lock_offsets.assign(lock_offsets, lock_offsets + (size_t)num_queries * n_seg + 1);
@@ -539,6 +539,20 @@ DevBuf<uint32_t> tap_build_trees(Context& ctx, const std::vector<const uint32_t*
     t.u32_size = u32_size;
     t.elem_stride = elem_stride;
     t.tree_stride = stride;
+    t.prefix = nullptr;
+    t.n_len = 5 * ((uint32_t)cols.size() + 1) + 1;  // a push takes 1..6 bytes
+    // the state after the first lock script, tabulated per script length, when that is less work
+    // than hashing that script for every leaf (TS_TAP_PREFIX=0 switches it off for A/B runs)
+    static const bool use_prefix = [] {
+        const char* e = getenv("TS_TAP_PREFIX");
+        return !(e && e[0] == '0');
+    }();
+    DevBuf<uint32_t> d_prefix;
+    if (use_prefix && N >= 4ull * t.n_len && (uint64_t)num_queries * t.n_len * TAP_PREFIX_WORDS * 4 <= (64u << 20)) {
+        d_prefix = DevBuf<uint32_t>(&ctx, (size_t)num_queries * t.n_len * TAP_PREFIX_WORDS);
+        launch_tap_prefix(ctx, t, num_queries, tap_mid(), d_prefix.p);
+        t.prefix = d_prefix.p;
+    }
     {
         StageTimer tm(&ctx, "taptree leaves");
         launch_tapleaf_template(ctx, t, N, num_queries, tap_mid(), trees.p);

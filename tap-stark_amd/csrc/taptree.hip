@@ -142,6 +142,36 @@ k_tapleaf_blob(const uint32_t* __restrict__ words, const uint64_t* __restrict__ 
     store_digest(digests + 8 * i, s.h);
 }
 
+// The script length is hashed first (compact size in the leaf header), so the hash state after
+// header + LOCK[q][0] depends on (q, length) only -- and a tree's leaves have few distinct lengths
+// (they differ by the sizes of the pushes).  k_tap_prefix tabulates that state for every length a
+// leaf of tree q can have; k_tapleaf_template then starts from the table instead of hashing the
+// first lock script again for each of the N leaves: one of the 1 + n_evals lock scripts less per
+// leaf (a third of the work for the FRI matrices and for a two-column trace).
+__global__ void __launch_bounds__(TPB)
+k_tap_prefix(TapTemplate t, TapMid mid, uint32_t* __restrict__ table) {
+    __shared__ uint32_t lds[16 * TPB];
+    const uint32_t d = blockIdx.x * TPB + threadIdx.x;
+    if (d >= t.n_len) return;
+    const uint32_t q = blockIdx.y;
+    const uint32_t n_seg = 1 + t.n_evals;
+    const uint64_t len = t.const_len[q] + 2 * (uint64_t)(t.n_evals * t.u32_size + 1) + 1 + d;
+    Stream s;
+#pragma unroll
+    for (int k = 0; k < 8; k++) s.h[k] = mid.leaf[k];
+    s.acc = 0; s.a = 0; s.widx = 0;
+    s.blk = lds + threadIdx.x;
+    put_leaf_header(s, len);
+    s.put_segment(t.seg_words + t.seg_word_off[(uint64_t)q * n_seg], t.seg_len[(uint64_t)q * n_seg]);
+    uint32_t* e = table + ((uint64_t)q * t.n_len + d) * TAP_PREFIX_WORDS;
+#pragma unroll
+    for (int k = 0; k < 8; k++) e[k] = s.h[k];
+    for (uint32_t k = 0; k < 16; k++) e[8 + k] = k < s.widx ? s.blk[k * TPB] : 0u;
+    e[24] = s.widx;
+    e[25] = s.acc;
+    e[26] = s.a;
+}
+
 // MMCS leaf `idx` of tree q = blockIdx.y (tcs/mod.rs:197-225):
 //   LOCK[q][0] push(idx) OP_EQUALVERIFY
 //   for every evaluation j: LOCK[q][1+j] { push(limb) OP_EQUALVERIFY } for limbs U-1 .. 0
@@ -158,17 +188,28 @@ k_tapleaf_template(TapTemplate t, uint64_t n_leaves, TapMid mid, uint32_t* __res
     const uint64_t* seg_off = t.seg_word_off + (uint64_t)q * n_seg;
     const uint32_t* seg_len = t.seg_len + (uint64_t)q * n_seg;
     // pass 1: the script length (it is hashed first, as a compact size)
-    uint64_t len = t.const_len[q] + tap_push_int_len((uint32_t)idx) + 1;
+    uint64_t pushes = tap_push_int_len((uint32_t)idx);
     for (uint32_t c = 0; c < t.n_evals * t.u32_size; c++)
-        len += tap_push_int_len(t.cols[c][(idx >> t.shift[c]) * t.elem_stride]) + 1;
-    len += 1;  // OP_1
+        pushes += tap_push_int_len(t.cols[c][(idx >> t.shift[c]) * t.elem_stride]);
+    const uint32_t n_push = t.n_evals * t.u32_size + 1;
+    const uint64_t len = t.const_len[q] + pushes + n_push + 1;  // + one OP_EQUALVERIFY per push + OP_1
     Stream s;
-#pragma unroll
-    for (int k = 0; k < 8; k++) s.h[k] = mid.leaf[k];
-    s.acc = 0; s.a = 0; s.widx = 0;
     s.blk = lds + threadIdx.x;
-    put_leaf_header(s, len);
-    s.put_segment(t.seg_words + seg_off[0], seg_len[0]);
+    if (t.prefix != nullptr) {
+        const uint32_t* e = t.prefix + ((uint64_t)q * t.n_len + (pushes - n_push)) * TAP_PREFIX_WORDS;
+#pragma unroll
+        for (int k = 0; k < 8; k++) s.h[k] = e[k];
+        s.widx = e[24];
+        s.acc = e[25];
+        s.a = e[26];
+        for (uint32_t k = 0; k < s.widx; k++) s.blk[k * TPB] = e[8 + k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; k++) s.h[k] = mid.leaf[k];
+        s.acc = 0; s.a = 0; s.widx = 0;
+        put_leaf_header(s, len);
+        s.put_segment(t.seg_words + seg_off[0], seg_len[0]);
+    }
     s.put_push_int((uint32_t)idx);
     s.put_byte(0x88);  // OP_EQUALVERIFY
     for (uint32_t j = 0; j < t.n_evals; j++) {
@@ -230,6 +271,12 @@ void launch_tapleaf_template(Context& ctx, const TapTemplate& t, uint64_t n_leav
     TS_REQUIRE(n_trees >= 1 && n_trees <= 65535, TS_ERR_INVALID, "taptree: 1..65535 trees");
     TS_LAUNCH(ctx, k_tapleaf_template, dim3((unsigned)((n_leaves + TPB - 1) / TPB), n_trees), dim3(TPB), 0,
               t, n_leaves, mid, digests);
+    TS_HIP(hipGetLastError());
+}
+
+void launch_tap_prefix(Context& ctx, const TapTemplate& t, uint32_t n_trees, const TapMid& mid, uint32_t* table) {
+    TS_REQUIRE(n_trees >= 1 && n_trees <= 65535 && t.n_len >= 1, TS_ERR_INVALID, "taptree: prefix table shape");
+    TS_LAUNCH(ctx, k_tap_prefix, dim3((t.n_len + TPB - 1) / TPB, n_trees), dim3(TPB), 0, t, mid, table);
     TS_HIP(hipGetLastError());
 }
 

@@ -39,13 +39,21 @@ struct TapTemplate {
     uint32_t elem_stride;              // words between consecutive rows of a column (1: column-major;
                                        // 8: an array of EF4 pairs, the FRI commit-phase matrices)
     uint64_t tree_stride;              // digests per tree (2 N - 1)
+    // optional (nullptr: none): the stream state after the leaf header and the first lock script,
+    // [Q][n_len][TAP_PREFIX_WORDS], entry d = script length const_len + 2 (n_values + 1) + 1 + d
+    const uint32_t* prefix;
+    uint32_t n_len;
 };
+// h[8], the 16 words of the open block, words in it, partial word, its bytes
+constexpr uint32_t TAP_PREFIX_WORDS = 32;
 
 void launch_tapleaf_blob(Context& ctx, const uint32_t* words, const uint64_t* word_off,
                          const uint64_t* byte_len, uint64_t n_leaves, const TapMid& mid,
                          uint32_t* digests);
 void launch_tapleaf_template(Context& ctx, const TapTemplate& t, uint64_t n_leaves, uint32_t n_trees,
                              const TapMid& mid, uint32_t* digests);
+// fills t.prefix (n_trees x t.n_len entries) for a template whose other fields are set
+void launch_tap_prefix(Context& ctx, const TapTemplate& t, uint32_t n_trees, const TapMid& mid, uint32_t* table);
 // every upper level of n_trees trees stored `tree_stride` digests apart, levels back to back
 void launch_tapbranch_levels(Context& ctx, uint32_t* trees, uint64_t tree_stride, unsigned log_leaves,
                              uint32_t n_trees, const TapMid& mid);

@@ -61,11 +61,7 @@ bool mmcs_verify(const std::vector<uint64_t>& heights, const std::vector<uint32_
                  uint64_t index, const uint32_t* rows, const uint32_t* path, size_t path_len,
                  const uint32_t root[8]) {
     uint64_t max_h = 0;
-    size_t total = 0;
-    for (size_t i = 0; i < heights.size(); i++) {
-        max_h = std::max(max_h, heights[i]);
-        total += widths[i];
-    }
+    for (size_t i = 0; i < heights.size(); i++) max_h = std::max(max_h, heights[i]);
     unsigned log_max = 0;
     while ((1ull << log_max) < max_h) log_max++;
     if (path_len != log_max || (index >> log_max) != 0) return false;

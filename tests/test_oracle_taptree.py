@@ -299,36 +299,3 @@ def test_postcard_round_trip_of_a_proof_over_taptrees(orc, lib):
     assert (back.words == proof).all()
     config = ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(*cfg), host_only=True))
     assert tt.verify_tap(config, air, ts.BfChallenger(), back.words, pis, locks) == 0
-
-
-def test_postcard_parser_survives_corruption(orc, lib):
-    # untrusted bytes: every truncation and a few hundred random byte flips of v1 and v2 proofs either
-    # raise TsError or decode to words that encode back to the same bytes; never crash, never hang
-    import time
-
-    import tapstark_amd as ts
-    from tapstark_amd._lib import TsError
-
-    cfg = (2, 3, 4)
-    air, trace, pis, tape, locks = _tap_case("fib", 3, cfg)
-    v2 = ts.Proof(words=orc.prove_tap(orc.FriConfig(*cfg), tape, trace, pis, locks)).to_postcard()
-    v1 = ts.Proof(words=orc.prove(orc.FriConfig(*cfg), tape, trace, pis)).to_postcard()
-    rng = np.random.default_rng(11)
-    t0 = time.time()
-    for data in (v1, v2):
-        cases = [data[:k] for k in range(0, len(data), 7)]
-        for _ in range(300):
-            b = bytearray(data)
-            for _ in range(int(rng.integers(1, 4))):
-                b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
-            cases.append(bytes(b))
-        ok = 0
-        for c in cases:
-            try:
-                p = ts.Proof.from_postcard(c)
-            except (TsError, ValueError):
-                continue
-            assert p.to_postcard() == c
-            ok += 1
-        assert ok < len(cases)  # most corruptions are refused
-    assert time.time() - t0 < 20

@@ -38,22 +38,37 @@ def _headers_mtime() -> float:
     return max(os.path.getmtime(h) for h in hs)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    os.makedirs(OBJ, exist_ok=True)
-    os.makedirs(LIBDIR, exist_ok=True)
+def build(force: bool = False, verbose: bool = False, asan: bool = False) -> str:
+    """asan=True: the HOST sources (.cpp: C ABI, wire formats, verifier, challenger, host prover) are
+    built with AddressSanitizer + UBSan into lib_asan/ (device code is not instrumented: GPU
+    sanitizers are not available on the pool).  Run the CPU suite on it with
+
+        TS_LIB_PATH=tap-stark_amd/lib_asan/libtapstark_hip.so ASAN_OPTIONS=detect_leaks=0 \
+        LD_PRELOAD="$(python -m tapstark_amd.build --asan-runtime)" python -m pytest tests -m "not gpu"
+    """
+    obj_dir = OBJ + ("_asan" if asan else "")
+    lib_dir = LIBDIR + ("_asan" if asan else "")
+    lib = os.path.join(lib_dir, "libtapstark_hip.so")
+    os.makedirs(obj_dir, exist_ok=True)
+    os.makedirs(lib_dir, exist_ok=True)
     hipcc = _hipcc()
     hdr_m = _headers_mtime()
     common = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-I", CSRC]
+    san = ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer",
+           "-shared-libsan"]
     jobs = []
     objs = []
     for src in _sources():
         sp = os.path.join(CSRC, src)
-        op = os.path.join(OBJ, src + ".o")
+        op = os.path.join(obj_dir, src + ".o")
         objs.append(op)
         if not force and os.path.exists(op) and os.path.getmtime(op) > max(os.path.getmtime(sp), hdr_m):
             continue
         if src.endswith(".hip"):
             cmd = [hipcc, f"--offload-arch={ARCH}", "-x", "hip", *common, "-c", sp, "-o", op]
+        elif asan:  # plain host C++ (no offload), instrumented
+            cmd = [_clangxx(), "-x", "c++", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(_rocm(), "include"),
+                   "-O1", "-g", *common[1:], *san, "-c", sp, "-o", op]
         else:  # host sources include HIP headers: same single target, no stray default-arch device code
             cmd = [hipcc, f"--offload-arch={ARCH}", *common, "-c", sp, "-o", op]
         jobs.append(cmd)
@@ -70,10 +85,36 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if jobs:
         with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
             list(ex.map(run, jobs))
-    if jobs or not os.path.exists(LIB):
-        run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB, *objs])
-    return LIB
+    if jobs or not os.path.exists(lib):
+        run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *(san if asan else []), "-o", lib, *objs])
+    return lib
+
+
+def _rocm() -> str:
+    return os.path.dirname(os.path.dirname(os.path.realpath(_hipcc())))
+
+
+def _clangxx() -> str:
+    for cand in (os.path.join(_rocm(), "lib", "llvm", "bin", "clang++"), "/opt/rocm/lib/llvm/bin/clang++"):
+        if os.path.exists(cand):
+            return cand
+    raise RuntimeError("clang++ of the ROCm toolchain not found")
+
+
+def asan_runtime() -> str:
+    """What LD_PRELOAD needs for the asan build under an uninstrumented python: clang's ASan runtime,
+    and libstdc++ so that the runtime's __cxa_throw interceptor finds the real one at start-up (the
+    library reports refused inputs with C++ exceptions internally)."""
+    import glob
+
+    rt = glob.glob(os.path.join(_rocm(), "lib", "llvm", "lib", "clang", "*", "lib", "linux",
+                                "libclang_rt.asan-x86_64.so"))
+    r = subprocess.run(["gcc", "-print-file-name=libstdc++.so.6"], capture_output=True, text=True)
+    return " ".join([rt[0], os.path.realpath(r.stdout.strip())])
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--asan-runtime" in sys.argv:
+        print(asan_runtime())
+    else:
+        print(build(force="--force" in sys.argv, verbose=True, asan="--asan" in sys.argv))

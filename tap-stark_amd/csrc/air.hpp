@@ -6,6 +6,7 @@
 // (symbolic_expression.rs:41-61,137,182,227; symbolic_builder.rs:15-32) and lowers it to a linear
 // register program that the quotient kernel interprets (quotient.hip), one thread per row.
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 
 #include <vector>

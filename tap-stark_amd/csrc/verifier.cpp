@@ -371,12 +371,15 @@ static int verify_impl(const FriConfig& fri, const AirProgram& air, BfChallenger
     if (pw != w || pqd != qd) return 1;
     const uint32_t* trace_root = rb.take(cw);
     const uint32_t* quot_root = rb.take(cw);
-    const Ef* trace_local = reinterpret_cast<const Ef*>(rb.take(4 * (size_t)w));
-    const Ef* trace_next = reinterpret_cast<const Ef*>(rb.take(4 * (size_t)w));
-    const Ef* qchunks = reinterpret_cast<const Ef*>(rb.take(16 * (size_t)qd));
+    const uint32_t* trace_local = rb.take(4 * (size_t)w);
+    const uint32_t* trace_next = rb.take(4 * (size_t)w);
+    const uint32_t* qchunks = rb.take(16 * (size_t)qd);
     if (rb.bad) return 9;
-    std::vector<Ef> tl(trace_local, trace_local + w), tn(trace_next, trace_next + w),
-        qc(qchunks, qchunks + 4 * (size_t)qd);
+    // (the proof is a word stream: Ef is 16-byte aligned, the words are not)
+    std::vector<Ef> tl(w), tn(w), qc(4 * (size_t)qd);
+    memcpy((void*)tl.data(), trace_local, 16 * (size_t)w);
+    memcpy((void*)tn.data(), trace_next, 16 * (size_t)w);
+    memcpy((void*)qc.data(), qchunks, 64 * (size_t)qd);
     for (auto* vec : {&tl, &tn, &qc})
         for (auto& e : *vec)
             for (int k = 0; k < 4; k++)

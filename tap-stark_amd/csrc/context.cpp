@@ -60,7 +60,10 @@ void* Context::alloc(size_t bytes) {
             release_cache();
             e = hipMalloc(&p, sz);
         }
-        if (e != hipSuccess) throw Error(TS_ERR_OOM, "device allocation failed");
+        if (e != hipSuccess) {
+            (void)hipGetLastError();  // the refusal must not surface again at the next launch check
+            throw Error(TS_ERR_OOM, "device allocation failed");
+        }
         bytes_reserved += sz;
     }
     live_blocks[p] = sz;

@@ -618,3 +618,20 @@ def test_zero_queries_refused(ctx):
     with pytest.raises(ts._lib.TsError):
         ts.prove(ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(2, 0, 8), ctx)), SynthMulAir(64),
                  ts.BfChallenger(), generate_synth_mul_trace(4), [])
+
+
+def test_device_out_of_memory_is_a_status_not_a_crash():
+    # more than the card holds (2^26 x 2048 words = 512 GiB against 288 GB of HBM): the allocation is
+    # refused with TS_ERR_OOM (after the context drops its block cache and retries once), nothing
+    # has been launched on the missing buffer, and the context goes on working
+    from tapstark_amd._lib import TsError
+
+    c = ts.Context(0)
+    with pytest.raises(TsError) as e:
+        ts.DeviceMatrix.synth_mul(c, 1 << 26, 2048)
+    assert e.value.code == 3  # TS_ERR_OOM
+    config = ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(2, 4, 8), c))
+    trace = generate_fibonacci_trace(0, 1, 64)
+    pis = fibonacci_public_values(trace)
+    proof = ts.prove(config, FibonacciAir(), ts.BfChallenger(), trace, pis)
+    ts.verify(config, FibonacciAir(), ts.BfChallenger(), proof, pis)

@@ -635,3 +635,21 @@ def test_device_out_of_memory_is_a_status_not_a_crash():
     pis = fibonacci_public_values(trace)
     proof = ts.prove(config, FibonacciAir(), ts.BfChallenger(), trace, pis)
     ts.verify(config, FibonacciAir(), ts.BfChallenger(), proof, pis)
+
+
+def test_out_of_memory_in_the_middle_of_a_proof():
+    # a 64 GiB trace fits, its 4x LDE does not: prove() must unwind (buffers back to the pool, kernels
+    # already queued on them finish harmlessly) and report TS_ERR_OOM; the context stays usable
+    from tapstark_amd._lib import TsError
+
+    c = ts.Context(0)
+    m = ts.DeviceMatrix.synth_mul(c, 1 << 24, 1024)
+    config = ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(2, 4, 8), c))
+    with pytest.raises(TsError) as e:
+        ts.prove(config, ts.CompiledAir(c, ts.air_tape(SynthMulAir(1024), 0)), ts.BfChallenger(), m, [])
+    assert e.value.code == 3  # TS_ERR_OOM
+    trace = generate_fibonacci_trace(0, 1, 64)
+    pis = fibonacci_public_values(trace)
+    proof = ts.prove(config, FibonacciAir(), ts.BfChallenger(), trace, pis)
+    ts.verify(config, FibonacciAir(), ts.BfChallenger(), proof, pis)
+    del proof, m, c  # the context (and its 128 GB block cache) goes away here

@@ -27,23 +27,45 @@ namespace {
 
 constexpr int TPB = 128;
 
+// Compressions happen at points every lane of a wavefront reaches together.  Lanes drift apart by a
+// few bytes (a value below 2^23 is pushed with fewer bytes: 3 % of the leaves of an EF4-pair matrix,
+// so most wavefronts hold one), and a stream that compresses "when my 16th word arrives" then runs
+// every block twice for such a wavefront, once per group of lanes.  Here a lane's words go to a
+// 32-word ring; inside a constant segment every 16 source words add exactly 16 stream words to every
+// lane, whatever its alignment, so the compression after them is unconditional (each lane has
+// 16..31 words pending); only the few words around the pushes are drained under a per-lane test.
+constexpr uint32_t RING = 32;
+
 struct Stream {
     uint32_t h[8];
-    uint32_t acc;   // partial word: `a` leading bytes valid (big-endian), the rest zero
-    uint32_t a;     // 0..3
-    uint32_t widx;  // words of the current block already in LDS
-    uint32_t* blk;  // this thread's column of the [16][TPB] block image
+    uint32_t acc;    // partial word: `a` leading bytes valid (big-endian), the rest zero
+    uint32_t a;      // 0..3
+    uint32_t wpos;   // words written
+    uint32_t rpos;   // words compressed (a multiple of 16)
+    uint32_t* ring;  // this thread's column of the [RING][TPB] image
 
-    __device__ __forceinline__ void flush_block() {
+    __device__ __forceinline__ void init(const uint32_t* iv, uint32_t* lds_column) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) h[k] = iv[k];
+        acc = 0; a = 0; wpos = 0; rpos = 0;
+        ring = lds_column;
+    }
+    __device__ __forceinline__ uint32_t pending() const { return wpos - rpos; }
+    __device__ __forceinline__ void compress_block() {  // needs pending() >= 16
         uint32_t m[16];
 #pragma unroll
-        for (int i = 0; i < 16; i++) m[i] = blk[i * TPB];
+        for (int i = 0; i < 16; i++) m[i] = ring[((rpos + i) & (RING - 1)) * TPB];
         sha::compress(h, m);
-        widx = 0;
+        rpos += 16;
+    }
+    // brings pending() below 16; every put_* below leaves at most RING words pending provided it
+    // started below 16, and the callers drain between them
+    __device__ __forceinline__ void drain() {
+        if (pending() >= 16) compress_block();
     }
     __device__ __forceinline__ void emit_word(uint32_t x) {
-        blk[widx * TPB] = x;
-        if (++widx == 16) flush_block();
+        ring[(wpos & (RING - 1)) * TPB] = x;
+        wpos++;
     }
     __device__ __forceinline__ void put_byte(uint32_t b) {
         acc |= b << (24 - 8 * a);
@@ -53,7 +75,7 @@ struct Stream {
             a = 0;
         }
     }
-    // one big-endian source word = 4 stream bytes
+    // one big-endian source word = 4 stream bytes = exactly one stream word
     __device__ __forceinline__ void put_word(uint32_t x) {
         if (a == 0) {
             emit_word(x);
@@ -62,19 +84,27 @@ struct Stream {
             acc = x << (32 - 8 * a);
         }
     }
-    // bytes [0, len) of a segment stored as big-endian words (zero padded)
+    // bytes [0, len) of a segment stored as big-endian words (zero padded); pending() < 16 on entry
+    // and on return
     __device__ __forceinline__ void put_segment(const uint32_t* __restrict__ words, uint32_t len) {
         const uint32_t full = len >> 2;
-        for (uint32_t k = 0; k < full; k++) put_word(words[k]);
+        uint32_t k = 0;
+        for (; k + 16 <= full; k += 16) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) put_word(words[k + i]);
+            compress_block();  // every lane alike
+        }
+        for (; k < full; k++) put_word(words[k]);
         const uint32_t tail = len & 3;
         if (tail) {
             const uint32_t x = words[full];
             for (uint32_t j = 0; j < tail; j++) put_byte((x >> (24 - 8 * j)) & 0xff);
         }
+        drain();
     }
-    // rust-bitcoin Builder::push_int for 0 <= v < 2^31 (script numbers: minimal little-endian
-    // sign-magnitude; 0 -> OP_0, 1..16 -> OP_1..OP_16)
-    __device__ __forceinline__ void put_push_int(uint32_t v) {
+    // rust-bitcoin Builder::push_int for 0 <= v < 2^32 (script numbers: minimal little-endian
+    // sign-magnitude; 0 -> OP_0, 1..16 -> OP_1..OP_16), followed by one opcode
+    __device__ __forceinline__ void put_push_int_op(uint32_t v, uint32_t opcode) {
         if (v == 0) {
             put_byte(0x00);
         } else if (v <= 16) {
@@ -84,6 +114,8 @@ struct Stream {
             put_byte(n);
             for (uint32_t j = 0; j < n; j++) put_byte(j < 4 ? (v >> (8 * j)) & 0xff : 0);
         }
+        put_byte(opcode);
+        drain();
     }
     // padding + length; total = bytes hashed since the IV (tag block included)
     __device__ __forceinline__ void finish(uint64_t total_bytes) {
@@ -93,10 +125,11 @@ struct Stream {
             acc = 0;
             a = 0;
         }
-        while (widx != 14) emit_word(0);
+        while ((pending() & 15) != 14) emit_word(0);
         const uint64_t bits = total_bytes * 8;
         emit_word((uint32_t)(bits >> 32));
         emit_word((uint32_t)bits);
+        while (pending() != 0) compress_block();
     }
 };
 
@@ -126,14 +159,11 @@ __global__ void __launch_bounds__(TPB)
 k_tapleaf_blob(const uint32_t* __restrict__ words, const uint64_t* __restrict__ word_off,
                const uint64_t* __restrict__ byte_len, uint64_t n_leaves, TapMid mid,
                uint32_t* __restrict__ digests) {
-    __shared__ uint32_t lds[16 * TPB];
+    __shared__ uint32_t lds[RING * TPB];
     const uint64_t i = (uint64_t)blockIdx.x * TPB + threadIdx.x;
     if (i >= n_leaves) return;
     Stream s;
-#pragma unroll
-    for (int k = 0; k < 8; k++) s.h[k] = mid.leaf[k];
-    s.acc = 0; s.a = 0; s.widx = 0;
-    s.blk = lds + threadIdx.x;
+    s.init(mid.leaf, lds + threadIdx.x);
     const uint64_t len = byte_len[i];
     put_leaf_header(s, len);
     s.put_segment(words + word_off[i], (uint32_t)len);
@@ -150,24 +180,22 @@ k_tapleaf_blob(const uint32_t* __restrict__ words, const uint64_t* __restrict__ 
 // leaf (a third of the work for the FRI matrices and for a two-column trace).
 __global__ void __launch_bounds__(TPB)
 k_tap_prefix(TapTemplate t, TapMid mid, uint32_t* __restrict__ table) {
-    __shared__ uint32_t lds[16 * TPB];
+    __shared__ uint32_t lds[RING * TPB];
     const uint32_t d = blockIdx.x * TPB + threadIdx.x;
     if (d >= t.n_len) return;
     const uint32_t q = blockIdx.y;
     const uint32_t n_seg = 1 + t.n_evals;
     const uint64_t len = t.const_len[q] + 2 * (uint64_t)(t.n_evals * t.u32_size + 1) + 1 + d;
     Stream s;
-#pragma unroll
-    for (int k = 0; k < 8; k++) s.h[k] = mid.leaf[k];
-    s.acc = 0; s.a = 0; s.widx = 0;
-    s.blk = lds + threadIdx.x;
+    s.init(mid.leaf, lds + threadIdx.x);
     put_leaf_header(s, len);
     s.put_segment(t.seg_words + t.seg_word_off[(uint64_t)q * n_seg], t.seg_len[(uint64_t)q * n_seg]);
     uint32_t* e = table + ((uint64_t)q * t.n_len + d) * TAP_PREFIX_WORDS;
 #pragma unroll
     for (int k = 0; k < 8; k++) e[k] = s.h[k];
-    for (uint32_t k = 0; k < 16; k++) e[8 + k] = k < s.widx ? s.blk[k * TPB] : 0u;
-    e[24] = s.widx;
+    const uint32_t pend = s.pending();  // < 16 after a segment
+    for (uint32_t k = 0; k < 16; k++) e[8 + k] = k < pend ? s.ring[((s.rpos + k) & (RING - 1)) * TPB] : 0u;
+    e[24] = pend;
     e[25] = s.acc;
     e[26] = s.a;
 }
@@ -180,7 +208,7 @@ k_tap_prefix(TapTemplate t, TapMid mid, uint32_t* __restrict__ table) {
 // padded row is cols[c][idx >> shift[c]]
 __global__ void __launch_bounds__(TPB)
 k_tapleaf_template(TapTemplate t, uint64_t n_leaves, TapMid mid, uint32_t* __restrict__ digests) {
-    __shared__ uint32_t lds[16 * TPB];
+    __shared__ uint32_t lds[RING * TPB];
     const uint64_t idx = (uint64_t)blockIdx.x * TPB + threadIdx.x;
     if (idx >= n_leaves) return;
     const uint32_t q = blockIdx.y;
@@ -194,30 +222,24 @@ k_tapleaf_template(TapTemplate t, uint64_t n_leaves, TapMid mid, uint32_t* __res
     const uint32_t n_push = t.n_evals * t.u32_size + 1;
     const uint64_t len = t.const_len[q] + pushes + n_push + 1;  // + one OP_EQUALVERIFY per push + OP_1
     Stream s;
-    s.blk = lds + threadIdx.x;
     if (t.prefix != nullptr) {
         const uint32_t* e = t.prefix + ((uint64_t)q * t.n_len + (pushes - n_push)) * TAP_PREFIX_WORDS;
-#pragma unroll
-        for (int k = 0; k < 8; k++) s.h[k] = e[k];
-        s.widx = e[24];
+        s.init(e, lds + threadIdx.x);
+        s.wpos = e[24];
         s.acc = e[25];
         s.a = e[26];
-        for (uint32_t k = 0; k < s.widx; k++) s.blk[k * TPB] = e[8 + k];
+        for (uint32_t k = 0; k < s.wpos; k++) s.ring[k * TPB] = e[8 + k];
     } else {
-#pragma unroll
-        for (int k = 0; k < 8; k++) s.h[k] = mid.leaf[k];
-        s.acc = 0; s.a = 0; s.widx = 0;
+        s.init(mid.leaf, lds + threadIdx.x);
         put_leaf_header(s, len);
         s.put_segment(t.seg_words + seg_off[0], seg_len[0]);
     }
-    s.put_push_int((uint32_t)idx);
-    s.put_byte(0x88);  // OP_EQUALVERIFY
+    s.put_push_int_op((uint32_t)idx, 0x88);  // OP_EQUALVERIFY
     for (uint32_t j = 0; j < t.n_evals; j++) {
         s.put_segment(t.seg_words + seg_off[1 + j], seg_len[1 + j]);
         for (uint32_t l = t.u32_size; l-- > 0;) {
             const uint32_t c = j * t.u32_size + l;
-            s.put_push_int(t.cols[c][(idx >> t.shift[c]) * t.elem_stride]);
-            s.put_byte(0x88);
+            s.put_push_int_op(t.cols[c][(idx >> t.shift[c]) * t.elem_stride], 0x88);
         }
     }
     s.put_byte(0x51);  // OP_1

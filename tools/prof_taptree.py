@@ -42,6 +42,10 @@ def main():
     kt = ctx.take_kernel_timings()
     script_len = sum(len(x) for x in locks(0, n_evals)) + 5 + n_evals * u32 * 6 + 1
     compress_per_leaf = (64 + 4 + script_len + 9 + 63) // 64
+    # with the prefix table (default; TS_TAP_PREFIX=0 switches it off) a leaf starts after the index
+    # lock script: those blocks are looked up, not compressed
+    prefix = os.environ.get("TS_TAP_PREFIX", "1") != "0"
+    executed = compress_per_leaf - ((4 + len(locks(0, n_evals)[0])) // 64 if prefix else 0)
     leaves = (1 << log_h) * Q
     leaf_ms = kt["k_tapleaf_template"][1] / kt["k_tapleaf_template"][0]
     branch_ms = kt["k_tapbranch_level"][1] / reps
@@ -49,7 +53,8 @@ def main():
         "shape": {"log_height": log_h, "width": width, "u32_size": u32, "num_queries": Q},
         "leaf_script_bytes": script_len, "compressions_per_leaf": compress_per_leaf,
         "k_tapleaf_template_ms": round(leaf_ms, 4),
-        "sha256_compressions_per_s": round(leaves * compress_per_leaf / (leaf_ms * 1e-3), 0),
+        "prefix_table": prefix, "compressions_executed_per_leaf": executed,
+        "sha256_compressions_per_s": round(leaves * executed / (leaf_ms * 1e-3), 0),
         "sha256_compressions_per_s_alu_peak": round(ctx.alu_ceiling(2), 0),
         "leaf_script_GB_per_s": round(leaves * script_len / (leaf_ms * 1e-3) / 1e9, 2),
         "k_tapbranch_levels_ms": round(branch_ms, 4),

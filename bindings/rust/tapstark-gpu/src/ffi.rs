@@ -97,6 +97,35 @@ extern "C" {
     pub fn ts_proof_to_postcard(proof: *const u32, n_words: usize, out: *mut u8, cap_bytes: usize,
                                 n_bytes_out: *mut usize) -> ts_status;
 
+    // the reference's own MMCS: TapTreeMmcs (csrc/taptree.cpp, tap_prover.cpp)
+    pub fn ts_tapleaf_hash(script: *const u8, len: usize, out: *mut u8) -> ts_status;
+    pub fn ts_tapbranch_hash(a: *const u8, b: *const u8, out: *mut u8) -> ts_status;
+    pub fn ts_tap_mmcs_commit(ctx: *mut ts_ctx, n_mats: u32, mats: *const *mut ts_matrix, u32_size: u32,
+                              num_queries: u32, lock_scripts: *const u8, lock_offsets: *const u64,
+                              roots_out: *mut u8, out: *mut *mut ts_tap_mmcs_data) -> ts_status;
+    pub fn ts_tap_mmcs_info(d: *const ts_tap_mmcs_data, n_mats: *mut u32, log_max_height: *mut u32,
+                            n_evals: *mut u32, num_queries: *mut u32) -> ts_status;
+    pub fn ts_tap_mmcs_open_batch(d: *const ts_tap_mmcs_data, query_times_index: u32, index: u64,
+                                  rows_out: *mut u32, path_out: *mut u8, script_out: *mut u8, script_cap: usize,
+                                  script_len: *mut usize) -> ts_status;
+    pub fn ts_tap_mmcs_verify_batch(lock_scripts: *const u8, lock_offsets: *const u64, n_evals: u32, u32_size: u32,
+                                    index: u64, opened_values: *const u32, path: *const u8, depth: u32,
+                                    root: *const u8, ok: *mut c_int) -> ts_status;
+    pub fn ts_tap_mmcs_free(d: *mut ts_tap_mmcs_data);
+    pub fn ts_prove_tap(ctx: *mut ts_ctx, cfg: *const ts_fri_config, air: *const ts_air, chal: *mut ts_challenger,
+                        trace: *mut ts_matrix, public_values: *const u32, n_public: u32, lock_scripts: *const u8,
+                        lock_offsets: *const u64, n_scripts: usize, proof_out: *mut u32, cap_words: usize,
+                        n_words_out: *mut usize) -> ts_status;
+    pub fn ts_prove_tap_sharded(ctx: *mut ts_ctx, cfg: *const ts_fri_config, comm: *const ts_comm,
+                                air: *const ts_air, chal: *mut ts_challenger, trace: *mut ts_matrix,
+                                public_values: *const u32, n_public: u32, lock_scripts: *const u8,
+                                lock_offsets: *const u64, n_scripts: usize, proof_out: *mut u32, cap_words: usize,
+                                n_words_out: *mut usize) -> ts_status;
+    pub fn ts_verify_tap(cfg: *const ts_fri_config, air: *const ts_air, chal: *mut ts_challenger,
+                         proof: *const u32, n_words: usize, public_values: *const u32, n_public: u32,
+                         lock_scripts: *const u8, lock_offsets: *const u64, n_scripts: usize,
+                         verdict: *mut c_int) -> ts_status;
+
     // native communicators (csrc/comm.cpp)
     pub fn ts_rccl_available() -> c_int;
     pub fn ts_rccl_unique_id(out: *mut u8) -> ts_status;

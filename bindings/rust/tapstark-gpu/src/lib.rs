@@ -22,6 +22,7 @@ pub mod ffi;
 pub mod pcs;
 pub mod proof;
 pub mod prove;
+pub mod tap;
 
 pub use air::serialize_constraints;
 pub use comm::{prove_gpu_sharded, rccl_unique_id, RcclComm};
@@ -29,3 +30,4 @@ pub use context::{DeviceMatrix, GpuChallenger, GpuContext};
 pub use pcs::{FriConfig, GpuFriPcs, GpuPcsError, GpuProverData};
 pub use proof::Proof;
 pub use prove::{prove_gpu, prove_gpu_stepwise, CompiledAir};
+pub use tap::{prove_gpu_tap, verify_gpu_tap, LockTable};

@@ -1,4 +1,4 @@
-//! The proof as Rust values: TSPF v1 words -> structs with the reference's field
+//! The proof as Rust values: TSPF v1 / v2 words -> structs with the reference's field
 //! names and field order (uni-stark/src/proof.rs:17-37, fri/src/proof.rs:13-33,
 //! fri/src/two_adic_pcs.rs:63-68), deriving serde so that `postcard::to_allocvec(&proof)` yields the
 //! bytes `ts_proof_to_postcard` yields.
@@ -56,10 +56,14 @@ pub struct Proof {
 pub(crate) struct Words<'a> {
     w: &'a [u32],
     pos: usize,
+    n_roots: usize, // roots per commitment: 1 (TSPF v1, Blake3 Merkle MMCS), num_queries (v2, taptrees)
 }
 impl<'a> Words<'a> {
     pub(crate) fn new(w: &'a [u32]) -> Self {
-        Self { w, pos: 0 }
+        Self { w, pos: 0, n_roots: 1 }
+    }
+    fn commitment(&mut self) -> Commitment {
+        (0..self.n_roots).map(|_| self.digest()).collect()
     }
     pub(crate) fn get(&mut self) -> u32 {
         let v = self.w[self.pos];
@@ -101,7 +105,7 @@ impl<'a> Words<'a> {
     }
     pub(crate) fn fri_proof(&mut self) -> FriProof {
         let r = self.get() as usize;
-        let commit_phase_commits = (0..r).map(|_| vec![self.digest()]).collect();
+        let commit_phase_commits = (0..r).map(|_| self.commitment()).collect();
         let q = self.get() as usize;
         let mut query_proofs = Vec::with_capacity(q);
         for _ in 0..q {
@@ -132,15 +136,21 @@ impl<'a> Words<'a> {
 }
 
 impl Proof {
-    /// TSPF v1: `[magic, 1, degree_bits, width, quotient_degree]`, commitments, opened values, FriProof
+    /// TSPF v1: `[magic, 1, degree_bits, width, quotient_degree]`, commitments, opened values, FriProof.
+    /// TSPF v2 (proofs over taptrees, `ts_prove_tap`): a sixth header word `num_queries`, and every
+    /// commitment is that many roots -- `Vec<TreeRoot>` exactly as the reference's `Commitment`.
     pub fn from_tspf(words: &[u32]) -> Self {
         let mut r = Words::new(words);
         assert_eq!(r.get(), 0x4650_5354, "TSPF magic");
-        assert_eq!(r.get(), 1, "TSPF version");
+        let version = r.get();
+        assert!(version == 1 || version == 2, "TSPF version");
         let degree_bits = r.get() as usize;
         let width = r.get() as usize;
         let qd = r.get() as usize;
-        let commitments = Commitments { trace: vec![r.digest()], quotient_chunks: vec![r.digest()] };
+        if version == 2 {
+            r.n_roots = r.get() as usize;
+        }
+        let commitments = Commitments { trace: r.commitment(), quotient_chunks: r.commitment() };
         let trace_local = (0..width).map(|_| r.ef()).collect();
         let trace_next = (0..width).map(|_| r.ef()).collect();
         let quotient_chunks = (0..qd).map(|_| (0..4).map(|_| r.ef()).collect()).collect();

@@ -400,6 +400,17 @@ ts_status ts_prove_tap(ts_ctx* ctx, const ts_fri_config* cfg, const ts_air* air,
                        ts_matrix* trace, const uint32_t* public_values, uint32_t n_public,
                        const uint8_t* lock_scripts, const uint64_t* lock_offsets, size_t n_scripts,
                        uint32_t* proof_out, size_t cap_words, size_t* n_words_out);
+/* ts_prove_tap with the commitments of ONE proof split over comm->world GPUs BY TREE (the
+ * reference clones the tree per query, tcs/mod.rs:284-292: the trees of a commitment are independent).
+ * Every rank passes the WHOLE trace and a challenger in the same state and repeats the numeric
+ * pipeline (milliseconds); rank g builds trees [g per, (g+1) per), per = ceil(num_queries / world), of
+ * every commitment -- the SHA-256 of kilobyte leaf scripts, which is where the seconds go -- the roots
+ * are all-gathered (32 bytes per tree), and query q is answered by the rank that owns tree q.  Every
+ * rank receives the whole proof, identical to ts_prove_tap's.  Only comm->all_gather is used. */
+ts_status ts_prove_tap_sharded(ts_ctx* ctx, const ts_fri_config* cfg, const ts_comm* comm, const ts_air* air,
+                               ts_challenger* chal, ts_matrix* trace, const uint32_t* public_values,
+                               uint32_t n_public, const uint8_t* lock_scripts, const uint64_t* lock_offsets,
+                               size_t n_scripts, uint32_t* proof_out, size_t cap_words, size_t* n_words_out);
 ts_status ts_verify_tap(const ts_fri_config* cfg, const ts_air* air, ts_challenger* chal,
                         const uint32_t* proof, size_t n_words, const uint32_t* public_values,
                         uint32_t n_public, const uint8_t* lock_scripts, const uint64_t* lock_offsets,

@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     "ts_taptree_from_scripts", "ts_taptree_combine", "ts_taptree_info", "ts_taptree_leaf_proof",
     "ts_taptree_verify_inclusion", "ts_taptree_free", "ts_tap_mmcs_commit", "ts_tap_mmcs_info",
     "ts_tap_mmcs_open_batch", "ts_tap_mmcs_verify_batch", "ts_tap_mmcs_free",
-    "ts_prove_tap", "ts_verify_tap",
+    "ts_prove_tap", "ts_prove_tap_sharded", "ts_verify_tap",
 ]
 
 STATUS = {0: "TS_OK", 1: "TS_ERR_INVALID", 2: "TS_ERR_HIP", 3: "TS_ERR_OOM",
@@ -193,6 +193,9 @@ def lib() -> C.CDLL:
                                                C.c_uint32, u8p, C.POINTER(C.c_int)]
         l.ts_prove_tap.argtypes = [C.c_void_p, C.POINTER(FriConfigC), C.c_void_p, C.c_void_p, C.c_void_p, u32p,
                                    C.c_uint32, C.c_char_p, u64p, C.c_size_t, u32p, C.c_size_t, szp]
+        l.ts_prove_tap_sharded.argtypes = [C.c_void_p, C.POINTER(FriConfigC), C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, u32p, C.c_uint32, C.c_char_p, u64p, C.c_size_t, u32p,
+                                           C.c_size_t, szp]
         l.ts_verify_tap.argtypes = [C.POINTER(FriConfigC), C.c_void_p, C.c_void_p, u32p, C.c_size_t, u32p,
                                     C.c_uint32, C.c_char_p, u64p, C.c_size_t, C.POINTER(C.c_int)]
         l.ts_tap_mmcs_free.argtypes = [C.c_void_p]

@@ -657,6 +657,21 @@ ts_status ts_prove(ts_ctx* ctx, const ts_fri_config* cfg, const ts_air* air, ts_
     });
 }
 
+static ts::Comm wrap_comm(const ts_comm& cb) {
+    ts::Comm c;
+    c.rank = cb.rank;
+    c.world = cb.world;
+    c.all_gather = [cb](const void* send, void* recv, size_t bytes, hipStream_t stream) {
+        if (cb.all_gather(cb.user, send, recv, bytes, (void*)stream) != 0)
+            throw ts::Error(ts::TS_ERR_COMM, "all_gather callback failed");
+    };
+    c.broadcast = [cb](void* buf, size_t bytes, int root, hipStream_t stream) {
+        if (cb.broadcast(cb.user, buf, bytes, root, (void*)stream) != 0)
+            throw ts::Error(ts::TS_ERR_COMM, "broadcast callback failed");
+    };
+    return c;
+}
+
 ts_status ts_prove_sharded(ts_ctx* ctx, const ts_fri_config* cfg, const ts_comm* comm,
                            const ts_air* air, ts_challenger* chal, ts_matrix* trace_rows,
                            const uint32_t* public_values, uint32_t n_public,
@@ -674,18 +689,8 @@ ts_status ts_prove_sharded(ts_ctx* ctx, const ts_fri_config* cfg, const ts_comm*
             TS_REQUIRE(public_values, ts::TS_ERR_INVALID, "null public values");
             pis.assign(public_values, public_values + n_public);
         }
-        ts::Comm c;
-        c.rank = comm->rank;
-        c.world = comm->world;
         const ts_comm cb = *comm;
-        c.all_gather = [cb](const void* send, void* recv, size_t bytes, hipStream_t stream) {
-            if (cb.all_gather(cb.user, send, recv, bytes, (void*)stream) != 0)
-                throw ts::Error(ts::TS_ERR_COMM, "all_gather callback failed");
-        };
-        c.broadcast = [cb](void* buf, size_t bytes, int root, hipStream_t stream) {
-            if (cb.broadcast(cb.user, buf, bytes, root, (void*)stream) != 0)
-                throw ts::Error(ts::TS_ERR_COMM, "broadcast callback failed");
-        };
+        ts::Comm c = wrap_comm(cb);
         ts::ShardOptions opt;
         if (options && options->min_local_log) {
             TS_REQUIRE(options->min_local_log <= 27, ts::TS_ERR_INVALID, "min_local_log > 27");
@@ -730,6 +735,42 @@ ts_status ts_prove_tap(ts_ctx* ctx, const ts_fri_config* cfg, const ts_air* air,
         locks.n_scripts = n_scripts;
         ts::StageTimer t(&ctx->ctx, "prove");
         std::vector<uint32_t> proof = ts::prove_tap(pcs, air->prog, chal->c, std::move(trace->m), pis, locks);
+        *n_words_out = proof.size();
+        TS_REQUIRE(proof.size() <= cap_words, ts::TS_ERR_BUFFER, "proof buffer too small");
+        memcpy(proof_out, proof.data(), proof.size() * 4);
+    });
+}
+
+ts_status ts_prove_tap_sharded(ts_ctx* ctx, const ts_fri_config* cfg, const ts_comm* comm, const ts_air* air,
+                               ts_challenger* chal, ts_matrix* trace, const uint32_t* public_values,
+                               uint32_t n_public, const uint8_t* lock_scripts, const uint64_t* lock_offsets,
+                               size_t n_scripts, uint32_t* proof_out, size_t cap_words, size_t* n_words_out) {
+    if (!ctx || !comm || !air || !chal || !trace || !proof_out || !n_words_out || !lock_scripts ||
+        !lock_offsets || !comm->all_gather)
+        return TS_ERR_INVALID;
+    *n_words_out = 0;
+    return guard(ctx, [&] {
+        ts::TwoAdicFriPcs pcs(ctx->ctx, load_cfg(cfg));
+        TS_REQUIRE(trace->m.buf.p, ts::TS_ERR_INVALID, "prove: trace matrix was already consumed");
+        std::vector<uint32_t> pis;
+        if (n_public) {
+            TS_REQUIRE(public_values, ts::TS_ERR_INVALID, "null public values");
+            pis.assign(public_values, public_values + n_public);
+        }
+        ts::TapLocks locks;
+        locks.bytes = lock_scripts;
+        locks.offsets = lock_offsets;
+        locks.n_scripts = n_scripts;
+        const ts_comm cb = *comm;
+        ts::Comm c = wrap_comm(cb);
+        ts::StageTimer t(&ctx->ctx, "prove");
+        std::vector<uint32_t> proof;
+        try {
+            proof = ts::prove_tap(pcs, air->prog, chal->c, std::move(trace->m), pis, locks, &c);
+        } catch (...) {
+            if (cb.abort) cb.abort(cb.user);  // the peers' pending collectives fail instead of waiting
+            throw;
+        }
         *n_words_out = proof.size();
         TS_REQUIRE(proof.size() <= cap_words, ts::TS_ERR_BUFFER, "proof buffer too small");
         memcpy(proof_out, proof.data(), proof.size() * 4);

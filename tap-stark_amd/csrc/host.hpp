@@ -196,9 +196,11 @@ struct TapLocks {
     const uint64_t* offsets = nullptr;  // n_scripts + 1 entries
     size_t n_scripts = 0;
 };
+// comm != nullptr: the commitments of ONE proof split by tree over comm->world ranks, each holding the
+// whole trace (tap_prover.cpp); every rank returns the whole proof, identical to the one-GPU one
 std::vector<uint32_t> prove_tap(TwoAdicFriPcs& pcs, const AirProgram& air, BfChallenger& challenger,
                                 DeviceMatrix trace, const std::vector<uint32_t>& public_values,
-                                const TapLocks& locks);
+                                const TapLocks& locks, const Comm* comm = nullptr);
 int verify_tap(const FriConfig& fri, const AirProgram& air, BfChallenger& challenger,
                const uint32_t* proof, size_t n_words, const std::vector<uint32_t>& public_values,
                const TapLocks& locks);

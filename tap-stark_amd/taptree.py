@@ -210,9 +210,11 @@ def make_lock_table(num_queries: int, width: int, quotient_degree: int, log_n: i
     return locks
 
 
-def prove_tap(config, air, challenger, trace, public_values, locks):
+def prove_tap(config, air, challenger, trace, public_values, locks, comm=None):
     """``uni_stark::prove`` with ``TapTreeMmcs`` as both MMCSs (``ts_prove_tap``); returns the
-    TSPF v2 words."""
+    TSPF v2 words.  With ``comm`` (``comm.LocalCommGroup.comm(r)``, ``comm.RcclComm``,
+    ``dist.TorchComm``) the commitments of this ONE proof are split by tree over ``comm.world`` GPUs
+    (``ts_prove_tap_sharded``): every rank passes the whole trace and gets the whole, identical proof."""
     from .air import BaseAir, air_tape
     from .stark import CompiledAir
 
@@ -233,10 +235,18 @@ def prove_tap(config, air, challenger, trace, public_values, locks):
     n_words = C.c_size_t()
     cfg = pcs.fri._c()
     blob, offs = _pack(locks)
-    ctx.check(ctx._l.ts_prove_tap(ctx.h, C.byref(cfg), air.h, challenger.h, trace.h,
-                                  _p(pis) if len(pis) else None, len(pis), blob,
-                                  offs.ctypes.data_as(C.POINTER(C.c_uint64)), len(locks), _p(out), cap,
-                                  C.byref(n_words)))
+    offs_p = offs.ctypes.data_as(C.POINTER(C.c_uint64))
+    pis_p = _p(pis) if len(pis) else None
+    if comm is None:
+        rc = ctx._l.ts_prove_tap(ctx.h, C.byref(cfg), air.h, challenger.h, trace.h, pis_p, len(pis), blob,
+                                 offs_p, len(locks), _p(out), cap, C.byref(n_words))
+    else:
+        rc = ctx._l.ts_prove_tap_sharded(ctx.h, C.byref(cfg), C.byref(comm.c), air.h, challenger.h, trace.h,
+                                         pis_p, len(pis), blob, offs_p, len(locks), _p(out), cap,
+                                         C.byref(n_words))
+        if rc == 7 and getattr(comm, "error", None):
+            raise RuntimeError("communicator callback failed:\n" + comm.error)
+    ctx.check(rc)
     return out[: n_words.value].copy()
 
 

@@ -223,3 +223,57 @@ def test_prove_over_taptrees_refuses_a_short_lock_table(ctx):
     config = ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(2, 4, 8), ctx))
     with pytest.raises(TsError):
         tt.prove_tap(config, FibonacciAir(), ts.BfChallenger(), trace, fibonacci_public_values(trace), locks[:-1])
+
+
+# ------------------------------------------------------------------ one proof over G GPUs, split by tree
+@pytest.mark.parametrize("G,air_name,log_n,cfg", [
+    (2, "fib", 5, (2, 7, 8)),    # 4 + 3 trees
+    (4, "fib", 3, (2, 5, 8)),    # 2, 2, 1, 0 trees: a rank with nothing to build
+    (8, "fib", 6, (2, 28, 8)),   # the reference's 28 queries over 8 ranks: 4, 4, ..., 0
+    (3, "mul7", 5, (3, 4, 4)),   # a world that is not a power of two; two chunk matrices
+    (8, "mul64", 4, (2, 3, 4)),  # more ranks than trees
+], ids=["G2", "G4-idle-rank", "G8-q28", "G3-mul7", "G8-three-trees"])
+def test_prove_over_taptrees_split_by_tree(ctx, G, air_name, log_n, cfg):
+    # every rank (a host thread with its own context, in-process communicator) passes the whole trace
+    # and must return the proof ts_prove_tap makes on one GPU, with its challenger in the same state
+    import threading
+
+    from tapstark_amd.airs import (FibonacciAir, SynthMulAir, fibonacci_public_values,
+                                   generate_fibonacci_trace, generate_synth_mul_trace)
+    from tapstark_amd.comm import LocalCommGroup
+
+    n = 1 << log_n
+    if air_name == "fib":
+        air, trace = FibonacciAir(), generate_fibonacci_trace(0, 1, n)
+        pis = fibonacci_public_values(trace)
+    else:
+        w = int(air_name[3:])
+        air, trace, pis = SynthMulAir(w), generate_synth_mul_trace(n, w), np.zeros(0, dtype=np.uint32)
+    qd = 1 << ts.get_log_quotient_degree(air, len(pis))
+    locks = tt.make_lock_table(cfg[1], trace.shape[1], qd, log_n, _lock_for)
+    ch0 = ts.BfChallenger()
+    want = tt.prove_tap(ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(*cfg), ctx)), air, ch0, trace.copy(), pis, locks)
+    state = ch0.sample_bits(20)
+    group = LocalCommGroup(G)
+    got, errs = [None] * G, [None] * G
+
+    def rank_main(r):
+        try:
+            c = ts.Context(0)
+            config = ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(*cfg), c))
+            ch = ts.BfChallenger()
+            p = tt.prove_tap(config, air, ch, trace.copy(), pis, locks, comm=group.comm(r))
+            got[r] = (p, ch.sample_bits(20))
+        except BaseException as e:  # noqa: BLE001
+            errs[r] = repr(e)
+
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(G)]
+    [t.start() for t in th]
+    [t.join(timeout=120) for t in th]
+    assert not any(errs), errs
+    for r in range(G):
+        assert got[r] is not None, f"rank {r} did not finish"
+        assert len(got[r][0]) == len(want) and (got[r][0] == want).all(), f"rank {r}: proof differs"
+        assert got[r][1] == state
+    assert tt.verify_tap(ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(*cfg), ctx)), air, ts.BfChallenger(),
+                         got[G - 1][0], pis, locks) == 0

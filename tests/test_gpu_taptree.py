@@ -277,3 +277,36 @@ def test_prove_over_taptrees_split_by_tree(ctx, G, air_name, log_n, cfg):
         assert got[r][1] == state
     assert tt.verify_tap(ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(*cfg), ctx)), air, ts.BfChallenger(),
                          got[G - 1][0], pis, locks) == 0
+
+
+def test_split_by_tree_rank_failure_does_not_hang(ctx):
+    # one rank is handed a lock table that is too short: it fails before its first collective and
+    # aborts the communicator; its peers return a communicator error instead of waiting for ever
+    import threading
+
+    from tapstark_amd.airs import FibonacciAir, fibonacci_public_values, generate_fibonacci_trace
+    from tapstark_amd.comm import LocalCommGroup
+
+    G, cfg = 4, (2, 6, 8)
+    trace = generate_fibonacci_trace(0, 1, 16)
+    pis = fibonacci_public_values(trace)
+    locks = tt.make_lock_table(cfg[1], 2, 1, 4, _lock_for)
+    group = LocalCommGroup(G)
+    out = [None] * G
+
+    def rank_main(r):
+        try:
+            c = ts.Context(0)
+            config = ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(*cfg), c))
+            tt.prove_tap(config, FibonacciAir(), ts.BfChallenger(), trace.copy(), pis,
+                         locks[:-1] if r == 1 else locks, comm=group.comm(r))
+            out[r] = "ok"
+        except BaseException as e:  # noqa: BLE001
+            out[r] = repr(e)
+
+    th = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(G)]
+    [t.start() for t in th]
+    [t.join(timeout=60) for t in th]
+    assert all(not t.is_alive() for t in th), f"ranks still waiting: {out}"
+    assert "TS_ERR_INVALID" in out[1]
+    assert all(o != "ok" for o in out), out

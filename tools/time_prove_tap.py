@@ -32,3 +32,34 @@ top = sorted(kt.items(), key=lambda kv: -kv[1][1])[:4]
 print(json.dumps({"workload": f"Fibonacci 2^{log_n}x2, log_blowup {b}, {Q} queries, TapTreeMmcs", "prove_ms": round(dt * 1e3, 2),
                   "verdict": ok, "proof_words": int(len(proof)), "lock_table_MB": round(sum(map(len, locks)) / 1e6, 2),
                   "top_kernels_ms": {k: round(v[1], 2) for k, v in top}}))
+
+# optional 4th argument G: the same proof with its trees split over G rank threads on this one GPU
+# (ts_prove_tap_sharded on the in-process communicator).  The ranks share the card, so wall time says
+# nothing; what the line shows is how the SHA-256 work -- a rank's leaf-kernel time -- divides.
+if len(sys.argv) >= 5:
+    import threading
+    from tapstark_amd.comm import LocalCommGroup
+    G = int(sys.argv[4])
+    group = LocalCommGroup(G)
+    res = [None] * G
+    host_trace = ts.DeviceMatrix.fibonacci(ctx, 0, 1, n).download()
+
+    def rank_main(r):
+        c = ts.Context(0)
+        conf = ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(b, Q, 8), c))
+        ca = ts.CompiledAir(c, ts.air_tape(air, 3))
+        for timed in (False, True):
+            c.set_kernel_timing(timed)
+            p = tt.prove_tap(conf, ca, ts.BfChallenger(), host_trace.copy(), pis, locks, comm=group.comm(r))
+        k = c.take_kernel_timings()
+        res[r] = (bool((p == proof).all()), round(k.get("k_tapleaf_template", (0, 0.0))[1], 2),
+                  round(sum(v[1] for v in k.values()), 2))
+
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(G)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    per = -(-Q // G)
+    print(json.dumps({"split_by_tree_over_ranks": G, "trees_per_rank": [max(0, min(Q, (r + 1) * per) - r * per) for r in range(G)],
+                      "proof_identical": [x[0] for x in res], "leaf_kernel_ms_per_rank": [x[1] for x in res],
+                      "all_kernels_ms_per_rank": [x[2] for x in res],
+                      "note": "G threads on ONE GPU: kernel times are inflated by sharing the card; the split is the point"}))

@@ -499,6 +499,31 @@ def main():
             "merkle_frac_of_alu_peak": round(compressions / b3_peak * 1e3 / b3_ms, 4) if b3_ms else None,
             "note": "peaks from ts_bench_alu (register-resident loops of the same butterfly / compression code, "
                     "no memory traffic); FRI-round leaf hashes fused into the fold kernel are not in merkle_kernels_ms"}
+        # ---- the ceiling that actually binds: VALU instruction issue.  A wave64 VALU instruction
+        # holds its SIMD for four cycles (tools/pmc_alu.sh: the register-resident loops issue exactly
+        # one per 4 cycles per SIMD at 2.30-2.34 GHz); the prover's kernels run at ~2.0 GHz
+        # (SQ_BUSY_CYCLES over their durations).  SQ_INSTS_VALU summed over one proof comes from a
+        # committed rocprofv3 --pmc pass (static, like roofline.traffic): tools/pmc_sq.sh.
+        valu_issue = None
+        try:
+            import hashlib
+            import re as _re
+            sqf = os.path.join(ROOT, "profiles", f"r02_{args.workload}_sq_counters.txt")
+            if os.path.exists(sqf) and args.log_n == (22 if args.workload == "config4" else 20):
+                m_ = _re.search(r"whole proof: SQ_INSTS_VALU ([0-9.e+]+)", open(sqf).read())
+                insts = float(m_.group(1))
+                simds, clock = 4 * ctx.num_cus if hasattr(ctx, "num_cus") else 1024, 2.0e9
+                floor_ms = insts * 4 / simds / clock * 1e3
+                valu_issue = {
+                    "wave_instructions_per_proof": insts, "simds": simds, "cycles_per_instruction": 4,
+                    "clock_hz_under_load": clock, "ms_per_proof_at_ceiling": round(floor_ms, 4),
+                    "frac_of_ceiling": round(floor_ms / res["ms_per_step"], 4),
+                    "source": {"file": os.path.relpath(sqf, ROOT),
+                               "sha256": hashlib.sha256(open(sqf, "rb").read()).hexdigest(),
+                               "note": "static: SQ_INSTS_VALU of an earlier rocprofv3 --pmc pass, not collected "
+                                       "in this run; clock = SQ_BUSY_CYCLES / kernel durations of the same pass"}}
+        except Exception:
+            valu_issue = None
         # ---- the rate a caller sees who hands over HOST traces (never `value`): pinned buffer,
         # asynchronous upload on each lane's stream, the upload of one lane overlapping the proofs of the others
         h2d = None
@@ -552,7 +577,7 @@ def main():
             "single_proof_latency_ms": round(single_latency, 4),
             "single_proof_latency_with_stage_timers_ms": stage_sum.get("prove"),
             "roofline": roofline, "roofline_stage": roofline_stage, "roofline_whole": roofline_whole,
-            "alu_ceiling": alu_ceiling, "h2d_inclusive": h2d,
+            "alu_ceiling": alu_ceiling, "valu_issue": valu_issue, "h2d_inclusive": h2d,
             "h2d_inclusive_ms_per_step": (h2d or {}).get("ms_per_step"), "cpu_baseline": cpu,
             "stages_ms": stage_sum,
             "shard_stages_ms_per_rank": shard_stages,

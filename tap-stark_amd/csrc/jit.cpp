@@ -61,11 +61,11 @@ __device__ __forceinline__ u32 umin32(u32 a, u32 b) { return a < b ? a : b; }
 __device__ __forceinline__ u32 add(u32 a, u32 b) { u32 s = a + b; return umin32(s, s - P); }
 __device__ __forceinline__ u32 sub(u32 a, u32 b) { u32 d = a - b; return umin32(d, d + P); }
 __device__ __forceinline__ u32 neg(u32 a) { return a ? P - a : 0u; }
+// additive form, as bb.hpp: m = -t p^-1 mod 2^32, (t + m p) / 2^32 < 2p  (mul_lo, mad_u64, sub, min)
 __device__ __forceinline__ u32 mont_reduce(u64 t) {
-    u32 m = (u32)t * 0x88000001u;
-    u32 u = __umulhi(m, P);
-    u32 r = (u32)(t >> 32) - u;
-    return umin32(r, r + P);
+    u32 m = (u32)t * 0x77ffffffu;
+    u32 r = (u32)((t + (u64)m * P) >> 32);
+    return umin32(r, r - P);
 }
 __device__ __forceinline__ u32 mont_mul(u32 a, u32 b) { return mont_reduce((u64)a * b); }
 __device__ __forceinline__ u32 to_mont(u32 a) { return mont_mul(a, 0x45dddde3u); }

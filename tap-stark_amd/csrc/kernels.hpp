@@ -140,9 +140,12 @@ void launch_reduce(Context& ctx, const ColMat& m, unsigned log_h, const uint32_t
 struct FusedReduceArgs {
     Ef z_mont[2];
     Ef off_t[2];   // alpha^0, alpha^w            (Montgomery)
-    Ef rys_t[2];   // reduced opened values       (canonical)
-    Ef off_c[MAX_QUOTIENT_CHUNKS];  // alpha^(2w + 4c)
-    Ef rys_c[MAX_QUOTIENT_CHUNKS];
+    // The chunk terms sum_c off_c (S_c - rys_c), off_c = alpha^(2w + 4c), are folded on the host:
+    // column k of chunk c is weighted with alpha^k off_c (chunk_w, device memory, Montgomery, 4 EF4
+    // per chunk) so that ONE dot product over all chunk columns gives sum_c off_c S_c, and every
+    // constant goes into k0 = off_t0 rys_t0 + sum_c off_c rys_c, k1 = off_t1 rys_t1 (canonical).
+    Ef k0, k1;
+    const uint32_t* chunk_w;
     const uint32_t* chunk[MAX_QUOTIENT_CHUNKS];
     uint64_t chunk_stride;
     uint32_t n_chunks;

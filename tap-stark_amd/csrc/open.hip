@@ -16,24 +16,6 @@ __device__ __forceinline__ uint32_t root_bitrev(const uint32_t* __restrict__ W, 
     return (r & 1) ? neg(w) : w;
 }
 
-// ---- lazy accumulation -------------------------------------------------------------------------
-// acc < 2^63 on entry of every pair of macs; each product is < p^2 < 2^61.82, so two of them keep
-// acc below 2^64.  fix(): if acc >= 2^63 subtract p*2^32 (< 2^62.91), which preserves acc mod p
-// and brings it back below 2^63.
-__device__ __forceinline__ uint64_t lazy_mac(uint64_t acc, uint32_t a, uint32_t b) {
-    return acc + (uint64_t)a * b;
-}
-// Invariant: acc < p*2^32 (2^62.91) after a fix; two products (each < p^2 < 2^61.82) later it is
-// still < 2p*2^32, so its high word is < 2p and one conditional subtraction of p (sub + min, two
-// VOP2 ops) restores the invariant without changing acc mod p.
-__device__ __forceinline__ uint64_t lazy_fix(uint64_t acc) {
-    uint32_t hi = (uint32_t)(acc >> 32);
-    hi = umin32(hi, hi - P);
-    return ((uint64_t)hi << 32) | (uint32_t)acc;
-}
-// final: acc < 2p*2^32 -> acc * 2^-32 mod p, canonical
-__device__ __forceinline__ uint32_t lazy_finish(uint64_t acc) { return mont_reduce(lazy_fix(acc)); }
-
 // ------------------------------------------------------------------ barycentric weights
 // out[p][t] = x_t / (z_p - x_t), x_t = 31 * omega_n^bitrev(t)   (Montgomery EF4)
 constexpr int BW_ROWS = 4;
@@ -226,10 +208,11 @@ void launch_bary_dots(Context& ctx, const ColMat& m, unsigned log_n, const Ef* w
 
 // ------------------------------------------------------------------ reduce (generic)
 // S(X) = sum_i alpha^i * p_i[X]  (dot_ext_powers, :375), canonical; alpha powers are wave-uniform
-__device__ __forceinline__ Ef row_dot_alpha(const uint32_t* __restrict__ m, uint64_t col_stride,
-                                            uint32_t width, uint64_t X,
-                                            const uint32_t* __restrict__ alpha_pows) {
-    uint64_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+// acc[0..3] += sum_i w_i * p_i[X] over `width` columns (lazy: acc stays below p*2^32 between calls)
+__device__ __forceinline__ void row_dot_acc(uint64_t (&acc)[4], const uint32_t* __restrict__ m,
+                                            uint64_t col_stride, uint32_t width, uint64_t X,
+                                            const uint32_t* __restrict__ weights) {
+    uint64_t a0 = acc[0], a1 = acc[1], a2 = acc[2], a3 = acc[3];
     // batches of 8 columns: the 8 loads are issued back to back (one load per iteration with a
     // wait behind it left the kernel latency-bound), then 32 MACs with a range fix every 2 columns
     constexpr int B = 8;
@@ -241,7 +224,7 @@ __device__ __forceinline__ Ef row_dot_alpha(const uint32_t* __restrict__ m, uint
         for (int k = 0; k < B; k++) v[k] = col[(uint64_t)(i + k) * col_stride];
 #pragma unroll
         for (int k = 0; k < B; k++) {
-            const uint32_t* ap = alpha_pows + 4 * (i + k);
+            const uint32_t* ap = weights + 4 * (i + k);
             a0 = lazy_mac(a0, v[k], ap[0]);
             a1 = lazy_mac(a1, v[k], ap[1]);
             a2 = lazy_mac(a2, v[k], ap[2]);
@@ -262,7 +245,7 @@ __device__ __forceinline__ Ef row_dot_alpha(const uint32_t* __restrict__ m, uint
 #pragma unroll
         for (int k = 0; k < B; k++) {
             if (i + k < width) {
-                const uint32_t* ap = alpha_pows + 4 * (i + k);
+                const uint32_t* ap = weights + 4 * (i + k);
                 a0 = lazy_mac(a0, v[k], ap[0]);
                 a1 = lazy_mac(a1, v[k], ap[1]);
                 a2 = lazy_mac(a2, v[k], ap[2]);
@@ -276,7 +259,15 @@ __device__ __forceinline__ Ef row_dot_alpha(const uint32_t* __restrict__ m, uint
             }
         }
     }
-    return Ef{{lazy_finish(a0), lazy_finish(a1), lazy_finish(a2), lazy_finish(a3)}};
+    acc[0] = a0; acc[1] = a1; acc[2] = a2; acc[3] = a3;
+}
+// S(X) = sum_i alpha^i * p_i[X]  (dot_ext_powers, :375), canonical; alpha powers are wave-uniform
+__device__ __forceinline__ Ef row_dot_alpha(const uint32_t* __restrict__ m, uint64_t col_stride,
+                                            uint32_t width, uint64_t X,
+                                            const uint32_t* __restrict__ alpha_pows) {
+    uint64_t acc[4] = {0, 0, 0, 0};
+    row_dot_acc(acc, m, col_stride, width, X, alpha_pows);
+    return Ef{{lazy_finish(acc[0]), lazy_finish(acc[1]), lazy_finish(acc[2]), lazy_finish(acc[3])}};
 }
 
 // 1/(x - z_p) for NP points with one shared base-field inversion (Montgomery)
@@ -342,6 +333,9 @@ void launch_reduce(Context& ctx, const ColMat& m, unsigned log_h, const uint32_t
 // ro[X] = inv(x - zeta)      * [ off_t0 (S_t - rys_t0) + sum_c off_c (S_c - rys_c) ]
 //       + inv(x - zeta omega) *   off_t1 (S_t - rys_t1)
 // where S_t is shared by the two trace openings (two_adic_pcs.rs:344-387 visits the trace twice).
+// Evaluated as  g0 = off_t0 S_t + D - k0,  g1 = off_t1 S_t - k1,  D = one dot product over every
+// chunk column with the folded weights alpha^k off_c (FusedReduceArgs): four EF4 products per row
+// instead of 5 + n_chunks -- this kernel, too, is bound by VALU issue, not by its 4 TB/s.
 __global__ void __launch_bounds__(256)
 k_reduce_fused(const uint32_t* __restrict__ trace, uint64_t trace_stride, uint32_t width,
                unsigned log_h, const uint32_t* __restrict__ W, uint32_t gen_mont,
@@ -352,12 +346,11 @@ k_reduce_fused(const uint32_t* __restrict__ trace, uint64_t trace_stride, uint32
     const uint32_t x = mont_mul(gen_mont, root_bitrev(W, log_h, a.row0 + X));
     Ef inv_d[2];
     inv_denoms<2>(x, a.z_mont, inv_d);
-    Ef g0 = ef_mul(ef_sub(St, a.rys_t[0]), a.off_t[0]);
-    for (uint32_t c = 0; c < a.n_chunks; c++) {
-        const Ef Sc = row_dot_alpha(a.chunk[c], a.chunk_stride, 4, X, alpha_pows);
-        g0 = ef_add(g0, ef_mul(ef_sub(Sc, a.rys_c[c]), a.off_c[c]));
-    }
-    const Ef g1 = ef_mul(ef_sub(St, a.rys_t[1]), a.off_t[1]);
+    uint64_t acc[4] = {0, 0, 0, 0};
+    for (uint32_t c = 0; c < a.n_chunks; c++) row_dot_acc(acc, a.chunk[c], a.chunk_stride, 4, X, a.chunk_w + 16 * c);
+    const Ef D{{lazy_finish(acc[0]), lazy_finish(acc[1]), lazy_finish(acc[2]), lazy_finish(acc[3])}};
+    const Ef g0 = ef_sub(ef_add(ef_mul(St, a.off_t[0]), D), a.k0);
+    const Ef g1 = ef_sub(ef_mul(St, a.off_t[1]), a.k1);
     const Ef r = ef_add(ef_mul(g0, inv_d[0]), ef_mul(g1, inv_d[1]));
     *reinterpret_cast<uint4*>(ro + X) = make_uint4(r.c[0], r.c[1], r.c[2], r.c[3]);
 }

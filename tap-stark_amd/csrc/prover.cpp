@@ -353,22 +353,32 @@ DevBuf<Ef> TwoAdicFriPcs::open_reduce_slab(const PcsData& trace_data, const PcsD
         a.z_mont[1] = pts_mont[1];
         uint64_t num_reduced = 0;
         a.off_t[0] = ef_pow(am, num_reduced);
-        a.rys_t[0] = reduced_ys(&opened_values[0], w);
+        a.k0 = ef_mul(reduced_ys(&opened_values[0], w), a.off_t[0]);  // canonical x Montgomery -> canonical
         num_reduced += w;
         a.off_t[1] = ef_pow(am, num_reduced);
-        a.rys_t[1] = reduced_ys(&opened_values[w], w);
+        a.k1 = ef_mul(reduced_ys(&opened_values[w], w), a.off_t[1]);
         num_reduced += w;
         a.n_chunks = qd;
         a.chunk_stride = N;
         a.row0 = slab.row0;
         a.rows = N;
+        std::vector<uint32_t> cw(16 * (size_t)qd);
         for (uint32_t c = 0; c < qd; c++) {
             TS_REQUIRE(quotient_data.ldes[c].col_stride == N, TS_ERR_INVALID, "open: chunk stride");
             a.chunk[c] = quotient_data.ldes[c].d;
-            a.off_c[c] = ef_pow(am, num_reduced);
-            a.rys_c[c] = reduced_ys(&opened_values[2 * w + 4 * c], 4);
+            const Ef off_c = ef_pow(am, num_reduced);
+            a.k0 = ef_add(a.k0, ef_mul(reduced_ys(&opened_values[2 * w + 4 * c], 4), off_c));
+            for (int k = 0; k < 4; k++) {  // alpha^k off_c: the weight of column k of chunk c
+                Ef ap;
+                memcpy(ap.c, &apow[4 * (size_t)k], 16);
+                const Ef wk = ef_mul(ap, off_c);
+                memcpy(&cw[16 * (size_t)c + 4 * k], wk.c, 16);
+            }
             num_reduced += 4;
         }
+        DevBuf<uint32_t> d_cw(&ctx_, cw.size());
+        h2d(ctx_, d_cw.p, cw.data(), cw.size() * 4);
+        a.chunk_w = d_cw.p;
         launch_reduce_fused(ctx_, tr, log_N, d_apow.p, a, ro.p);
     }
     return ro;

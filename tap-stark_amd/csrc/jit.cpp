@@ -69,10 +69,11 @@ __device__ __forceinline__ u32 mont_reduce(u64 t) {
 }
 __device__ __forceinline__ u32 mont_mul(u32 a, u32 b) { return mont_reduce((u64)a * b); }
 __device__ __forceinline__ u32 to_mont(u32 a) { return mont_mul(a, 0x45dddde3u); }
-__device__ __forceinline__ u64 lazy_fix(u64 acc) {
-    u32 hi = (u32)(acc >> 32);
-    hi = umin32(hi, hi - P);
-    return ((u64)hi << 32) | (u32)acc;
+typedef u32 v2u __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u64 lazy_fix(u64 acc) {  // high word corrected in place (bb.hpp lazy_fix)
+    v2u u = __builtin_bit_cast(v2u, acc);
+    u.y = umin32(u.y, u.y - P);
+    return __builtin_bit_cast(u64, u);
 }
 __device__ __forceinline__ u32 lazy_finish(u64 acc) { return mont_reduce(lazy_fix(acc)); }
 struct QC { u32 inv_zh[64]; };  // = QuotConsts

@@ -117,7 +117,7 @@ __device__ __forceinline__ void radix_round(uint32_t* s, unsigned log_total, uns
 
 // Last forward round of a strided tile: groups read from the LDS, results written straight to the
 // tile's positions in HBM (element e of the tile lives at o[((e >> log_T) << row_shift) + (e & mask)]),
-// in canonical form.  A group's elements are 2^LOG_DL >= 2^log_T apart... and consecutive lanes hold
+// (values stay in [0, 2p): the contiguous forward pass follows).  A group's elements are 2^LOG_DL >= 2^log_T apart... and consecutive lanes hold
 // consecutive `lo`, so every store instruction writes whole 2^log_T-word row pieces, exactly like the
 // copy loop it replaces; no barrier is needed after it.
 template <int K, int LOG_DL, int NTH>
@@ -139,7 +139,7 @@ __device__ __forceinline__ void radix_round_fwd_to_global(const uint32_t* s, uns
 #pragma unroll
         for (int q = 0; q < R; q++) {
             const uint32_t e = base + ((uint32_t)q << LOG_DL);
-            o[((uint64_t)(e >> log_T) << row_shift) + (e & tmask)] = red2p(v[q]);
+            o[((uint64_t)(e >> log_T) << row_shift) + (e & tmask)] = v[q];  // lazy: k_lde_fwd_contig reads it next
         }
     }
 }
@@ -201,14 +201,21 @@ __device__ __forceinline__ void chunk_load(uint32_t* s, const uint32_t* __restri
     }
     __syncthreads();
 }
+// The butterflies leave values in [0, 2p).  CANON: canonical form on the way to HBM (the LDE itself).
+// Between the passes of one transform the next pass reduces its inputs anyway (red2p on `a`, a
+// product with b < 2p is still < p 2^32), so intermediate images stay lazy: 2 VALU instructions per
+// element less, in kernels that are bound by VALU issue.
+template <bool CANON>
 __device__ __forceinline__ void chunk_store(const uint32_t* s, uint32_t* __restrict__ g) {
     uint4* g4 = reinterpret_cast<uint4*>(g);
 #pragma unroll
     for (int k = 0; k < CHUNK / 4 / NT; k++) {
         const uint32_t i4 = threadIdx.x + (uint32_t)k * NT;
         const uint32_t a = 4 * i4 + (i4 >> 2);
-        // the butterflies leave values in [0, 2p): canonical form on the way to HBM
-        g4[i4] = make_uint4(red2p(s[a]), red2p(s[a + 1]), red2p(s[a + 2]), red2p(s[a + 3]));
+        if (CANON)
+            g4[i4] = make_uint4(red2p(s[a]), red2p(s[a + 1]), red2p(s[a + 2]), red2p(s[a + 3]));
+        else
+            g4[i4] = make_uint4(s[a], s[a + 1], s[a + 2], s[a + 3]);
     }
 }
 
@@ -224,7 +231,7 @@ k_intt_contig(uint32_t* __restrict__ data, uint64_t col_stride, unsigned log_n,
     radix_round<4, true, 0, NT>(s, LOG_M, 8, sb, c, Winv);
     radix_round<4, true, 4, NT>(s, LOG_M, 4, sb, c, Winv);
     radix_round<4, true, 8, NT>(s, LOG_M, 0, sb, c, Winv);
-    chunk_store(s, g);
+    chunk_store<false>(s, g);  // read next by k_lde_mid's inverse rounds
 }
 
 // in place on chunk `c` of coset block `beta` of column blockIdx.y: forward stages sA .. log_n-1
@@ -241,7 +248,7 @@ k_lde_fwd_contig(uint32_t* __restrict__ out, uint64_t out_col_stride, unsigned l
     radix_round<4, false, 8, NT>(s, LOG_M, 0, sb, c, W);
     radix_round<4, false, 4, NT>(s, LOG_M, 4, sb, c, W);
     radix_round<4, false, 0, NT>(s, LOG_M, 8, sb, c, W);
-    chunk_store(s, o);
+    chunk_store<true>(s, o);
 }
 
 // ------------------------------------------------------------------ middle kernel
@@ -371,8 +378,8 @@ k_lde_mid(const uint32_t* __restrict__ evals, uint64_t in_col_stride, uint32_t* 
                 // VGPRs here -- 137, one workgroup per CU instead of two -- and measured 0.85 ms
                 // against 0.64; forced back to 128 VGPRs it spills)
                 radix_round<4, false, 5, NTM>(s, 13, 4, 0, 0, W);
-                for (uint32_t i = threadIdx.x; i < total; i += NTM)
-                    og[((uint64_t)(i >> 5) << LOG_M) + (i & 31)] = red2p(s[pad(i)]);
+                for (uint32_t i = threadIdx.x; i < total; i += NTM)  // lazy: k_lde_fwd_contig reads it next
+                    og[((uint64_t)(i >> 5) << LOG_M) + (i & 31)] = s[pad(i)];
             } else {
                 radix_round<3, false, LOG_TILE - 7, NTM>(s, LOG_TILE, 4, 0, 0, W);
                 radix_round_fwd_to_global<3, LOG_TILE - 10, NTM>(s, LOG_TILE, 7, W, og, LOG_TILE - 10, LOG_M);
@@ -392,8 +399,13 @@ k_lde_mid(const uint32_t* __restrict__ evals, uint64_t in_col_stride, uint32_t* 
             tile_forward_rt<NTM>(s, log_len, log_T, 0, 0, W);
         }
         uint32_t* o = out + (uint64_t)col_id * out_col_stride + ((uint64_t)bl << log_n) + j2_0;
-        for (uint32_t i = threadIdx.x; i < total; i += NTM)
-            o[((uint64_t)(i >> log_T) << row_shift) + (i & tmask)] = red2p(s[pad(i)]);
+        if (row_shift != 0) {  // n > 4096: k_lde_fwd_contig follows and takes lazy values
+            for (uint32_t i = threadIdx.x; i < total; i += NTM)
+                o[((uint64_t)(i >> log_T) << row_shift) + (i & tmask)] = s[pad(i)];
+        } else {  // the whole transform was done here: canonical output
+            for (uint32_t i = threadIdx.x; i < total; i += NTM)
+                o[((uint64_t)(i >> log_T) << row_shift) + (i & tmask)] = red2p(s[pad(i)]);
+        }
     }
 }
 

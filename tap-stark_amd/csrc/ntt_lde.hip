@@ -44,7 +44,10 @@ __device__ __forceinline__ void radix_butterflies(uint32_t (&v)[1 << K], unsigne
 #pragma unroll
         for (int d = 0; d < K; d++) {
             const int half = R >> (d + 1);
-            const uint32_t wb = (1u << (s_base + u0 + d)) + (c << (u0 + d)) + (hi << d);
+            // ONE address per stage: the 2^d twiddles of this group are consecutive words, read at
+            // immediate offsets from wp (indexing W[wb + j] made the compiler rebuild a 64-bit
+            // address for every j: ~3 VALU instructions per twiddle, 8 % of a contiguous pass)
+            const uint32_t* __restrict__ wp = W + ((1u << (s_base + u0 + d)) + (c << (u0 + d)) + (hi << d));
 #pragma unroll
             for (int q = 0; q < R; q++) {
                 if ((q & half) == 0) {
@@ -53,7 +56,7 @@ __device__ __forceinline__ void radix_butterflies(uint32_t (&v)[1 << K], unsigne
                     const uint32_t a = red2p(v[q]);
                     uint32_t t = v[q + half];
                     if (TOP && (q >> (K - d)) == 0) t = red2p(t);
-                    else t = mont_mul(t, W[wb + (q >> (K - d))]);
+                    else t = mont_mul(t, wp[q >> (K - d)]);
                     v[q] = a + t;
                     v[q + half] = a - t + P;
                 }
@@ -63,7 +66,7 @@ __device__ __forceinline__ void radix_butterflies(uint32_t (&v)[1 << K], unsigne
 #pragma unroll
         for (int d = K - 1; d >= 0; d--) {
             const int half = R >> (d + 1);
-            const uint32_t wb = (1u << (s_base + u0 + d)) + (c << (u0 + d)) + (hi << d);
+            const uint32_t* __restrict__ wp = W + ((1u << (s_base + u0 + d)) + (c << (u0 + d)) + (hi << d));
 #pragma unroll
             for (int q = 0; q < R; q++) {
                 if ((q & half) == 0) {
@@ -71,7 +74,7 @@ __device__ __forceinline__ void radix_butterflies(uint32_t (&v)[1 << K], unsigne
                     const uint32_t a = red2p(v[q]), b = red2p(v[q + half]);
                     v[q] = a + b;
                     uint32_t dlt = a - b + P;
-                    if (!(TOP && (q >> (K - d)) == 0)) dlt = mont_mul_lazy(dlt, W[wb + (q >> (K - d))]);
+                    if (!(TOP && (q >> (K - d)) == 0)) dlt = mont_mul_lazy(dlt, wp[q >> (K - d)]);
                     v[q + half] = dlt;
                 }
             }
@@ -312,8 +315,21 @@ k_lde_mid(const uint32_t* __restrict__ evals, uint64_t in_col_stride, uint32_t* 
     const uint32_t* g = evals + (uint64_t)col_id * in_col_stride + j2_0;
     const uint32_t total = 1u << (log_len + log_T);
     const uint32_t tmask = (1u << log_T) - 1;
-    for (uint32_t i = threadIdx.x; i < total; i += NTM)
-        s[pad(i)] = g[((uint64_t)(i >> log_T) << row_shift) + (i & tmask)];
+    if constexpr (PLAN == 1 || PLAN == 2) {
+        // fixed shape: PER_THREAD loads issued back to back (the generic loop below is a run-time
+        // loop whose iterations the compiler keeps in order: load, wait, LDS store)
+        uint32_t t[PER_THREAD];
+#pragma unroll
+        for (int k = 0; k < PER_THREAD; k++) {
+            const uint32_t i = threadIdx.x + (uint32_t)k * NTM;
+            t[k] = g[((uint64_t)(i >> log_T) << row_shift) + (i & tmask)];
+        }
+#pragma unroll
+        for (int k = 0; k < PER_THREAD; k++) s[pad(threadIdx.x + (uint32_t)k * NTM)] = t[k];
+    } else {
+        for (uint32_t i = threadIdx.x; i < total; i += NTM)
+            s[pad(i)] = g[((uint64_t)(i >> log_T) << row_shift) + (i & tmask)];
+    }
     __syncthreads();
     if (PLAN == 1) {
         radix_round<4, true, 5, NTM>(s, 13, 4, 0, 0, Winv);
@@ -378,8 +394,15 @@ k_lde_mid(const uint32_t* __restrict__ evals, uint64_t in_col_stride, uint32_t* 
                 // VGPRs here -- 137, one workgroup per CU instead of two -- and measured 0.85 ms
                 // against 0.64; forced back to 128 VGPRs it spills)
                 radix_round<4, false, 5, NTM>(s, 13, 4, 0, 0, W);
-                for (uint32_t i = threadIdx.x; i < total; i += NTM)  // lazy: k_lde_fwd_contig reads it next
-                    og[((uint64_t)(i >> 5) << LOG_M) + (i & 31)] = s[pad(i)];
+                // lazy values: k_lde_fwd_contig reads them next.  Unrolled: 16 LDS reads in flight, then
+                // 16 stores whose addresses differ by constants (as a run-time loop each iteration
+                // cost 7 VALU instructions and waited for its own LDS read)
+                uint32_t t[PER_THREAD];
+#pragma unroll
+                for (int k = 0; k < PER_THREAD; k++) t[k] = s[pad(threadIdx.x + (uint32_t)k * NTM)];
+                uint32_t* ot = og + ((uint64_t)(threadIdx.x >> 5) << LOG_M) + (threadIdx.x & 31);
+#pragma unroll
+                for (int k = 0; k < PER_THREAD; k++) ot[(uint64_t)k * (NTM >> 5) << LOG_M] = t[k];
             } else {
                 radix_round<3, false, LOG_TILE - 7, NTM>(s, LOG_TILE, 4, 0, 0, W);
                 radix_round_fwd_to_global<3, LOG_TILE - 10, NTM>(s, LOG_TILE, 7, W, og, LOG_TILE - 10, LOG_M);

@@ -141,6 +141,30 @@ __global__ void k_transpose_bitrev(const uint32_t* __restrict__ src, uint32_t* _
     const uint32_t p0 = blockIdx.x << tr;
     const uint32_t c0 = blockIdx.y * 64;
     const uint32_t tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    if (rows == 64 && c0 + 64 <= w) {
+        // full tile: 16 loads in flight, then 16 LDS writes; as run-time loops every iteration waited
+        // for its own load.  bitrev(p0 + i) for i < 64 = bitrev(p0) + (bitrev6(i) << (log_n - 6))
+        // (p0 is a multiple of 64: its six low bits are free), so the source rows of a thread are a
+        // base plus constants.
+        const uint32_t rb = bitrev32(p0, log_n);
+        const uint32_t* sp = src + (uint64_t)rb * src_width + c0 + tx;
+        const uint64_t row_step = (uint64_t)src_width << (log_n - 6);
+        uint32_t t[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const uint32_t i = ty + 4 * (uint32_t)k;  // tile row
+            t[k] = sp[(uint64_t)(__brev(i) >> 26) * row_step];
+        }
+#pragma unroll
+        for (int k = 0; k < 16; k++) tile[ty + 4 * k][tx] = t[k];
+        __syncthreads();
+        uint32_t* dp = dst + (uint64_t)(c0 + ty) * dst_col_stride + p0 + tx;
+#pragma unroll
+        for (int k = 0; k < 16; k++) t[k] = tile[tx][ty + 4 * k];
+#pragma unroll
+        for (int k = 0; k < 16; k++) dp[(uint64_t)(4 * k) * dst_col_stride] = t[k];
+        return;
+    }
     for (uint32_t i = ty; i < rows; i += 4) {
         uint32_t r = bitrev32(p0 + i, log_n);
         uint32_t c = c0 + tx;

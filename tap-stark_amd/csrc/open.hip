@@ -347,7 +347,25 @@ k_reduce_fused(const uint32_t* __restrict__ trace, uint64_t trace_stride, uint32
     Ef inv_d[2];
     inv_denoms<2>(x, a.z_mont, inv_d);
     uint64_t acc[4] = {0, 0, 0, 0};
-    for (uint32_t c = 0; c < a.n_chunks; c++) row_dot_acc(acc, a.chunk[c], a.chunk_stride, 4, X, a.chunk_w + 16 * c);
+    uint32_t c = 0;
+    for (; c + 2 <= a.n_chunks; c += 2) {
+        // two width-4 chunks = one full batch of eight columns (their weights are consecutive): eight
+        // loads in flight, 32 multiply-adds, 16 range fixes -- as two 4-column tails it cost twice that
+        uint32_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = a.chunk[c + (k >> 2)][(uint64_t)(k & 3) * a.chunk_stride + X];
+        const uint32_t* ap = a.chunk_w + 16 * c;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[j] = lazy_mac(acc[j], v[k], ap[4 * k + j]);
+            if (k & 1) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[j] = lazy_fix(acc[j]);
+            }
+        }
+    }
+    for (; c < a.n_chunks; c++) row_dot_acc(acc, a.chunk[c], a.chunk_stride, 4, X, a.chunk_w + 16 * c);
     const Ef D{{lazy_finish(acc[0]), lazy_finish(acc[1]), lazy_finish(acc[2]), lazy_finish(acc[3])}};
     const Ef g0 = ef_sub(ef_add(ef_mul(St, a.off_t[0]), D), a.k0);
     const Ef g1 = ef_sub(ef_mul(St, a.off_t[1]), a.k1);

@@ -154,6 +154,12 @@ bool jit_compile_quotient(const AirProgram& air, const char* arch, JitKernel& ou
         return false;
     }
     const std::string src = jit_quotient_source(air);
+    if (const char* dump = getenv("TS_JIT_DUMP")) {  // the generated source, for offline inspection (hipcc -S)
+        if (FILE* f = fopen(dump, "w")) {
+            fwrite(src.data(), 1, src.size(), f);
+            fclose(f);
+        }
+    }
     rtcProgram prog = nullptr;
     if (r.create(&prog, src.c_str(), "quotient_jit.hip", 0, nullptr, nullptr) != 0) {
         log = "hiprtcCreateProgram failed";

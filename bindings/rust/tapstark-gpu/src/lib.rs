@@ -30,4 +30,4 @@ pub use context::{DeviceMatrix, GpuChallenger, GpuContext};
 pub use pcs::{FriConfig, GpuFriPcs, GpuPcsError, GpuProverData};
 pub use proof::Proof;
 pub use prove::{prove_gpu, prove_gpu_stepwise, CompiledAir};
-pub use tap::{prove_gpu_tap, verify_gpu_tap, LockTable};
+pub use tap::{prove_gpu_tap, verify_gpu_tap, GpuTapProof, GpuTapProverData, GpuTapTreeMmcs, LockTable};

@@ -132,3 +132,124 @@ where
     );
     verdict
 }
+
+// ------------------------------------------------------------------ BFMmcs surface of TapTreeMmcs
+/// `TapTreeMmcs<Val>` (basic/src/mmcs/taptree_mmcs.rs:24-119) with the trees built on the device:
+/// `commit` / `open_batch` / `verify_batch` with the trait's argument meaning.  `Commitment` is the
+/// reference's `Vec<TreeRoot>` (num_queries roots, each `[[u8; 4]; 8]`), `Proof` here is the sibling
+/// path plus the opened leaf's script (`CommitedProof.leaf`, tcs/mod.rs:103-108) as bytes: turning
+/// those into the reference's `CommitedProof<BO, B>` (which also carries the bit-commitment
+/// operators) is the caller's, since `BO` / `B` live in the un-vendored crates.
+pub struct GpuTapTreeMmcs<'c> {
+    pub ctx: &'c crate::context::GpuContext,
+    pub num_queries: usize,
+    /// lock scripts of ONE commitment in tree order: num_queries x (1 + n_evals) scripts
+    pub locks: LockTable,
+}
+pub struct GpuTapProverData<'c> {
+    ctx: &'c crate::context::GpuContext,
+    raw: *mut ts_tap_mmcs_data,
+    widths: Vec<usize>,
+    log_max_height: usize,
+}
+impl Drop for GpuTapProverData<'_> {
+    fn drop(&mut self) {
+        let _ = self.ctx;
+        unsafe { ts_tap_mmcs_free(self.raw) }
+    }
+}
+pub struct GpuTapProof {
+    pub path: Vec<[u8; 32]>,
+    pub leaf_script: Vec<u8>,
+}
+
+impl<'c> GpuTapTreeMmcs<'c> {
+    /// `BFMmcs::commit` (taptree_mmcs.rs:101-114): base-field matrices (U32_SIZE = 1)
+    pub fn commit(&self, inputs: Vec<RowMajorMatrix<Val>>) -> (Vec<[[u8; 4]; 8]>, GpuTapProverData<'c>) {
+        let widths: Vec<usize> = inputs.iter().map(|m| m.width()).collect();
+        let log_max_height = inputs.iter().map(|m| m.height()).max().unwrap().trailing_zeros() as usize;
+        let mats: Vec<*mut ts_matrix> = inputs
+            .iter()
+            .map(|m| {
+                let words: Vec<u32> = m.values.iter().map(|v| v.as_canonical_u32()).collect();
+                DeviceMatrix::upload(self.ctx, &words, m.height(), m.width()).into_raw()
+            })
+            .collect();
+        let mut roots = vec![0u8; 32 * self.num_queries];
+        let mut raw = ptr::null_mut();
+        self.ctx.check(
+            unsafe {
+                ts_tap_mmcs_commit(self.ctx.raw, mats.len() as u32, mats.as_ptr(), 1, self.num_queries as u32,
+                                   self.locks.bytes.as_ptr(), self.locks.offsets.as_ptr(), roots.as_mut_ptr(),
+                                   &mut raw)
+            },
+            "ts_tap_mmcs_commit",
+        );
+        for m in mats {
+            unsafe { ts_matrix_free(self.ctx.raw, m) };
+        }
+        // TreeRoot = u256_to_u32(root bytes) (chan_field.rs:87-95): 8 groups of 4 bytes
+        let commitment = roots
+            .chunks(32)
+            .map(|r| {
+                let mut t = [[0u8; 4]; 8];
+                for k in 0..8 {
+                    t[k].copy_from_slice(&r[4 * k..4 * k + 4]);
+                }
+                t
+            })
+            .collect();
+        (commitment, GpuTapProverData { ctx: self.ctx, raw, widths, log_max_height })
+    }
+
+    /// `BFMmcs::open_batch` (taptree_mmcs.rs:46-75)
+    pub fn open_batch(&self, query_times_index: usize, query_index: usize, data: &GpuTapProverData<'c>)
+                      -> (Vec<Vec<Val>>, GpuTapProof) {
+        use p3_field::AbstractField;
+        let total: usize = data.widths.iter().sum();
+        let mut rows = vec![0u32; total];
+        let mut path = vec![0u8; 32 * data.log_max_height];
+        let mut script = vec![0u8; 1 << 20];
+        let mut script_len = 0usize;
+        self.ctx.check(
+            unsafe {
+                ts_tap_mmcs_open_batch(data.raw, query_times_index as u32, query_index as u64, rows.as_mut_ptr(),
+                                       path.as_mut_ptr(), script.as_mut_ptr(), script.len(), &mut script_len)
+            },
+            "ts_tap_mmcs_open_batch",
+        );
+        script.truncate(script_len);
+        let mut at = 0;
+        let opened = data
+            .widths
+            .iter()
+            .map(|&w| {
+                let r = rows[at..at + w].iter().map(|&v| Val::from_canonical_u32(v)).collect();
+                at += w;
+                r
+            })
+            .collect();
+        let path = path.chunks(32).map(|c| c.try_into().unwrap()).collect();
+        (opened, GpuTapProof { path, leaf_script: script })
+    }
+
+    /// `BFMmcs::verify_batch` (taptree_mmcs.rs:77-99), host only: the leaf is rebuilt from the tree's
+    /// lock scripts, `query_index` and the opened values, and checked against root `query_times_index`
+    pub fn verify_batch(&self, query_times_index: usize, query_index: usize, opened_values: &Vec<Vec<Val>>,
+                        proof: &GpuTapProof, roots: &Vec<[[u8; 4]; 8]>) -> Result<(), ()> {
+        let vals: Vec<u32> = opened_values.iter().flatten().map(|v| v.as_canonical_u32()).collect();
+        let n_evals = vals.len();
+        let first = query_times_index * (1 + n_evals);
+        let base = self.locks.offsets[first];
+        let offs: Vec<u64> = self.locks.offsets[first..first + n_evals + 2].iter().map(|o| o - base).collect();
+        let root: Vec<u8> = roots[query_times_index].iter().flatten().copied().collect();
+        let path: Vec<u8> = proof.path.iter().flatten().copied().collect();
+        let mut ok = 0;
+        let rc = unsafe {
+            ts_tap_mmcs_verify_batch(self.locks.bytes.as_ptr().add(base as usize), offs.as_ptr(), n_evals as u32, 1,
+                                     query_index as u64, vals.as_ptr(), path.as_ptr(), proof.path.len() as u32,
+                                     root.as_ptr(), &mut ok)
+        };
+        if rc == TS_OK && ok == 1 { Ok(()) } else { Err(()) }
+    }
+}

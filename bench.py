@@ -6,12 +6,19 @@
 One "step" = one complete prove() (commit trace -> quotient -> commit chunks -> open -> FRI ->
 queries -> proof on the host) of BASELINE.json configs[2]: the build-defined SynthMulAir-64 trace,
 2^20 rows x 64 columns, log_blowup 2, 28 queries, 8 PoW bits, with the trace already resident in
-HBM when the timed region starts.  N > 1 (launched by torch.distributed.run, one rank per GPU):
-by default every rank proves its own independent traces (proofs are independent objects: no
-data-path collective, weak scaling, `value` is the aggregate over ranks).  `--mode sharded` instead
-splits ONE proof over the ranks (tap-stark_amd/csrc/sharded.cpp; needs N <= 2^log_blowup; RCCL
-all-gathers of the trace, the Merkle sub-roots and the FRI tail) -- strong scaling, the latency mode
-meant for BASELINE config 4 (`--workload config4`).
+HBM when the timed region starts.
+
+N > 1: one rank per GPU.  Launched by `python -m torch.distributed.run` (RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* in the environment) the process IS a rank; launched as a plain command with
+WORLD_SIZE unset it spawns its N ranks itself as fresh child processes -- before it makes any GPU
+call -- relays rank 0's JSON line and propagates a non-zero exit.  A WORLD_SIZE that differs from
+--gpus, or fewer visible devices than ranks, is an error, never a silent one-GPU run.
+By default every rank proves its own independent traces (proofs are independent objects: no
+data-path collective, weak scaling, `value` is the aggregate over ranks).  After that measurement
+every N > 1 run also proves BASELINE config 4 (2^22 x 64, log_blowup 4, 16 queries) as ONE proof
+sharded over the ranks (tap-stark_amd/csrc/sharded.cpp over the library's native RCCL communicator)
+and attaches it as `sharded_config4`.  `--mode sharded` makes the sharded proof the measured step
+itself (strong scaling, the latency mode; `--workload config4`).
 
 Prints ONE JSON line on rank 0 with the driver's contract fields plus:
   roofline     -- the dominant kernel's achieved algorithmic-bytes rate from HIP events recorded
@@ -25,21 +32,73 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-
 HBM_PEAK = 8.0e12  # B/s, /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
 
 
+# ------------------------------------------------------------------------------------------------
+# self-launch: `python bench.py --gpus N` as a plain command
+def spawn_ranks(n_ranks: int) -> int:
+    """Starts the N ranks as children of this (GPU-free) process and waits for them.  Rank 0's
+    stdout is relayed (its last line is the JSON record); any rank's failure ends the job non-zero.
+    Nothing here imports torch or touches the GPU: a process that has initialised the GPU must not
+    be replaced or re-executed (and is not: the ranks are fresh processes)."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks),
+                   LOCAL_WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+                   TS_BENCH_SELF_LAUNCHED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    out0 = []
+
+    def pump():
+        for line in procs[0].stdout:
+            out0.append(line)
+
+    t = threading.Thread(target=pump, daemon=True)
+    t.start()
+    rc = 0
+    alive = set(range(n_ranks))
+    while alive:
+        for r in list(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"bench.py: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr)
+                for q in alive:
+                    procs[q].terminate()
+        time.sleep(0.05)
+    t.join(timeout=10)
+    sys.stdout.buffer.write(b"".join(out0))
+    sys.stdout.flush()
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------
 def workload(name: str, log_n: int, need_host_trace: bool):
     """(air, host trace or None, public values, description, fri config, device-side generator).
     The traces are generated ON THE DEVICE (ts_trace_*): inputs are born in HBM; a host copy is only
     made when a mode needs to slice it."""
+    import numpy as np
+
     import tapstark_amd as ts
     from tapstark_amd.airs import (FibonacciAir, SynthMulAir, generate_fibonacci_trace,
                                    generate_synth_mul_trace)
@@ -98,6 +157,7 @@ def algorithmic_bytes_per_proof(n: int, w: int, b: int, qd: int) -> dict:
     return {
         "k_transpose_bitrev": 8 * n * w,
         "k_intt_contig": 8 * n * wall,
+        "k_intt_contig_rm": 8 * n * w,
         "k_lde_mid<1>": 4 * n * wall + 4 * N * wall,
         "k_lde_mid<0>": 4 * n * wall + 4 * N * wall,
         "k_lde_fwd_contig": 8 * N * wall,
@@ -133,9 +193,10 @@ def _omp_set_threads(n: int):
 def cpu_baseline(target_seconds: float = 20.0) -> dict:
     """The oracle prover (oracle/, a C port of the reference's algorithm: the Rust reference cannot
     be built here) on this box's host cores, on a bounded sample of the same workload: the median
-    of 5 runs after a warm-up with every core of the GPU's share, plus one
-    1-thread sample -- the reference as configured is single-threaded (no manifest enables
-    p3-maybe-rayon's `parallel`)."""
+    of 5 runs after a warm-up with every core of the GPU's share, ONE run at
+    the full 2^20 x 64 size BASELINE.json quotes, plus one 1-thread sample -- the reference as
+    configured is single-threaded (no manifest enables p3-maybe-rayon's `parallel`, SURVEY.md
+    section 2)."""
     import tapstark_amd as ts
     from oracle import oracle_py as orc
     from tapstark_amd.airs import SynthMulAir, generate_synth_mul_trace
@@ -167,6 +228,16 @@ def cpu_baseline(target_seconds: float = 20.0) -> dict:
     timed(trace)  # warm-up at size
     runs = sorted(timed(trace) for _ in range(5))
     dt = runs[2]
+    # the configuration BASELINE.json quotes, once, unscaled (skipped if the probe says > 25 s)
+    full = None
+    if log_n < 20 and dt * (1 << (20 - log_n)) <= 25.0:
+        dt_full = timed(generate_synth_mul_trace(1 << 20))
+        full = {"value": (64 << 20) / dt_full, "unit": "trace cells/sec", "cores": cores,
+                "sample": f"one run of the same prover at the full 2^20x64 size ({dt_full:.2f} s)",
+                "proofs_per_sec": 1.0 / dt_full}
+    elif log_n == 20:
+        full = {"value": (64 << 20) / dt, "unit": "trace cells/sec", "cores": cores,
+                "sample": "the median sample above is already the full 2^20x64 size", "proofs_per_sec": 1.0 / dt}
     # one thread, on a sample 1/8 the size (about the same wall time)
     log_n1 = max(log_n - 3, 10)
     trace1 = generate_synth_mul_trace(1 << log_n1)
@@ -179,29 +250,187 @@ def cpu_baseline(target_seconds: float = 20.0) -> dict:
                       f"{cores} host threads",
             "proofs_per_sec": 1.0 / dt,
             "runs_s": [round(r, 3) for r in runs],
+            "full_size": full,
             "one_thread": {"value": (64 << log_n1) / dt1, "unit": "trace cells/sec", "cores": 1,
                            "sample": f"the same prover on 2^{log_n1}x64, best of 2 ({dt1:.2f} s), 1 thread"}}
 
 
+# ------------------------------------------------------------------------------------------------
+class Watchdog:
+    """Bounds a block that contains collectives nobody has run on more than one rank yet: if it is
+    still running at the deadline, `on_timeout` runs on the watchdog thread (rank 0 prints the record
+    it has, every rank leaves with os._exit)."""
+
+    def __init__(self, seconds: float, on_timeout):
+        self._ev = threading.Event()
+        self.phase = "start"
+
+        def run():
+            if not self._ev.wait(seconds):
+                on_timeout(self.phase)
+
+        self._t = threading.Thread(target=run, daemon=True)
+        self._t.start()
+
+    def done(self):
+        self._ev.set()
+
+
+def sharded_config4_block(ts, env, ctx, dev, watchdog: Watchdog | None) -> dict:
+    """BASELINE config 4 (SynthMulAir-64, 2^22 x 64, log_blowup 4, 16 queries) as ONE proof sharded
+    over the ranks: ts_prove_sharded over the library's native RCCL communicator (torch.distributed
+    callbacks where the process group is not nccl: the gloo rehearsal).  Variants (A/B in one lease):
+    `replicated` (every rank generates the trace on its device), `colshard` (+ column-sharded
+    inverse), `sliced` (row slices in, adds the trace all-gather; TS_BENCH_SHARD_VARIANTS picks)."""
+    import numpy as np
+    import torch.distributed as dist
+
+    from tapstark_amd.airs import SynthMulAir
+
+    def phase(p):
+        if watchdog is not None:
+            watchdog.phase = p
+
+    log_n = int(os.environ.get("TS_BENCH_SHARD_LOG_N", "22"))
+    n, w, cfg = 1 << log_n, 64, (4, 16, 8)
+    steps = int(os.environ.get("TS_BENCH_SHARD_STEPS", "4"))
+    world = env.world
+    gsize = min(world, 1 << cfg[0])
+    while world % gsize or (gsize & (gsize - 1)):
+        gsize -= 1
+    n_groups = world // gsize
+    grank = env.rank % gsize
+    out = {"workload": f"SynthMulAir-64, trace 2^{log_n}x64, log_blowup=4, 16 queries, pow 8: ONE proof "
+                       f"sharded over {gsize} rank(s)" + (f", {n_groups} groups" if n_groups > 1 else ""),
+           "steps": steps, "group_size": gsize, "n_groups": n_groups}
+    phase("communicator")
+    group = None
+    if n_groups > 1:
+        for gi in range(n_groups):  # every rank takes part in creating every group
+            gr = dist.new_group(list(range(gi * gsize, (gi + 1) * gsize)))
+            if env.rank // gsize == gi:
+                group = gr
+    use_native = os.environ.get("TS_BENCH_COMM", "rccl") == "rccl" and dist.get_backend() == "nccl"
+    if use_native:
+        from tapstark_amd import comm as tcomm
+        ids = [None] * world
+        dist.all_gather_object(ids, tcomm.rccl_unique_id() if grank == 0 else None)
+        comm = tcomm.RcclComm(ctx, ids[(env.rank // gsize) * gsize], grank, gsize)
+        info = comm.info()
+        out["comm"] = "rccl (native ts_comm: ncclAllGather / ncclBroadcast on the context's stream)"
+        out["n_ranks_seen_by_rccl"] = info["comm_count"]
+        out["rccl_info_rank0"] = info
+    else:
+        from tapstark_amd.dist import TorchComm
+        comm = TorchComm(dev, group=group)
+        out["comm"] = f"torch.distributed ({comm.backend}; host-staged unless nccl)"
+        out["n_ranks_seen_by_rccl"] = None
+    config = ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(*cfg), ctx))
+    cair = ts.CompiledAir(ctx, ts.air_tape(SynthMulAir(64), 0))
+    pis = np.zeros(0, dtype=np.uint32)
+    variants = os.environ.get("TS_BENCH_SHARD_VARIANTS", "replicated,colshard").split(",")
+    out["variants"] = {}
+    for var in variants:
+        var = var.strip()
+        if var not in ("replicated", "colshard", "sliced"):
+            continue
+        phase(f"{var}: inputs")
+        sliced = var == "sliced"
+        kw = dict(trace_replicated=not sliced, column_sharded_inverse=(var == "colshard"))
+        if sliced:
+            full = ts.DeviceMatrix.synth_mul(ctx, n, w).download()
+            rows = np.ascontiguousarray(full[grank * n // gsize:(grank + 1) * n // gsize])
+            del full
+            mats = [ts.DeviceMatrix.upload(ctx, rows) for _ in range(steps + 2)]
+        else:
+            mats = [ts.DeviceMatrix.synth_mul(ctx, n, w) for _ in range(steps + 2)]
+
+        def prove_one(i):
+            return ts.prove_sharded(config, cair, ts.BfChallenger(), mats[i], pis, comm, **kw)
+
+        phase(f"{var}: warm-up proof")
+        first = prove_one(0)
+        ctx.synchronize()
+        dist.barrier()
+        phase(f"{var}: timed proofs")
+        t0 = time.perf_counter()
+        for i in range(1, steps + 1):
+            prove_one(i)
+        ctx.synchronize()
+        dist.barrier()
+        dt = env.max_over_ranks(time.perf_counter() - t0)
+        phase(f"{var}: stage timers")
+        ctx.set_timing(True)
+        prove_one(steps + 1)
+        mine = {}
+        for k, v in ctx.take_timings():
+            mine[k] = round(mine.get(k, 0.0) + v, 3)
+        ctx.set_timing(False)
+        stages = [None] * world
+        dist.all_gather_object(stages, mine)
+        # every rank must hold the same proof: compare a digest of the words
+        import hashlib
+        digs = [None] * world
+        dist.all_gather_object(digs, hashlib.sha256(first.words.tobytes()).hexdigest())
+        out["variants"][var] = {
+            "ms_per_step": round(1e3 * dt / steps, 4),
+            "proofs_per_sec": round(n_groups * steps / dt, 3),
+            "trace_cells_per_sec": n_groups * steps * float(n * w) / dt,
+            "all_ranks_same_proof": len(set(digs[(env.rank // gsize) * gsize:(env.rank // gsize + 1) * gsize])) == 1,
+            "proof_words": int(len(first.words)),
+            "shard_stages_ms_per_rank": stages}
+        del mats
+    if "replicated" in out["variants"]:
+        out["ms_per_step"] = out["variants"]["replicated"]["ms_per_step"]
+        out["shard_stages_ms_per_rank"] = out["variants"]["replicated"]["shard_stages_ms_per_rank"]
+    phase("done")
+    if use_native:
+        comm.close()
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # 48 steps = 12 per lane: the lanes start in lockstep and only drift into complementary phases
-    # after a few proofs (K = 12: 3.3-3.4 ms/step, K = 40: 3.0)
-    ap.add_argument("--steps", type=int, default=48)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5,
+                    help="untimed proofs before the timed region, dealt to the lanes in turn; at least one "
+                         "per lane is always run (tables, device pools and code objects are per context)")
     ap.add_argument("--workload", default="config3", choices=["config3", "config2", "config4", "config5"])
     ap.add_argument("--log-n", type=int, default=None, help="default 20 (22 for config4)")
     ap.add_argument("--mode", default="replicas", choices=["replicas", "sharded"],
                     help="N > 1: independent proofs per GPU (default) or one proof over all GPUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="skip the roofline / latency / h2d / cpu legs (parameter sweeps)")
+    ap.add_argument("--no-sharded-block", action="store_true",
+                    help="N > 1: do not append the sharded config-4 measurement")
     ap.add_argument("--host-traces", action="store_true",
                     help="hand every step its trace as a HOST buffer (ts_matrix_upload inside the "
                          "timed region): the PCIe-inclusive rate, reported in DESIGN.md, never `value`")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("TS_BENCH_STREAMS", "4")),
                     help="independent proofs in flight per GPU (one context = one HIP stream and one "
                          "host thread each); the K timed steps are shared among them")
+    ap.add_argument("--stagger-ms", type=float, default=float(os.environ.get("TS_BENCH_STAGGER_MS", "-1")),
+                    help="lane l enters the timed region l * this many ms after lane 0, so that the lanes "
+                         "run in complementary phases from the first proof on instead of drifting there "
+                         "(-1 = auto: a quarter of one lane's proof period / number of lanes)")
+    ap.add_argument("--windows", type=int, default=3,
+                    help="timed windows of K steps each, back to back; `value` is the FIRST (the contract's "
+                         "K steps), the others are reported as spread")
     args = ap.parse_args()
+
+    # ---- launch protocol (before anything imports torch or touches the GPU)
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if env_world is None and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))
+    if env_world is not None and int(env_world) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={env_world}: refusing to run "
+                         "(launch N ranks, or run `python bench.py --gpus N` as a plain command)")
+
     # Native libraries print to stdout on their own (RCCL's version banner at communicator creation):
     # everything but the one JSON line goes to stderr, the line itself to the real stdout at the end.
     sys.stdout.flush()
@@ -210,12 +439,45 @@ def main():
     if args.log_n is None:
         args.log_n = 22 if args.workload == "config4" else 20
     sharded = args.mode == "sharded"
+    stub = bool(os.environ.get("TS_BENCH_STUB"))  # protocol tests on CPU: no prover, no GPU
+    share_gpu = bool(os.environ.get("TS_BENCH_SHARE_GPU"))
+    if share_gpu and "TS_BENCH_BACKEND" not in os.environ:
+        os.environ["TS_BENCH_BACKEND"] = "gloo"  # RCCL refuses two ranks on one device
 
     from tapstark_amd.benchutil import init_dist, run_timed
 
     env = init_dist()
-    if env.world != args.gpus and env.world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={env.world}")
+    assert env.world == args.gpus
+
+    def emit(record: dict):
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(record) + "\n").encode())
+
+    if stub:
+        if os.environ.get("TS_BENCH_STUB_FAIL_RANK") == str(env.rank):
+            raise SystemExit(f"rank {env.rank}: TS_BENCH_STUB_FAIL_RANK")
+        res = run_timed(env, lambda i: time.sleep(0.002), args.steps, args.warmup, lambda: None,
+                        units_per_step=1.0, extra_windows=max(args.windows - 1, 0))
+        rec = {"metric": "stub", "stub": True, "value": res["value"], "unit": "steps/sec", "n_gpus": env.world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
+               "windows_ms_per_step": res.get("windows_ms_per_step"),
+               "data": "stub (TS_BENCH_STUB: launch / timing protocol only, no prover, no GPU)",
+               "self_launched": bool(os.environ.get("TS_BENCH_SELF_LAUNCHED")),
+               "sharded_config4": {"skipped": "stub"} if env.world > 1 else None}
+        env.close()
+        if env.rank == 0:
+            emit(rec)
+        return
+
+    import numpy as np
+    import torch
+
+    if not share_gpu:
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", env.world))
+        have = torch.cuda.device_count()
+        if have < local_world or env.local_rank >= have:
+            raise SystemExit(f"bench.py: {local_world} rank(s) on this node but only {have} visible GPU(s) "
+                             "(TS_BENCH_SHARE_GPU=1 puts every rank on GPU 0 for a rehearsal)")
 
     import tapstark_amd as ts
     from tapstark_amd.build import build
@@ -226,7 +488,7 @@ def main():
         if env.dist is not None:
             env.dist.barrier()
     # one GPU per rank (TS_BENCH_SHARE_GPU=1 lets a rehearsal put every rank on GPU 0)
-    dev = 0 if os.environ.get("TS_BENCH_SHARE_GPU") else env.local_rank
+    dev = 0 if share_gpu else env.local_rank
     ctx = ts.Context(dev)  # raises without a GPU: there is no fallback path
 
     air, trace, pis, desc, cfg, (n, w), make_trace = workload(args.workload, args.log_n, False)
@@ -251,12 +513,17 @@ def main():
                       ts.CompiledAir(c2, ts.air_tape(air, len(pis)))))
 
     # inputs resident in HBM before the timed region (prove() consumes its trace, like the
-    # reference's moved RowMajorMatrix, so one copy per step); step i runs on lane i % S
-    total = args.warmup + args.steps
+    # reference's moved RowMajorMatrix, so one copy per step); step i runs on lane i % S.
+    # Warm-up: at least one proof per lane (W = 5 on 4 lanes: 2, 1, 1, 1).
+    warmup = max(args.warmup, S) if not sharded else args.warmup
+    n_windows = max(1, args.windows)
+    while n_windows > 1 and (warmup + n_windows * args.steps) * n * w * 4 > (100 << 30):
+        n_windows -= 1
+    total = warmup + n_windows * args.steps
     last = {}
+    gsize, n_groups, comm = 1, 1, None
     if sharded:
         # one proof per step over all ranks: rank g is handed natural rows [g n/G, (g+1) n/G)
-        import torch
         import torch.distributed as dist
         from tapstark_amd.dist import TorchComm
 
@@ -288,12 +555,13 @@ def main():
             ids = [None] * dist.get_world_size()
             dist.all_gather_object(ids, tcomm.rccl_unique_id() if grank == 0 else None)
             comm = tcomm.RcclComm(ctx, ids[(env.rank // gsize) * gsize], grank, gsize)
-            comm.backend = "rccl (native ts_comm)"
+            comm.backend = f"rccl (native ts_comm; ncclCommCount = {comm.info()['comm_count']})"
         else:
             comm = TorchComm(dev, group=group)
         # every rank generates the whole trace on its own device (ts_trace_*): nothing to exchange
         # for the input; TS_BENCH_SLICED=1 hands out row slices instead (adds the trace all-gather)
         sliced = bool(os.environ.get("TS_BENCH_SLICED"))
+        colshard = bool(os.environ.get("TS_BENCH_COLSHARD"))
         if sliced:
             full = make_trace(ctx).download()
             rows = np.ascontiguousarray(full[grank * n // gsize:(grank + 1) * n // gsize])
@@ -303,7 +571,7 @@ def main():
 
         def prove_one(i):
             last["proof"] = ts.prove_sharded(config, cair, ts.BfChallenger(), mats[i], pis, comm,
-                                             trace_replicated=not sliced)
+                                             trace_replicated=not sliced, column_sharded_inverse=colshard)
     else:
         # one resident trace per step (prove() consumes it); beyond 100 GB of them (288 GB of HBM) the
         # trace of a step is generated on the device at the start of the step instead, inside the
@@ -325,6 +593,7 @@ def main():
             if pregen:
                 mats[i] = None  # the matrix handle is spent
 
+    stagger = {"ms": 0.0}
     if S == 1:
         step = prove_one
         run_steps = None
@@ -334,8 +603,19 @@ def main():
         step = prove_one
 
         def run_steps(first, count):
-            # lane l proves steps first+l, first+l+S, ... in its own thread (ctypes drops the GIL)
+            # lane l proves steps first+l, first+l+S, ... in its own thread (ctypes drops the GIL).
+            # Staggered entry: with every lane starting at the same instant the S proofs run in
+            # lockstep -- all of them in their latency-bound phases (Merkle tops, FRI rounds) at the
+            # same time -- and only drift into complementary phases after a few proofs; entering
+            # lane l a little later puts the lanes there from the first proof on.  Lane 0 starts at
+            # once, and a proof alone fills the chip in its long kernels, so nothing idles meanwhile.
+            t_start = time.perf_counter()
+
             def lane_job(l):
+                delay = l * stagger["ms"] * 1e-3
+                if delay > 0 and first + l < first + count:
+                    while time.perf_counter() - t_start < delay:
+                        time.sleep(min(2e-4, max(0.0, delay - (time.perf_counter() - t_start))))
                 for i in range(first + l, first + count, S):
                     prove_one(i)
             list(pool.map(lane_job, range(S)))
@@ -344,29 +624,37 @@ def main():
         for c, _, _ in lanes:
             c.synchronize()
         if env.dist is not None and env.device is not None:
-            import torch
             torch.cuda.synchronize()
 
-    # Prime every lane with one untimed proof of its own (beyond the W warm-up steps, which only
-    # reach the first W lanes): a context builds its twiddle / scale / selector tables and grows its
-    # device pool on first use, and that must not fall into the timed region.
+    # Stagger: explicit, or auto = a quarter of the step time a single lane sustains (measured here
+    # on one untimed proof per lane, which also primes every lane's tables / pools / code objects)
+    single_ms = None
     if not sharded:
         prime = [make_trace(lanes[l][0]) for l in range(S)]
 
         def prime_lane(l):
             c, conf, ca = lanes[l]
             ts.prove(conf, ca, ts.BfChallenger(), prime[l], pis)
-        if S == 1:
-            prime_lane(0)
-        else:
-            list(pool.map(prime_lane, range(S)))
+        prime_lane(0)
+        ctx.synchronize()
+        m0 = make_trace(ctx)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        ts.prove(config, cair, ts.BfChallenger(), m0, pis)
+        single_ms = 1e3 * (time.perf_counter() - t0)
+        if S > 1:
+            list(pool.map(prime_lane, range(1, S)))
         del prime
+        if S > 1:
+            stagger["ms"] = args.stagger_ms if args.stagger_ms >= 0 else 0.25 * single_ms
 
     # sharded: the ranks of a group share each step's n*w cells
-    res = run_timed(env, step, args.steps, args.warmup, local_sync,
-                    units_per_step=float(n * w) / (gsize if sharded else 1), run_steps=run_steps)
+    res = run_timed(env, step, args.steps, warmup, local_sync,
+                    units_per_step=float(n * w) / (gsize if sharded else 1), run_steps=run_steps,
+                    extra_windows=n_windows - 1)
     shard_stages = None
     if sharded:
+        import torch.distributed as dist
         res["steps_per_sec"] = n_groups * args.steps / res["elapsed_s"]
         # one more proof with the stage timers on, on every rank: where a rank's time goes
         ctx.set_timing(True)
@@ -380,182 +668,12 @@ def main():
 
     out = None
     if env.rank == 0:
-        # ---- roofline leg: per-kernel HIP-event timings over 3 extra (untimed) proofs
-        reps = 3
-        extra = [make_trace(ctx) for _ in range(reps)]
-        ctx.set_kernel_timing(True)
-        for m in extra:
-            ts.prove(config, cair, ts.BfChallenger(), m, pis)
-        kt = ctx.take_kernel_timings()
-        ctx.set_kernel_timing(False)
-        ctx.set_timing(True)
-        ts.prove(config, cair, ts.BfChallenger(), make_trace(ctx), pis)
-        stages = ctx.take_timings()
-        ctx.set_timing(False)
-        # one proof alone on the GPU, no timers inside (the stage timers synchronise at every stage
-        # boundary): host wall clock around ts_prove, which returns with the proof on the host
-        lat = []
-        for _ in range(5):
-            m_ = make_trace(ctx)
-            ctx.synchronize()
-            t0 = time.perf_counter()
-            ts.prove(config, cair, ts.BfChallenger(), m_, pis)
-            lat.append(1e3 * (time.perf_counter() - t0))
-        single_latency = sorted(lat)[len(lat) // 2]
-        stage_sum = {}
-        for k, v in stages:  # a stage name can occur twice (trace commit, quotient commit)
-            stage_sum[k] = round(stage_sum.get(k, 0.0) + v, 3)
-        alg = algorithmic_bytes_per_proof(n, w, cfg[0], qd)
-
-        def alg_bytes(name):  # every instantiation of the strided NTT pass moves the same bytes
-            if "k_lde_mid" in name:
-                return alg["k_lde_mid<1>"]
-            if name == "k_merkle_level<1>" and "k_merkle_level<2>" not in kt:
-                return alg["k_merkle_level<1>"] + alg["k_merkle_level<2>"]
-            return alg.get(name)
-
-        per_kernel = {}
-        for name, (cnt, ms) in kt.items():
-            ms_pp = ms / reps
-            b = alg_bytes(name)
-            per_kernel[name] = {
-                "launches_per_proof": cnt / reps, "ms_per_proof": round(ms_pp, 4),
-                "avg_launch_ms": round(ms / cnt, 5),
-                "alg_gbps": round(b / (ms_pp * 1e-3) / 1e9, 1) if b and ms_pp > 0 else None}
-        dom = max(kt.items(), key=lambda kv: kv[1][1])[0]
-        dom_ms_pp = kt[dom][1] / reps
-        achieved = (alg_bytes(dom) or 0) / (dom_ms_pp * 1e-3)
-        # HBM traffic of that kernel from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE and
-        # --pmc WRITE_SIZE in separate passes, KiB units, FETCH_SIZE doubled for gfx950:
-        # profiles/*_pmc_traffic.json, made from tools/prof_prove.py); bytes per launch, or null
-        # NOT measured in this run (PMC collection needs rocprofv3 around the process): the file it
-        # comes from and that file's hash are reported beside it
-        traffic, traffic_source = None, None
-        try:
-            import glob
-            import hashlib
-            tag = {"config3": "", "config2": "config2_", "config4": "config4_"}.get(args.workload)
-            pmc_files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json"))
-                               if tag is not None and (("config" in os.path.basename(f)) == bool(tag))
-                               and (not tag or tag in os.path.basename(f)))
-            if pmc_files and args.log_n == (22 if args.workload == "config4" else 20):
-                ks = json.load(open(pmc_files[-1]))["kernels"]
-                stem = dom.strip("()").rstrip(">")  # "k_lde_mid<1" matches "k_lde_mid<1, 8192, 512>"
-                pk = ks.get(dom) or next((v for k, v in ks.items() if k.startswith(stem)), None)
-                if pk:
-                    traffic = round((pk["fetch_bytes_per_proof_corrected"] + pk["write_bytes_per_proof"])
-                                    / pk["launches_per_proof"])
-                    traffic_source = {
-                        "file": os.path.relpath(pmc_files[-1], ROOT),
-                        "sha256": hashlib.sha256(open(pmc_files[-1], "rb").read()).hexdigest(),
-                        "note": "static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run "
-                                "(tools/prof_prove.py), not collected in this run"}
-        except Exception:
-            traffic, traffic_source = None, None
-        lpp = kt[dom][0] / reps
-        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved / 1e9, 2),
-                    "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 4),
-                    "traffic": traffic, "traffic_source": traffic_source,
-                    "alg_bytes_per_launch": round((alg_bytes(dom) or 0) / lpp) if lpp else None,
-                    "avg_launch_ms": round(kt[dom][1] / kt[dom][0], 5),
-                    "launches_per_proof": kt[dom][0] / reps,
-                    "alg_bytes_per_proof": alg_bytes(dom),
-                    "kernel_ms_total_per_proof": round(sum(v[1] for v in kt.values()) / reps, 3)}
-        # ---- the stage and the whole job against the same roofline (SURVEY.md section 8(d) terms)
-        N_ = n << cfg[0]
-        wall_ = w + 4 * qd
-        A1 = 4 * n * w + 4 * N_ * w            # trace LDE: read n x w, write N x w
-        C1 = 16 * n * qd + 16 * N_ * qd        # chunk LDE
-        whole = (A1 + 32 * (2 * N_ - 1) + (4 * n * qd * w + 16 * n * qd) + C1 + 32 * (2 * N_ - 1)
-                 + (4 * N_ * w + 16 * N_ * qd + 16 * N_) + (32 * N_ + 16 * N_ + 64 * N_))
-        lde_ms = stage_sum.get("coset_lde")
-        roofline_stage = None
-        if lde_ms:
-            roofline_stage = {"stage": "coset_lde (trace + quotient chunks)", "alg_bytes": A1 + C1,
-                              "ms": lde_ms, "achieved": round((A1 + C1) / (lde_ms * 1e-3) / 1e9, 1),
-                              "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                              "frac": round((A1 + C1) / (lde_ms * 1e-3) / HBM_PEAK, 4),
-                              "note": "single proof alone on the GPU; the stage is three passes (60 n W bytes "
-                                      "moved for 20 n W algorithmic) and VALU-bound, see alu_ceiling"}
-        roofline_whole = {"alg_bytes_per_proof": whole, "ms_per_step": round(res["ms_per_step"], 4),
-                          "achieved": round(whole / (res["ms_per_step"] * 1e-3) / 1e9, 1), "peak": HBM_PEAK / 1e9,
-                          "unit": "GB/s", "frac": round(whole / (res["ms_per_step"] * 1e-3) / HBM_PEAK, 4)}
-        # ---- the integer-ALU ceiling, measured in this run with the library's own arithmetic
-        log_n_ = n.bit_length() - 1
-        butterflies = wall_ * (n // 2) * log_n_ * (1 + (1 << cfg[0]))
-        compressions = N_ * ((4 * w + 63) // 64) + N_ * ((16 * qd + 63) // 64) + N_ + 3 * N_
-
-        def ms_of(*names):
-            return sum(v["ms_per_proof"] for k, v in per_kernel.items() if any(x in k for x in names))
-        bf_peak, b3_peak = ctx.alu_ceiling(0), ctx.alu_ceiling(1)
-        ntt_ms = ms_of("k_intt_contig", "k_lde_mid", "k_lde_fwd_contig")
-        b3_ms = ms_of("k_leaf_hash", "k_merkle_level", "k_merkle_tree", "k_fri_round")
-        alu_ceiling = {
-            "butterflies_per_s_peak": round(bf_peak), "butterflies_per_proof": butterflies,
-            "ntt_kernels_ms": round(ntt_ms, 4), "ntt_ms_at_peak": round(butterflies / bf_peak * 1e3, 4),
-            "ntt_frac_of_alu_peak": round(butterflies / bf_peak * 1e3 / ntt_ms, 4) if ntt_ms else None,
-            "blake3_compressions_per_s_peak": round(b3_peak), "blake3_compressions_per_proof": compressions,
-            "merkle_kernels_ms": round(b3_ms, 4), "merkle_ms_at_peak": round(compressions / b3_peak * 1e3, 4),
-            "merkle_frac_of_alu_peak": round(compressions / b3_peak * 1e3 / b3_ms, 4) if b3_ms else None,
-            "note": "peaks from ts_bench_alu (register-resident loops of the same butterfly / compression code, "
-                    "no memory traffic); FRI-round leaf hashes fused into the fold kernel are not in merkle_kernels_ms"}
-        # ---- the ceiling that actually binds: VALU instruction issue.  A wave64 VALU instruction
-        # holds its SIMD for four cycles (tools/pmc_alu.sh: the register-resident loops issue exactly
-        # one per 4 cycles per SIMD at 2.30-2.34 GHz); the prover's kernels run at ~2.0 GHz
-        # (SQ_BUSY_CYCLES over their durations).  SQ_INSTS_VALU summed over one proof comes from a
-        # committed rocprofv3 --pmc pass (static, like roofline.traffic): tools/pmc_sq.sh.
-        valu_issue = None
-        try:
-            import hashlib
-            import re as _re
-            sqf = os.path.join(ROOT, "profiles", f"r02_{args.workload}_sq_counters.txt")
-            if os.path.exists(sqf) and args.log_n == (22 if args.workload == "config4" else 20):
-                m_ = _re.search(r"whole proof: SQ_INSTS_VALU ([0-9.e+]+)", open(sqf).read())
-                insts = float(m_.group(1))
-                simds, clock = 4 * ctx.num_cus if hasattr(ctx, "num_cus") else 1024, 2.0e9
-                floor_ms = insts * 4 / simds / clock * 1e3
-                valu_issue = {
-                    "wave_instructions_per_proof": insts, "simds": simds, "cycles_per_instruction": 4,
-                    "clock_hz_under_load": clock, "ms_per_proof_at_ceiling": round(floor_ms, 4),
-                    "frac_of_ceiling": round(floor_ms / res["ms_per_step"], 4),
-                    "source": {"file": os.path.relpath(sqf, ROOT),
-                               "sha256": hashlib.sha256(open(sqf, "rb").read()).hexdigest(),
-                               "note": "static: SQ_INSTS_VALU of an earlier rocprofv3 --pmc pass, not collected "
-                                       "in this run; clock = SQ_BUSY_CYCLES / kernel durations of the same pass"}}
-        except Exception:
-            valu_issue = None
-        # ---- the rate a caller sees who hands over HOST traces (never `value`): pinned buffer,
-        # asynchronous upload on each lane's stream, the upload of one lane overlapping the proofs of the others
-        h2d = None
-        if env.world == 1 and not sharded and not args.host_traces and args.workload in ("config3", "config2") and S > 1:
-            try:
-                pin = ts.PinnedHostMatrix(n, w)
-                pin.array[:] = make_trace(ctx).download()
-                k2 = 6 * S
-
-                def h2d_job(l):
-                    c, conf, ca = lanes[l]
-                    for _ in range(k2 // S):
-                        ts.prove(conf, ca, ts.BfChallenger(), ts.DeviceMatrix.upload_async(c, pin), pis)
-                list(pool.map(h2d_job, range(S)))  # warm-up
-                local_sync()
-                t0 = time.perf_counter()
-                list(pool.map(h2d_job, range(S)))
-                local_sync()
-                dt_h = time.perf_counter() - t0
-                h2d = {"ms_per_step": round(1e3 * dt_h / k2, 4), "steps": k2,
-                       "h2d_GB_per_s": round(n * w * 4 * k2 / dt_h / 1e9, 1),
-                       "note": "every step uploads its trace from page-locked host memory inside the timed "
-                               "region (hipMemcpyAsync on the lane's stream); PCIe Gen5 x16 bounds it"}
-            except Exception as e:  # never let the extra leg take the headline down
-                h2d = {"error": repr(e)}
-        # (the contract: timed on rank 0 at N = 1 only)
-        cpu = None if (args.no_cpu_baseline or env.world > 1) else cpu_baseline()
         proof = last["proof"]
+        wins = res.get("windows_ms_per_step") or [res["ms_per_step"]]
         out = {
             "metric": "trace cells/sec (proofs/sec alongside), 2^20x64 BabyBear trace",
             "value": res["value"], "unit": "trace cells/sec", "n_gpus": env.world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
+            "steps": args.steps, "warmup": warmup, "ms_per_step": res["ms_per_step"],
             "higher_is_better": True,
             "scaling": ("strong" if n_groups == 1 else "strong within a group, weak across groups")
                        if sharded else "weak", "vs_baseline": None,
@@ -568,28 +686,284 @@ def main():
                        "parallelism": (f"{n_groups} group(s) of {gsize} GPU(s), one proof sharded over each group, "
                                         f"collectives over {comm.backend}" if sharded else
                                        ("1 rank per GPU (replicas)" if env.world > 1 else "1 GPU")
-                                       + f", {S} proofs in flight per GPU"),
+                                       + f", {S} proofs in flight per GPU, lane l entering the timed region "
+                                         f"{stagger['ms']:.2f} ms x l after lane 0"),
                        "quotient_kernel": "hiprtc-specialised" if cair.is_jit else "interpreter",
                        "proof_words": int(len(proof.words))},
             "proofs_per_sec": res["steps_per_sec"],
-            # one proof alone on the GPU, HIP events around ts_prove (the `value` above keeps
-            # several in flight; this is the latency a single caller sees)
-            "single_proof_latency_ms": round(single_latency, 4),
-            "single_proof_latency_with_stage_timers_ms": stage_sum.get("prove"),
-            "roofline": roofline, "roofline_stage": roofline_stage, "roofline_whole": roofline_whole,
-            "alu_ceiling": alu_ceiling, "valu_issue": valu_issue, "h2d_inclusive": h2d,
-            "h2d_inclusive_ms_per_step": (h2d or {}).get("ms_per_step"), "cpu_baseline": cpu,
-            "stages_ms": stage_sum,
+            "extra": {"windows_ms_per_step": [round(x, 4) for x in wins],
+                      "windows_min_ms_per_step": round(min(wins), 4),
+                      "windows_median_ms_per_step": round(sorted(wins)[len(wins) // 2], 4),
+                      "note": f"{len(wins)} back-to-back timed windows of {args.steps} steps each, every one "
+                              "bracketed by barrier + device sync; `value` / `ms_per_step` are window 1",
+                      "lanes": S, "stagger_ms": round(stagger["ms"], 3),
+                      "one_proof_alone_ms_before_the_run": None if single_ms is None else round(single_ms, 3),
+                      "self_launched": bool(os.environ.get("TS_BENCH_SELF_LAUNCHED"))},
             "shard_stages_ms_per_rank": shard_stages,
-            "kernels": per_kernel,
         }
+    if env.rank == 0 and not args.headline_only:
+        out.update(rank0_legs(ts, args, env, ctx, config, cair, lanes, S, pool if S > 1 else None, local_sync,
+                              make_trace, pis, cfg, n, w, qd, res, sharded))
+
+    # ---- N > 1: BASELINE config 4 as one sharded proof, in the same lease
+    if env.world > 1 and not sharded and not args.no_sharded_block:
+        for c, _, _ in lanes[1:]:
+            c.synchronize()
+        mats = None
+        limit = float(os.environ.get("TS_BENCH_SHARD_TIMEOUT_S", "240"))
+
+        def on_timeout(phase):
+            if env.rank == 0 and out is not None:
+                out["sharded_config4"] = {"error": f"no result after {limit:.0f} s (stuck in: {phase}); the "
+                                                   "replicas measurement above is unaffected"}
+                emit(out)
+            os._exit(0)  # the record carries the error; a non-zero exit would void the replicas line too
+
+        wd = Watchdog(limit, on_timeout)
+        try:
+            blk = sharded_config4_block(ts, env, ctx, dev, wd)
+        except BaseException as e:  # noqa: BLE001 -- the headline must survive a failure here
+            import traceback
+            blk = {"error": repr(e), "traceback": traceback.format_exc()[-1500:]}
+        wd.done()
+        if out is not None:
+            out["sharded_config4"] = blk
+
     if sharded and env.dist is None:
         import torch.distributed as dist
         dist.destroy_process_group()
     env.close()
     if out is not None:
-        sys.stdout.flush()
-        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+        emit(out)
+
+
+def latest_profile(pattern: str):
+    import glob
+    fs = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    return fs[-1] if fs else None
+
+
+def rank0_legs(ts, args, env, ctx, config, cair, lanes, S, pool, local_sync, make_trace, pis, cfg, n, w, qd,
+               res, sharded) -> dict:
+    """Everything on the record beside the headline: measured on rank 0 after the timed region."""
+    import hashlib
+
+    import numpy as np
+
+    # ---- roofline leg: per-kernel HIP-event timings over 3 extra (untimed) proofs
+    reps = 3
+    extra = [make_trace(ctx) for _ in range(reps)]
+    ctx.set_kernel_timing(True)
+    for m in extra:
+        ts.prove(config, cair, ts.BfChallenger(), m, pis)
+    kt = ctx.take_kernel_timings()
+    ctx.set_kernel_timing(False)
+    ctx.set_timing(True)
+    ts.prove(config, cair, ts.BfChallenger(), make_trace(ctx), pis)
+    stages = ctx.take_timings()
+    ctx.set_timing(False)
+    # one proof alone on the GPU, no timers inside (the stage timers synchronise at every stage
+    # boundary): host wall clock around ts_prove, which returns with the proof on the host
+    lat = []
+    for _ in range(5):
+        m_ = make_trace(ctx)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        ts.prove(config, cair, ts.BfChallenger(), m_, pis)
+        lat.append(1e3 * (time.perf_counter() - t0))
+    single_latency = sorted(lat)[len(lat) // 2]
+    stage_sum = {}
+    for k, v in stages:  # a stage name can occur twice (trace commit, quotient commit)
+        stage_sum[k] = round(stage_sum.get(k, 0.0) + v, 3)
+    alg = algorithmic_bytes_per_proof(n, w, cfg[0], qd)
+
+    def alg_bytes(name):  # every instantiation of the strided NTT pass moves the same bytes
+        if "k_lde_mid" in name:
+            return alg["k_lde_mid<1>"]
+        if name == "k_merkle_level<1>" and "k_merkle_level<2>" not in kt:
+            return alg["k_merkle_level<1>"] + alg["k_merkle_level<2>"]
+        return alg.get(name)
+
+    per_kernel = {}
+    for name, (cnt, ms) in kt.items():
+        ms_pp = ms / reps
+        b = alg_bytes(name)
+        per_kernel[name] = {
+            "launches_per_proof": cnt / reps, "ms_per_proof": round(ms_pp, 4),
+            "avg_launch_ms": round(ms / cnt, 5),
+            "alg_gbps": round(b / (ms_pp * 1e-3) / 1e9, 1) if b and ms_pp > 0 else None}
+    dom = max(kt.items(), key=lambda kv: kv[1][1])[0]
+    dom_ms_pp = kt[dom][1] / reps
+    achieved = (alg_bytes(dom) or 0) / (dom_ms_pp * 1e-3)
+    # HBM traffic of that kernel from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE and
+    # --pmc WRITE_SIZE in separate passes, KiB units, FETCH_SIZE doubled for gfx950:
+    # profiles/*_pmc_traffic.json, made from tools/prof_prove.py); bytes per launch, or null
+    # NOT measured in this run (PMC collection needs rocprofv3 around the process): the file it
+    # comes from and that file's hash are reported beside it
+    traffic, traffic_source = None, None
+    try:
+        import glob
+        tag = {"config3": "", "config2": "config2_", "config4": "config4_"}.get(args.workload)
+        pmc_files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json"))
+                           if tag is not None and (("config" in os.path.basename(f)) == bool(tag))
+                           and (not tag or tag in os.path.basename(f)))
+        if pmc_files and args.log_n == (22 if args.workload == "config4" else 20):
+            ks = json.load(open(pmc_files[-1]))["kernels"]
+            stem = dom.strip("()").rstrip(">")  # "k_lde_mid<1" matches "k_lde_mid<1, 8192, 512>"
+            pk = ks.get(dom) or next((v for k, v in ks.items() if k.startswith(stem)), None)
+            if pk:
+                traffic = round((pk["fetch_bytes_per_proof_corrected"] + pk["write_bytes_per_proof"])
+                                / pk["launches_per_proof"])
+                traffic_source = {
+                    "file": os.path.relpath(pmc_files[-1], ROOT),
+                    "sha256": hashlib.sha256(open(pmc_files[-1], "rb").read()).hexdigest(),
+                    "note": "static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run "
+                            "(tools/prof_prove.py), not collected in this run"}
+    except Exception:
+        traffic, traffic_source = None, None
+    lpp = kt[dom][0] / reps
+    roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved / 1e9, 2),
+                "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 4),
+                "traffic": traffic, "traffic_source": traffic_source,
+                "alg_bytes_per_launch": round((alg_bytes(dom) or 0) / lpp) if lpp else None,
+                "avg_launch_ms": round(kt[dom][1] / kt[dom][0], 5),
+                "launches_per_proof": kt[dom][0] / reps,
+                "alg_bytes_per_proof": alg_bytes(dom),
+                "kernel_ms_total_per_proof": round(sum(v[1] for v in kt.values()) / reps, 3)}
+    # ---- the stage and the whole job against the same roofline (SURVEY.md section 8(d) terms)
+    N_ = n << cfg[0]
+    wall_ = w + 4 * qd
+    A1 = 4 * n * w + 4 * N_ * w            # trace LDE: read n x w, write N x w
+    C1 = 16 * n * qd + 16 * N_ * qd        # chunk LDE
+    whole = (A1 + 32 * (2 * N_ - 1) + (4 * n * qd * w + 16 * n * qd) + C1 + 32 * (2 * N_ - 1)
+             + (4 * N_ * w + 16 * N_ * qd + 16 * N_) + (32 * N_ + 16 * N_ + 64 * N_))
+    lde_ms = stage_sum.get("coset_lde")
+    roofline_stage = None
+    if lde_ms:
+        roofline_stage = {"stage": "coset_lde (trace + quotient chunks)", "alg_bytes": A1 + C1,
+                          "ms": lde_ms, "achieved": round((A1 + C1) / (lde_ms * 1e-3) / 1e9, 1),
+                          "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                          "frac": round((A1 + C1) / (lde_ms * 1e-3) / HBM_PEAK, 4),
+                          "note": "single proof alone on the GPU; the stage is three passes (60 n W bytes "
+                                  "moved for 20 n W algorithmic) and VALU-bound, see alu_ceiling"}
+    roofline_whole = {"alg_bytes_per_proof": whole, "ms_per_step": round(res["ms_per_step"], 4),
+                      "achieved": round(whole / (res["ms_per_step"] * 1e-3) / 1e9, 1), "peak": HBM_PEAK / 1e9,
+                      "unit": "GB/s", "frac": round(whole / (res["ms_per_step"] * 1e-3) / HBM_PEAK, 4)}
+    # ---- the integer-ALU ceiling, measured in this run with the library's own arithmetic
+    log_n_ = n.bit_length() - 1
+    butterflies = wall_ * (n // 2) * log_n_ * (1 + (1 << cfg[0]))
+    compressions = N_ * ((4 * w + 63) // 64) + N_ * ((16 * qd + 63) // 64) + N_ + 3 * N_
+
+    def ms_of(*names):
+        return sum(v["ms_per_proof"] for k, v in per_kernel.items() if any(x in k for x in names))
+    bf_peak, b3_peak = ctx.alu_ceiling(0), ctx.alu_ceiling(1)
+    ntt_ms = ms_of("k_intt_contig", "k_lde_mid", "k_lde_fwd_contig")
+    b3_ms = ms_of("k_leaf_hash", "k_merkle_level", "k_merkle_tree", "k_fri_round")
+    alu_ceiling = {
+        "butterflies_per_s_peak": round(bf_peak), "butterflies_per_proof": butterflies,
+        "ntt_kernels_ms": round(ntt_ms, 4), "ntt_ms_at_peak": round(butterflies / bf_peak * 1e3, 4),
+        "ntt_frac_of_alu_peak": round(butterflies / bf_peak * 1e3 / ntt_ms, 4) if ntt_ms else None,
+        "blake3_compressions_per_s_peak": round(b3_peak), "blake3_compressions_per_proof": compressions,
+        "merkle_kernels_ms": round(b3_ms, 4), "merkle_ms_at_peak": round(compressions / b3_peak * 1e3, 4),
+        "merkle_frac_of_alu_peak": round(compressions / b3_peak * 1e3 / b3_ms, 4) if b3_ms else None,
+        "note": "peaks from ts_bench_alu (register-resident loops of the same butterfly / compression code, "
+                "no memory traffic); FRI-round leaf hashes fused into the fold kernel are not in merkle_kernels_ms"}
+    # ---- the ceiling that actually binds: VALU instruction issue.  A wave64 VALU instruction
+    # holds its SIMD for four cycles (tools/pmc_alu.sh: the register-resident loops issue exactly
+    # one per 4 cycles per SIMD at 2.30-2.34 GHz); the prover's kernels run at ~2.0 GHz
+    # (SQ_BUSY_CYCLES over their durations).  SQ_INSTS_VALU summed over one proof comes from a
+    # committed rocprofv3 --pmc pass (static, like roofline.traffic): tools/pmc_sq.sh.
+    valu_issue = None
+    try:
+        import re as _re
+        sqf = latest_profile(f"r*_{args.workload}_sq_counters.txt")
+        if sqf and args.log_n == (22 if args.workload == "config4" else 20):
+            m_ = _re.search(r"whole proof: SQ_INSTS_VALU ([0-9.e+]+)", open(sqf).read())
+            insts = float(m_.group(1))
+            simds, clock = 4 * ctx.num_cus if hasattr(ctx, "num_cus") else 1024, 2.0e9
+            floor_ms = insts * 4 / simds / clock * 1e3
+            valu_issue = {
+                "wave_instructions_per_proof": insts, "simds": simds, "cycles_per_instruction": 4,
+                "clock_hz_under_load": clock, "ms_per_proof_at_ceiling": round(floor_ms, 4),
+                "frac_of_ceiling": round(floor_ms / res["ms_per_step"], 4),
+                "source": {"file": os.path.relpath(sqf, ROOT),
+                           "sha256": hashlib.sha256(open(sqf, "rb").read()).hexdigest(),
+                           "note": "static: SQ_INSTS_VALU of an earlier rocprofv3 --pmc pass, not collected "
+                                   "in this run; clock = SQ_BUSY_CYCLES / kernel durations of the same pass"}}
+    except Exception:
+        valu_issue = None
+
+    # ---- the rate a caller sees who hands over HOST traces (never `value`): pinned buffer,
+    # asynchronous upload on each lane's stream, the upload of one lane overlapping the proofs of the others
+    def h2d_leg(lanes_, make_trace_, pis_, n_, w_):
+        try:
+            pin = ts.PinnedHostMatrix(n_, w_)
+            pin.array[:] = make_trace_(lanes_[0][0]).download()
+            k2 = 6 * len(lanes_)
+
+            def h2d_job(l):
+                c, conf, ca = lanes_[l]
+                for _ in range(k2 // len(lanes_)):
+                    ts.prove(conf, ca, ts.BfChallenger(), ts.DeviceMatrix.upload_async(c, pin), pis_)
+            list(pool.map(h2d_job, range(len(lanes_))))  # warm-up
+            local_sync()
+            t0 = time.perf_counter()
+            list(pool.map(h2d_job, range(len(lanes_))))
+            local_sync()
+            dt_h = time.perf_counter() - t0
+            return {"ms_per_step": round(1e3 * dt_h / k2, 4), "steps": k2,
+                    "h2d_GB_per_s": round(n_ * w_ * 4 * k2 / dt_h / 1e9, 1),
+                    "note": "every step uploads its trace from page-locked host memory inside the timed "
+                            "region (hipMemcpyAsync on the lane's stream); PCIe Gen5 x16 bounds it"}
+        except Exception as e:  # never let the extra leg take the headline down
+            return {"error": repr(e)}
+
+    h2d = h2d_c2 = None
+    if env.world == 1 and not sharded and not args.host_traces and pool is not None:
+        if args.workload in ("config3", "config2"):
+            h2d = h2d_leg(lanes, make_trace, pis, n, w)
+        if args.workload == "config3":
+            # the same leg for BASELINE config 2 (Fibonacci 2^20 x 2): the other shape a caller of the
+            # reference's fib_air test would hand over; with its device-resident rate beside it
+            try:
+                air2, _, pis2, desc2, cfg2, (n2, w2), make2 = workload("config2", 20, False)
+                pis2 = np.array([0, 1, pis2(ctx)], dtype=np.uint32)
+                lanes2 = [(c, ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(*cfg2), c)),
+                           ts.CompiledAir(c, ts.air_tape(air2, len(pis2)))) for c, _, _ in lanes]
+                k2 = 6 * len(lanes2)
+                mats2 = [make2(lanes2[i % len(lanes2)][0]) for i in range(2 * k2)]
+
+                def dev_job(first):
+                    def job(l):
+                        c, conf, ca = lanes2[l]
+                        for i in range(first + l, first + k2, len(lanes2)):
+                            ts.prove(conf, ca, ts.BfChallenger(), mats2[i], pis2)
+                    return job
+                list(pool.map(dev_job(0), range(len(lanes2))))
+                local_sync()
+                t0 = time.perf_counter()
+                list(pool.map(dev_job(k2), range(len(lanes2))))
+                local_sync()
+                dev_ms = 1e3 * (time.perf_counter() - t0) / k2
+                h2d_c2 = h2d_leg(lanes2, make2, pis2, n2, w2)
+                h2d_c2["workload"] = desc2
+                h2d_c2["device_resident_ms_per_step"] = round(dev_ms, 4)
+            except Exception as e:
+                h2d_c2 = {"error": repr(e)}
+    # (the contract: timed on rank 0 at N = 1 only)
+    cpu = None if (args.no_cpu_baseline or env.world > 1) else cpu_baseline()
+    return {
+        # one proof alone on the GPU, HIP events around ts_prove (the `value` above keeps
+        # several in flight; this is the latency a single caller sees)
+        "single_proof_latency_ms": round(single_latency, 4),
+        "single_proof_latency_with_stage_timers_ms": stage_sum.get("prove"),
+        "roofline": roofline, "roofline_stage": roofline_stage, "roofline_whole": roofline_whole,
+        "alu_ceiling": alu_ceiling, "valu_issue": valu_issue, "h2d_inclusive": h2d,
+        "h2d_inclusive_config2": h2d_c2,
+        "h2d_inclusive_ms_per_step": (h2d or {}).get("ms_per_step"), "cpu_baseline": cpu,
+        "stages_ms": stage_sum,
+        "kernels": per_kernel,
+    }
 
 
 if __name__ == "__main__":

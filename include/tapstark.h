@@ -248,6 +248,16 @@ ts_status ts_rccl_unique_id(uint8_t out[128]);
 ts_status ts_comm_rccl_create(ts_ctx* ctx, const uint8_t unique_id[128], int rank, int world,
                               ts_comm* out, ts_rccl_comm** handle);
 void ts_comm_rccl_destroy(ts_rccl_comm* handle);
+/* What RCCL itself reports for the communicator (ncclCommCount / ncclCommUserRank / ncclCommCuDevice /
+ * ncclGetVersion; -1 where the symbol is missing or the communicator was aborted) beside what it was
+ * created with.  ts_comm_rccl_create already refuses (TS_ERR_COMM) a communicator whose count or rank
+ * differ from the arguments; this is for launchers that want to print them. */
+typedef struct {
+    int rank, world;                 /* as passed to ts_comm_rccl_create */
+    int comm_count, comm_user_rank;  /* as RCCL reports them */
+    int comm_device, rccl_version, aborted;
+} ts_rccl_info;
+ts_status ts_comm_rccl_info(const ts_rccl_comm* handle, ts_rccl_info* out);
 /* In-process group: `world` ranks = `world` host threads of one process, each with its own
  * context (same device or one device each: copies go device to device, peer to peer over xGMI).
  * Every rank's thread takes its ts_comm with ts_comm_local_get. */
@@ -255,6 +265,12 @@ typedef struct ts_comm_group ts_comm_group;
 ts_status ts_comm_local_group_create(int world, ts_comm_group** out);
 ts_status ts_comm_local_get(ts_comm_group* group, int rank, ts_comm* out);
 void ts_comm_local_group_destroy(ts_comm_group* group);
+/* A group is ONE-SHOT with respect to failure: after ts_comm.abort on any rank, or after a rendezvous
+ * timed out (a peer died silently; 600 s unless TS_COMM_TIMEOUT_S or ..._set_timeout says otherwise),
+ * every collective on it returns an error.  ts_comm_local_group_reset makes it usable again; call it
+ * only once EVERY rank's ts_prove_sharded has returned (no thread may still be inside a collective). */
+ts_status ts_comm_local_group_reset(ts_comm_group* group);
+ts_status ts_comm_local_group_set_timeout(ts_comm_group* group, int seconds);
 
 /* prove() with the work of ONE proof split over comm->world ranks, one GPU each: rank g owns the
  * bit-reversed LDE rows [g N/G, (g+1) N/G) -- whole cosets, so world must be a power of two
@@ -320,6 +336,13 @@ ts_status ts_proof_to_postcard(const uint32_t* proof, size_t n_words, uint8_t* o
                                size_t* n_bytes_out);
 ts_status ts_proof_from_postcard(const uint8_t* bytes, size_t n_bytes, uint32_t* proof_out,
                                  size_t cap_words, size_t* n_words_out);
+/* The postcard bytes do not record which MMCS produced them.  ts_proof_from_postcard infers the TSPF
+ * version from the number of roots per commitment (one -> v1, several -> v2), which is wrong for the
+ * one case of a proof over taptrees (v2) made with num_queries = 1.  tspf_version = 1 or 2 asks for
+ * that framing explicitly (1 refuses several roots; 2 always writes the num_queries header word);
+ * 0 infers as above. */
+ts_status ts_proof_from_postcard_v(const uint8_t* bytes, size_t n_bytes, int tspf_version,
+                                   uint32_t* proof_out, size_t cap_words, size_t* n_words_out);
 
 /* ------------------------------------------------------------------ taptree-compatible MMCS
  * The reference's real BFMmcs (basic/src/mmcs/taptree_mmcs.rs:24-119) commits to Bitcoin taptrees:

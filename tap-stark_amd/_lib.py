@@ -26,9 +26,11 @@ ABI_SYMBOLS = [
     "ts_quotient_chunks", "ts_pcs_open_reduce", "ts_pcs_open", "ts_pcs_verify", "ts_fri_prove", "ts_fri_verify", "ts_fri_fold", "ts_chal_new", "ts_chal_clone",
     "ts_chal_free", "ts_chal_observe", "ts_chal_observe_commitment", "ts_chal_sample",
     "ts_chal_sample_bits", "ts_chal_check_witness", "ts_chal_grind", "ts_chal_state", "ts_prove", "ts_prove_sharded", "ts_verify", "ts_check_constraints",
-    "ts_proof_to_postcard", "ts_proof_from_postcard",
+    "ts_proof_to_postcard", "ts_proof_from_postcard", "ts_proof_from_postcard_v",
     "ts_rccl_available", "ts_rccl_unique_id", "ts_comm_rccl_create", "ts_comm_rccl_destroy",
+    "ts_comm_rccl_info",
     "ts_comm_local_group_create", "ts_comm_local_get", "ts_comm_local_group_destroy",
+    "ts_comm_local_group_reset", "ts_comm_local_group_set_timeout",
     "ts_bench_alu", "ts_host_alloc", "ts_host_free", "ts_matrix_upload_async",
     "ts_tapleaf_hash", "ts_tapbranch_hash", "ts_tap_winternitz_lock_script", "ts_tap_leaf_script",
     "ts_taptree_from_scripts", "ts_taptree_combine", "ts_taptree_info", "ts_taptree_leaf_proof",
@@ -61,6 +63,13 @@ class CommC(C.Structure):
     """``ts_comm`` (include/tapstark.h)."""
     _fields_ = [("rank", C.c_int), ("world", C.c_int), ("user", C.c_void_p),
                 ("all_gather", ALL_GATHER_FN), ("broadcast", BROADCAST_FN), ("abort", ABORT_FN)]
+
+
+class RcclInfoC(C.Structure):
+    """``ts_rccl_info`` (include/tapstark.h)."""
+    _fields_ = [("rank", C.c_int), ("world", C.c_int), ("comm_count", C.c_int),
+                ("comm_user_rank", C.c_int), ("comm_device", C.c_int), ("rccl_version", C.c_int),
+                ("aborted", C.c_int)]
 
 
 class ShardOptionsC(C.Structure):
@@ -162,6 +171,9 @@ def lib() -> C.CDLL:
         l.ts_comm_rccl_create.argtypes = [C.c_void_p, u8p, C.c_int, C.c_int, C.POINTER(CommC), voidpp]
         l.ts_comm_rccl_destroy.argtypes = [C.c_void_p]
         l.ts_comm_rccl_destroy.restype = None
+        l.ts_comm_rccl_info.argtypes = [C.c_void_p, C.POINTER(RcclInfoC)]
+        l.ts_comm_local_group_reset.argtypes = [C.c_void_p]
+        l.ts_comm_local_group_set_timeout.argtypes = [C.c_void_p, C.c_int]
         l.ts_comm_local_group_create.argtypes = [C.c_int, voidpp]
         l.ts_comm_local_get.argtypes = [C.c_void_p, C.c_int, C.POINTER(CommC)]
         l.ts_comm_local_group_destroy.argtypes = [C.c_void_p]
@@ -202,6 +214,7 @@ def lib() -> C.CDLL:
         l.ts_tap_mmcs_free.restype = None
         l.ts_proof_to_postcard.argtypes = [u32p, C.c_size_t, u8p, C.c_size_t, C.POINTER(C.c_size_t)]
         l.ts_proof_from_postcard.argtypes = [u8p, C.c_size_t, u32p, C.c_size_t, C.POINTER(C.c_size_t)]
+        l.ts_proof_from_postcard_v.argtypes = [u8p, C.c_size_t, C.c_int, u32p, C.c_size_t, C.POINTER(C.c_size_t)]
         l.ts_check_constraints.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, u32p, C.c_uint32,
                                            C.POINTER(C.c_int64)]
         l.ts_verify.argtypes = [C.POINTER(FriConfigC), C.c_void_p, C.c_void_p, u32p, C.c_size_t, u32p,

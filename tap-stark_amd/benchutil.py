@@ -78,21 +78,28 @@ def init_dist(backend: Optional[str] = None) -> DistEnv:
 
 def run_timed(env: DistEnv, step: Callable[[int], None], steps: int, warmup: int,
               local_sync: Callable[[], None], units_per_step: float,
-              run_steps: Optional[Callable[[int, int], None]] = None) -> dict:
+              run_steps: Optional[Callable[[int, int], None]] = None, extra_windows: int = 0) -> dict:
     """W untimed warm-up steps, then EXACTLY K timed steps bracketed by barrier + device sync on
     both sides; returns the job-level numbers (identical on every rank).  `run_steps(first, count)`
     may replace the sequential loop (e.g. to keep several independent steps in flight); it must
-    complete exactly the steps first .. first+count-1."""
+    complete exactly the steps first .. first+count-1.  `extra_windows` more windows of K steps each
+    follow the first, every one bracketed the same way: their ms/step are returned beside the first
+    window's (`windows_ms_per_step`) so that the spread between windows is on the record; `value`,
+    `ms_per_step` and `elapsed_s` are ALWAYS the first window's."""
     if run_steps is None:
         def run_steps(first, count):
             for i in range(first, first + count):
                 step(i)
     run_steps(0, warmup)
-    env.barrier(local_sync)
-    t0 = time.perf_counter()
-    run_steps(warmup, steps)
-    env.barrier(local_sync)
-    elapsed = env.max_over_ranks(time.perf_counter() - t0)
+    windows = []
+    for k in range(1 + max(0, extra_windows)):
+        env.barrier(local_sync)
+        t0 = time.perf_counter()
+        run_steps(warmup + k * steps, steps)
+        env.barrier(local_sync)
+        windows.append(env.max_over_ranks(time.perf_counter() - t0))
+    elapsed = windows[0]
     total_units = env.sum_over_ranks(units_per_step * steps)
     return {"elapsed_s": elapsed, "ms_per_step": 1e3 * elapsed / steps,
-            "value": total_units / elapsed, "steps_per_sec": env.world * steps / elapsed}
+            "value": total_units / elapsed, "steps_per_sec": env.world * steps / elapsed,
+            "windows_ms_per_step": [1e3 * e / steps for e in windows]}

@@ -101,6 +101,33 @@ def _clangxx() -> str:
     raise RuntimeError("clang++ of the ROCm toolchain not found")
 
 
+def device_disassembly(source: str) -> dict:
+    """{mangled kernel name: [instruction lines]} of the gfx950 code object inside the object file of
+    `source` (e.g. "merkle.hip"); builds first if needed.  Used by tests/test_build_isa.py to check
+    the memory-scope bits of the cross-workgroup hand-offs."""
+    import re
+    import tempfile
+
+    build()
+    obj = os.path.join(OBJ, source + ".o")
+    objdump = os.path.join(_rocm(), "lib", "llvm", "bin", "llvm-objdump")
+    with tempfile.TemporaryDirectory() as td:
+        tmp = os.path.join(td, os.path.basename(obj))
+        shutil.copy(obj, tmp)
+        subprocess.run([objdump, "--offloading", tmp], check=True, capture_output=True)  # unbundles beside the input
+        cos = [f for f in os.listdir(td) if "amdgcn" in f]
+        if not cos:
+            raise RuntimeError(f"no gfx950 code object in {obj}")
+        text = subprocess.run([objdump, "-d", os.path.join(td, cos[0])], check=True, capture_output=True,
+                              text=True).stdout
+    out = {}
+    for block in re.split(r"\n(?=[0-9a-f]{16} <)", text):
+        m = re.match(r"[0-9a-f]{16} <([^>]+)>:", block)
+        if m:
+            out[m.group(1)] = [l.split("//")[0].strip() for l in block.splitlines()[1:] if l.strip()]
+    return out
+
+
 def asan_runtime() -> str:
     """What LD_PRELOAD needs for the asan build under an uninstrumented python: clang's ASan runtime,
     and libstdc++ so that the runtime's __cxa_throw interceptor finds the real one at start-up (the

@@ -34,6 +34,18 @@ class LocalCommGroup:
             raise _lib.TsError(rc, "ts_comm_local_get")
         return _NativeComm(c, self)
 
+    def reset(self):
+        """Make a group usable again after an aborted proof (one-shot failure semantics otherwise,
+        include/tapstark.h): only once every rank's prove call has returned."""
+        rc = _lib.lib().ts_comm_local_group_reset(self.h)
+        if rc:
+            raise _lib.TsError(rc, "ts_comm_local_group_reset")
+
+    def set_timeout(self, seconds: int):
+        rc = _lib.lib().ts_comm_local_group_set_timeout(self.h, int(seconds))
+        if rc:
+            raise _lib.TsError(rc, "ts_comm_local_group_set_timeout")
+
     def __del__(self):
         try:
             if self.h:
@@ -65,6 +77,14 @@ class RcclComm(_NativeComm):
         if rc:
             raise _lib.TsError(rc, "ts_comm_rccl_create")
         super().__init__(c, ctx)
+
+    def info(self) -> dict:
+        """What RCCL itself reports (ncclCommCount, ncclCommUserRank, ...) beside the arguments."""
+        i = _lib.RcclInfoC()
+        rc = _lib.lib().ts_comm_rccl_info(self.h, C.byref(i))
+        if rc:
+            raise _lib.TsError(rc, "ts_comm_rccl_info")
+        return {k: int(getattr(i, k)) for k, _ in _lib.RcclInfoC._fields_}
 
     def close(self):
         if self.h:

@@ -129,18 +129,23 @@ ts_status ts_proof_to_postcard(const uint32_t* proof, size_t n_words, uint8_t* o
 }
 ts_status ts_proof_from_postcard(const uint8_t* bytes, size_t n_bytes, uint32_t* proof_out,
                                  size_t cap_words, size_t* n_words_out) {
-    if (!bytes || !proof_out || !n_words_out) return TS_ERR_INVALID;
+    return ts_proof_from_postcard_v(bytes, n_bytes, 0, proof_out, cap_words, n_words_out);
+}
+ts_status ts_proof_from_postcard_v(const uint8_t* bytes, size_t n_bytes, int tspf_version,
+                                   uint32_t* proof_out, size_t cap_words, size_t* n_words_out) {
+    if (!bytes || !proof_out || !n_words_out || tspf_version < 0 || tspf_version > 2) return TS_ERR_INVALID;
     *n_words_out = 0;
     return guard(nullptr, [&] {
         std::vector<uint32_t> w;
-        TS_REQUIRE(ts::postcard_to_tspf(bytes, n_bytes, w), ts::TS_ERR_INVALID, "malformed postcard proof");
+        TS_REQUIRE(ts::postcard_to_tspf(bytes, n_bytes, w, tspf_version), ts::TS_ERR_INVALID,
+                   "malformed postcard proof (or not of the TSPF version asked for)");
         *n_words_out = w.size();
         TS_REQUIRE(w.size() <= cap_words, ts::TS_ERR_BUFFER, "proof buffer too small");
         memcpy(proof_out, w.data(), w.size() * 4);
     });
 }
 
-uint32_t ts_abi_version(void) { return 2; }  // 2: ts_comm.abort, native communicators, ts_mmcs_*, taptree
+uint32_t ts_abi_version(void) { return 3; }  // 3: ts_proof_from_postcard_v, ts_comm_rccl_info, ts_comm_local_group_reset/_set_timeout
 
 ts_status ts_ctx_create(int device, ts_ctx** out) {
     if (!out) return TS_ERR_INVALID;

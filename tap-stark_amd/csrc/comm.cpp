@@ -18,6 +18,7 @@
 // group is poisoned (every waiting or later rendezvous returns an error), the RCCL communicator is
 // aborted (ncclCommAbort makes pending collectives on the peers fail rather than hang).
 #include <dlfcn.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <atomic>
@@ -47,8 +48,10 @@ struct ts_comm_group {
     };
     std::vector<Slot> slots;
 
-    // all ranks arrive; returns false if the group was poisoned (or on a 10-minute timeout, which
-    // poisons it: a peer died without telling anyone)
+    int timeout_s = 600;  // TS_COMM_TIMEOUT_S / ts_comm_local_group_set_timeout
+
+    // all ranks arrive; returns false if the group was poisoned (or on a timeout -- 10 minutes unless
+    // configured -- which poisons it: a peer died without telling anyone)
     bool rendezvous() {
         std::unique_lock<std::mutex> lk(mu);
         if (poisoned) return false;
@@ -59,7 +62,7 @@ struct ts_comm_group {
             cv.notify_all();
             return true;
         }
-        const bool ok = cv.wait_for(lk, std::chrono::minutes(10),
+        const bool ok = cv.wait_for(lk, std::chrono::seconds(timeout_s),
                                     [&] { return generation != gen || poisoned; });
         if (!ok) {
             poisoned = true;
@@ -148,6 +151,10 @@ struct Rccl {
     int (*broadcast)(const void*, void*, size_t, int, int, NcclComm, hipStream_t) = nullptr;
     int (*comm_destroy)(NcclComm) = nullptr;
     int (*comm_abort)(NcclComm) = nullptr;
+    int (*comm_count)(NcclComm, int*) = nullptr;
+    int (*comm_user_rank)(NcclComm, int*) = nullptr;
+    int (*comm_cu_device)(NcclComm, int*) = nullptr;
+    int (*get_version)(int*) = nullptr;
     const char* (*get_error_string)(int) = nullptr;
     bool ok = false;
 };
@@ -173,6 +180,10 @@ Rccl load_rccl() {
     r.broadcast = (decltype(r.broadcast))dlsym(r.lib, "ncclBroadcast");
     r.comm_destroy = (decltype(r.comm_destroy))dlsym(r.lib, "ncclCommDestroy");
     r.comm_abort = (decltype(r.comm_abort))dlsym(r.lib, "ncclCommAbort");
+    r.comm_count = (decltype(r.comm_count))dlsym(r.lib, "ncclCommCount");
+    r.comm_user_rank = (decltype(r.comm_user_rank))dlsym(r.lib, "ncclCommUserRank");
+    r.comm_cu_device = (decltype(r.comm_cu_device))dlsym(r.lib, "ncclCommCuDevice");
+    r.get_version = (decltype(r.get_version))dlsym(r.lib, "ncclGetVersion");
     r.get_error_string = (decltype(r.get_error_string))dlsym(r.lib, "ncclGetErrorString");
     r.ok = r.get_unique_id && r.comm_init_rank && r.all_gather && r.broadcast && r.comm_destroy;
     return r;
@@ -225,6 +236,10 @@ ts_status ts_comm_local_group_create(int world, ts_comm_group** out) {
     auto* g = new (std::nothrow) ts_comm_group();
     if (!g) return TS_ERR_OOM;
     g->world = world;
+    if (const char* e = getenv("TS_COMM_TIMEOUT_S")) {
+        const int t = atoi(e);
+        if (t > 0) g->timeout_s = t;
+    }
     g->send.assign(world, nullptr);
     g->recv.assign(world, nullptr);
     g->device.assign(world, 0);
@@ -247,6 +262,22 @@ ts_status ts_comm_local_get(ts_comm_group* group, int rank, ts_comm* out) {
 }
 
 void ts_comm_local_group_destroy(ts_comm_group* group) { delete group; }
+
+ts_status ts_comm_local_group_set_timeout(ts_comm_group* group, int seconds) {
+    if (!group || seconds < 1) return TS_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(group->mu);
+    group->timeout_s = seconds;
+    return TS_OK;
+}
+
+ts_status ts_comm_local_group_reset(ts_comm_group* group) {
+    if (!group) return TS_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(group->mu);
+    group->poisoned = false;
+    group->arrived = 0;
+    group->generation++;  // a straggler of the aborted collective (there must be none) would not match
+    return TS_OK;
+}
 
 int ts_rccl_available(void) { return rccl().ok ? 1 : 0; }
 
@@ -277,6 +308,17 @@ ts_status ts_comm_rccl_create(ts_ctx* ctx, const uint8_t unique_id[128], int ran
     }
     c->rank = rank;
     c->world = world;
+    // what RCCL itself believes must be what the caller asked for: a communicator that came up with
+    // another size or rank would exchange the wrong slabs without any error
+    if (rccl().comm_count && rccl().comm_user_rank) {
+        int n = -1, r = -1;
+        if (rccl().comm_count(c->comm, &n) != 0 || rccl().comm_user_rank(c->comm, &r) != 0 ||
+            n != world || r != rank) {
+            if (rccl().comm_abort) rccl().comm_abort(c->comm);
+            delete c;
+            return TS_ERR_COMM;
+        }
+    }
     memset(out, 0, sizeof *out);
     out->rank = rank;
     out->world = world;
@@ -285,6 +327,21 @@ ts_status ts_comm_rccl_create(ts_ctx* ctx, const uint8_t unique_id[128], int ran
     out->broadcast = rccl_broadcast;
     out->abort = rccl_abort;
     *handle = c;
+    return TS_OK;
+}
+
+ts_status ts_comm_rccl_info(const ts_rccl_comm* c, ts_rccl_info* out) {
+    if (!c || !out) return TS_ERR_INVALID;
+    memset(out, 0, sizeof *out);
+    out->comm_count = out->comm_user_rank = out->comm_device = out->rccl_version = -1;
+    out->rank = c->rank;
+    out->world = c->world;
+    out->aborted = c->aborted ? 1 : 0;
+    if (rccl().get_version) rccl().get_version(&out->rccl_version);
+    if (!c->comm || c->aborted) return TS_OK;
+    if (rccl().comm_count) rccl().comm_count(c->comm, &out->comm_count);
+    if (rccl().comm_user_rank) rccl().comm_user_rank(c->comm, &out->comm_user_rank);
+    if (rccl().comm_cu_device) rccl().comm_cu_device(c->comm, &out->comm_device);
     return TS_OK;
 }
 

@@ -237,6 +237,6 @@ int fri_verify_pass_through(const FriConfig& fri, BfChallenger& challenger, cons
 
 // ------------------------------------------------------------------ wire format (wire.cpp)
 bool tspf_to_postcard(const uint32_t* words, size_t n_words, std::vector<uint8_t>& out);
-bool postcard_to_tspf(const uint8_t* bytes, size_t n_bytes, std::vector<uint32_t>& out);
+bool postcard_to_tspf(const uint8_t* bytes, size_t n_bytes, std::vector<uint32_t>& out, int want_version = 0);
 
 }  // namespace ts

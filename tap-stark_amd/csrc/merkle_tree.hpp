@@ -2,7 +2,7 @@
 //
 // Workgroup g takes a block of B = 2^log_b consecutive nodes of the first level and reduces it to
 // its sub-root; the workgroup that finishes LAST (ticket counter in device memory, sub-roots handed
-// over with sc1 stores / loads, no fence: see the hand-off note in k_merkle_tree) reduces the n_sub
+// over with sc1 stores / loads behind one acquire in the finisher: see the hand-off note in tree_body) reduces the n_sub
 // sub-roots to the root and, if asked, runs the device challenger step.  Every level is stored in
 // the tree (levels back to back, as the gathers of the query phase expect).
 //
@@ -175,7 +175,13 @@ __device__ __forceinline__ void tree_body(Lds& lds, uint32_t& s_last, Producer& 
         // sc1 (written through, dropped from the XCD's L2) and loaded sc1 (bypassing L1); the
         // storing wave drains its stores, the workgroup meets, ONE lane adds to the ticket counter
         // at agent scope; the workgroup whose add came last loads after a barrier behind that add.
-        // No release/acquire fence: those cost 2-6 us each here, more than the levels themselves.
+        // No RELEASE fence on the producing side (sc1 stores are written through; 2-6 us saved per
+        // workgroup).  The consuming side keeps ONE agent-scope acquire in the finishing workgroup:
+        // the guide's fence-free consumer form is measured at one workgroup per CU only, and this
+        // kernel runs two or three per CU with several proofs in flight.  It costs the
+        // finisher ~2.4 us per tree (30.1 against 27.7 us for a 2^16-leaf top) -- once per launch, not
+        // per workgroup -- and the sub-root loads stay sc1 on top of it.  tests/test_build_isa.py
+        // checks the disassembly: sc1 on these stores and loads, buffer_inv sc1, no flat_ access.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -184,6 +190,11 @@ __device__ __forceinline__ void tree_body(Lds& lds, uint32_t& s_last, Producer& 
         }
         __syncthreads();
         if (s_last) {
+            if (threadIdx.x == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();
             StagedNodes<true> sub{lv.at(log_b, 0)};
             top = reduce_block(lds, sub, n_sub, lv, log_b, 0, moff, false);
             if (threadIdx.x == 0)  // ready for the next launch on this stream

@@ -218,11 +218,17 @@ bool tspf_to_postcard(const uint32_t* words, size_t n_words, std::vector<uint8_t
 
 // postcard -> TSPF v1.  Returns false on malformed input (truncated, non-canonical field element,
 // a shape TSPF cannot hold, trailing bytes).
-bool postcard_to_tspf(const uint8_t* bytes, size_t n_bytes, std::vector<uint32_t>& out) {
+// want_version: 0 = infer (one root per commitment -> v1, several -> v2); 1 / 2 = that framing.  The
+// postcard bytes do not say which MMCS made them: a proof over taptrees with num_queries = 1 has one
+// root per commitment too, and only the caller knows it must come back as v2.
+bool postcard_to_tspf(const uint8_t* bytes, size_t n_bytes, std::vector<uint32_t>& out, int want_version) {
+    if (want_version < 0 || want_version > 2) return false;
     ByteReader r{bytes, n_bytes};
     std::vector<uint32_t> body;  // everything after the header words
-    const uint64_t n_roots = r.commitment(body, 0);  // 1: TSPF v1; more: v2
+    const uint64_t n_roots = r.commitment(body, 0);  // 1: TSPF v1 (or a v2 proof of one query); more: v2
     if (r.bad) return false;
+    if (want_version == 1 && n_roots != 1) return false;
+    const bool v2 = want_version == 2 || (want_version == 0 && n_roots != 1);
     r.commitment(body, n_roots);
     uint64_t width = 0;
     for (int k = 0; k < 2; k++) {
@@ -285,11 +291,11 @@ bool postcard_to_tspf(const uint8_t* bytes, size_t n_bytes, std::vector<uint32_t
     out.clear();
     out.reserve(5 + body.size());
     out.push_back(TSPF_MAGIC);
-    out.push_back(n_roots == 1 ? 1 : 2);
+    out.push_back(v2 ? 2 : 1);
     out.push_back((uint32_t)degree_bits);
     out.push_back((uint32_t)width);
     out.push_back((uint32_t)qd);
-    if (n_roots != 1) out.push_back((uint32_t)n_roots);
+    if (v2) out.push_back((uint32_t)n_roots);
     out.insert(out.end(), body.begin(), body.end());
     return true;
 }

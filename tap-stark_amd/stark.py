@@ -576,13 +576,15 @@ class Proof:
         return out[: n.value].tobytes()
 
     @classmethod
-    def from_postcard(cls, data: bytes) -> "Proof":
+    def from_postcard(cls, data: bytes, version: int = 0) -> "Proof":
+        """``version``: 0 infers TSPF v1 / v2 from the number of roots per commitment; 2 must be
+        given for a proof over taptrees made with one query (``ts_proof_from_postcard_v``)."""
         l = _lib.lib()
         b = np.frombuffer(data, dtype=np.uint8).copy()
         out = np.zeros(len(b) + 16, dtype=np.uint32)  # every word takes at least one byte
         n = C.c_size_t()
-        rc = l.ts_proof_from_postcard(b.ctypes.data_as(C.POINTER(C.c_uint8)), len(b), _p(out), len(out),
-                                      C.byref(n))
+        rc = l.ts_proof_from_postcard_v(b.ctypes.data_as(C.POINTER(C.c_uint8)), len(b), int(version),
+                                        _p(out), len(out), C.byref(n))
         if rc:
             raise _lib.TsError(rc, "ts_proof_from_postcard")
         return cls.parse(out[: n.value].copy())

@@ -281,6 +281,71 @@ def test_sharded_failure_on_one_rank_does_not_hang_the_others(ctx):
     assert all(isinstance(e, TsError) for e in errors), errors
     assert errors[2].code == 1 and {errors[r].code for r in (0, 1, 3)} == {7}
 
+    # The group is one-shot with respect to failure (include/tapstark.h): every later collective
+    # fails until it is reset -- and after ts_comm_local_group_reset the SAME group proves again
+    # (one bad proof must not kill the group for the rest of the process).
+    errors2 = [None] * G
+
+    def rank_poisoned(r):
+        try:
+            c = ts.Context(0)
+            config = ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(2, 4, 8), c))
+            rows = np.ascontiguousarray(trace[r * n // G:(r + 1) * n // G])
+            ts.prove_sharded(config, ts.CompiledAir(c, ts.air_tape(air, 0)), ts.BfChallenger(), rows, pis,
+                             group.comm(r), 2)
+        except BaseException as e:  # noqa: BLE001
+            errors2[r] = e
+
+    threads = [threading.Thread(target=rank_poisoned, args=(r,)) for r in range(G)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert all(isinstance(e, TsError) and e.code == 7 for e in errors2), errors2
+    group.reset()
+    config0 = ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(2, 4, 8), ctx))
+    want = ts.prove(config0, air, ts.BfChallenger(), trace, pis)
+    proofs, errors3 = [None] * G, [None] * G
+
+    def rank_good(r):
+        try:
+            c = ts.Context(0)
+            config = ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(2, 4, 8), c))
+            rows = np.ascontiguousarray(trace[r * n // G:(r + 1) * n // G])
+            proofs[r] = ts.prove_sharded(config, ts.CompiledAir(c, ts.air_tape(air, 0)), ts.BfChallenger(),
+                                         rows, pis, group.comm(r), 2).words
+        except BaseException as e:  # noqa: BLE001
+            errors3[r] = e
+
+    threads = [threading.Thread(target=rank_good, args=(r,)) for r in range(G)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in threads)
+    for r in range(G):
+        assert errors3[r] is None, f"rank {r} after reset: {errors3[r]!r}"
+        assert (proofs[r] == want.words).all()
+
+
+def test_local_group_timeout_is_configurable(ctx):
+    # a peer that never arrives: the waiting rank gives up after the configured time (not 10 minutes)
+    import time
+
+    import torch
+
+    from tapstark_amd.comm import LocalCommGroup
+
+    group = LocalCommGroup(2)
+    group.set_timeout(1)
+    c = group.comm(0).c
+    buf = torch.zeros(64, dtype=torch.uint8, device="cuda:0")
+    out = torch.zeros(128, dtype=torch.uint8, device="cuda:0")
+    t0 = time.time()
+    rc = c.all_gather(c.user, buf.data_ptr(), out.data_ptr(), 64, ctx.stream())
+    assert rc != 0 and time.time() - t0 < 10
+    group.reset()
+
 
 def test_rccl_native_comm_world_of_one(ctx, orc):
     # the C++ RCCL communicator (ncclAllGather / ncclBroadcast on the context's stream) with a
@@ -299,6 +364,50 @@ def test_rccl_native_comm_world_of_one(ctx, orc):
     p = ts.prove_sharded(config, air, ch, trace, pis, rc, 6)
     assert (p.words == want.words).all()
     assert ch.sample_bits(20) == want_bits
+    info = rc.info()
+    assert info["comm_count"] == 1 and info["comm_user_rank"] == 0 and info["world"] == 1, info
+    assert info["rccl_version"] > 0 and info["aborted"] == 0
+    rc.close()
+
+
+def test_rccl_native_comm_collective_shapes_of_config4(ctx):
+    """Every collective shape BASELINE config 4 puts on the native RCCL communicator at G = 8, run
+    with the one world size a one-GPU box allows (1): the 128 MiB-per-rank trace all-gather, the
+    16 n-byte quotient-chunk broadcast (64 MiB at n = 2^22), the 32-byte sub-root all-gathers, the
+    FRI-tail and answered-query gathers (odd sizes, not multiples of 16).  What this can catch before
+    a node exists: buffer-size / alignment / datatype errors, stream ordering with the context's own
+    non-blocking stream.  What it cannot: anything about a second rank."""
+    import torch
+
+    from tapstark_amd import comm as tc
+
+    if not tc.rccl_available():
+        pytest.skip("librccl not loadable")
+    c = ts.Context(0)
+    rc = tc.RcclComm(c, tc.rccl_unique_id(), 0, 1)
+    cc = rc.c
+    stream = c.stream()
+    g = torch.Generator(device="cuda:0")
+    g.manual_seed(5)
+    for nbytes in (128 << 20, 64 << 20, 32, 8 * 32, 16 * 4096, 4 * 21877, 12345, 1):
+        src = torch.randint(0, 256, (nbytes,), dtype=torch.uint8, device="cuda:0", generator=g)
+        dst = torch.zeros(nbytes, dtype=torch.uint8, device="cuda:0")
+        torch.cuda.synchronize()
+        assert cc.all_gather(cc.user, src.data_ptr(), dst.data_ptr(), nbytes, stream) == 0
+        c.synchronize()
+        assert torch.equal(src, dst), f"all_gather of {nbytes} bytes"
+        keep = src.clone()
+        torch.cuda.synchronize()
+        assert cc.broadcast(cc.user, src.data_ptr(), nbytes, 0, stream) == 0
+        c.synchronize()
+        assert torch.equal(src, keep), f"broadcast of {nbytes} bytes"
+    # unaligned device pointers (a slab that starts in the middle of a buffer)
+    big = torch.randint(0, 256, (1 << 16,), dtype=torch.uint8, device="cuda:0", generator=g)
+    out = torch.zeros(1 << 16, dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
+    assert cc.all_gather(cc.user, big.data_ptr() + 36, out.data_ptr() + 4, 1000, stream) == 0
+    c.synchronize()
+    assert torch.equal(big[36:1036], out[4:1004])
     rc.close()
 
 

@@ -47,3 +47,32 @@ def test_postcard_parser_survives_corruption(orc, lib):
             ok += 1
         assert ok < len(cases)  # most corruptions are refused
     assert time.time() - t0 < 20
+
+
+def test_postcard_round_trip_of_a_one_query_taptree_proof(orc, lib):
+    # a proof over taptrees (TSPF v2) made with num_queries = 1 has ONE root per commitment,
+    # like a v1 proof; the postcard bytes cannot tell the two apart, so the reader takes the version
+    # as an argument (ts_proof_from_postcard_v).  Inferred, it comes back as v1 and verify_tap refuses
+    # it; asked for v2, the words are the prover's and verify_tap accepts.
+    import tapstark_amd as ts
+    from tapstark_amd._lib import TsError
+
+    cfg = (2, 1, 4)
+    air, trace, pis, tape, locks = _tap_case("fib", 3, cfg)
+    ocfg = orc.FriConfig(*cfg)
+    words = orc.prove_tap(ocfg, tape, trace, pis, locks)
+    assert int(words[1]) == 2 and int(words[5]) == 1
+    data = ts.Proof(words=words).to_postcard()
+    inferred = ts.Proof.from_postcard(data)
+    assert int(inferred.words[1]) == 1 and len(inferred.words) == len(words) - 1
+    back = ts.Proof.from_postcard(data, version=2)
+    assert len(back.words) == len(words) and (back.words == words).all()
+    assert orc.verify_tap(ocfg, tape, back.words, pis, locks) == 0
+    assert back.to_postcard() == data
+    # version 1 refuses a proof with several roots per commitment
+    cfg3 = (2, 3, 4)
+    air, trace, pis, tape, locks3 = _tap_case("fib", 3, cfg3)
+    v2 = ts.Proof(words=orc.prove_tap(orc.FriConfig(*cfg3), tape, trace, pis, locks3)).to_postcard()
+    with pytest.raises(TsError):
+        ts.Proof.from_postcard(v2, version=1)
+    assert int(ts.Proof.from_postcard(v2, version=2).words[1]) == 2

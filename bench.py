@@ -782,7 +782,10 @@ def rank0_legs(ts, args, env, ctx, config, cair, lanes, S, pool, local_sync, mak
             return alg["k_lde_mid<1>"]
         if name == "k_merkle_level<1>" and "k_merkle_level<2>" not in kt:
             return alg["k_merkle_level<1>"] + alg["k_merkle_level<2>"]
-        return alg.get(name)
+        if name in alg:
+            return alg[name]
+        stem = name.strip("()").split("<")[0]  # "k_lde_fwd_contig<14, 4>" -> "k_lde_fwd_contig"
+        return alg.get(stem)
 
     per_kernel = {}
     for name, (cnt, ms) in kt.items():

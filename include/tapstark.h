@@ -192,6 +192,11 @@ ts_status ts_fri_verify(const ts_fri_config* cfg, ts_challenger* chal, const uin
 /* FriGenericConfig::fold_matrix, two_adic_pcs.rs:116-147 (host in, host out; 2h EF4 -> h EF4) */
 ts_status ts_fri_fold(ts_ctx* ctx, const uint32_t* in, uint64_t h, const uint32_t beta[4],
                       uint32_t* out);
+/* The same on DEVICE vectors (16-byte aligned), enqueued on the context's stream: what a caller that
+ * keeps its FRI vectors in HBM binds, and what tools/bench_fold.py times against the reference's only
+ * benchmark (fri/benches/fold_even_odd.rs:14-46). */
+ts_status ts_fri_fold_device(ts_ctx* ctx, const uint32_t* in_dev, uint64_t h, const uint32_t beta[4],
+                             uint32_t* out_dev);
 
 /* ------------------------------------------------------------------ challenger */
 /* BfChallenger::new, basic/src/challenger/mod.rs:122-137.  permutation: 0 = Blake3Permutation

@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "ts_matrix_from_device", "ts_trace_fibonacci", "ts_trace_synth_mul", "ts_trace_synth_ext", "ts_matrix_dims", "ts_matrix_download", "ts_matrix_free",
     "ts_air_compile", "ts_air_info", "ts_air_is_jit", "ts_air_free", "ts_pcs_commit", "ts_mmcs_commit", "ts_pcs_data_lde",
     "ts_pcs_data_info", "ts_pcs_data_matrix_info", "ts_pcs_data_digests", "ts_pcs_open_batch", "ts_pcs_data_free",
-    "ts_quotient_chunks", "ts_pcs_open_reduce", "ts_pcs_open", "ts_pcs_verify", "ts_fri_prove", "ts_fri_verify", "ts_fri_fold", "ts_chal_new", "ts_chal_clone",
+    "ts_quotient_chunks", "ts_pcs_open_reduce", "ts_pcs_open", "ts_pcs_verify", "ts_fri_prove", "ts_fri_verify", "ts_fri_fold", "ts_fri_fold_device", "ts_chal_new", "ts_chal_clone",
     "ts_chal_free", "ts_chal_observe", "ts_chal_observe_commitment", "ts_chal_sample",
     "ts_chal_sample_bits", "ts_chal_check_witness", "ts_chal_grind", "ts_chal_state", "ts_prove", "ts_prove_sharded", "ts_verify", "ts_check_constraints",
     "ts_proof_to_postcard", "ts_proof_from_postcard", "ts_proof_from_postcard_v",
@@ -160,6 +160,7 @@ def lib() -> C.CDLL:
         l.ts_fri_verify.argtypes = [C.POINTER(FriConfigC), C.c_void_p, u32p, C.c_size_t,
                                     C.POINTER(C.c_int)]
         l.ts_fri_fold.argtypes = [C.c_void_p, u32p, C.c_uint64, u32p, u32p]
+        l.ts_fri_fold_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, u32p, C.c_void_p]
         l.ts_prove.argtypes = [C.c_void_p, C.POINTER(FriConfigC), C.c_void_p, C.c_void_p, C.c_void_p,
                                u32p, C.c_uint32, u32p, C.c_size_t, C.POINTER(C.c_size_t)]
         l.ts_prove_sharded.argtypes = [C.c_void_p, C.POINTER(FriConfigC), C.POINTER(CommC), C.c_void_p,

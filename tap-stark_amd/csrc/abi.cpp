@@ -597,6 +597,16 @@ ts_status ts_fri_fold(ts_ctx* ctx, const uint32_t* in, uint64_t h, const uint32_
     });
 }
 
+ts_status ts_fri_fold_device(ts_ctx* ctx, const uint32_t* in_dev, uint64_t h, const uint32_t beta[4],
+                             uint32_t* out_dev) {
+    if (!ctx || !in_dev || !beta || !out_dev || h == 0) return TS_ERR_INVALID;
+    if (((uintptr_t)in_dev | (uintptr_t)out_dev) & 15) return TS_ERR_INVALID;  // EF4 = 16-byte accesses
+    return guard(ctx, [&] {
+        ts::launch_fri_fold(ctx->ctx, reinterpret_cast<const ts::Ef*>(in_dev), h, load_ef(beta),
+                            reinterpret_cast<ts::Ef*>(out_dev), nullptr);
+    });
+}
+
 // ------------------------------------------------------------------ challenger
 ts_status ts_chal_new(int permutation, int sample_ext, ts_challenger** out) {
     if (!out || (permutation != 0 && permutation != 1)) return TS_ERR_INVALID;

@@ -9,16 +9,25 @@
 //                    transform, writing coset block beta -- the coefficients never touch HBM
 //   k_lde_fwd_contig stages sA .. log_n-1 of the forward transform, in place on 4096-element chunks
 // For n <= 4096 k_lde_mid alone does everything.
+//
+// The contiguous chunk is 2^LM elements, LM = 12 by default.  For n = 2^21 and 2^22 it grows to
+// 2^13 / 2^14 (LM = log_n - 8) so that the strided pass keeps the shape it has at n = 2^20 -- 8
+// strided stages on 256-row x 128-byte tiles, two 512-thread workgroups per CU, one LDS round per
+// coset (PLAN 1) -- instead of 9 / 10 stages on tiles whose rows are 64 bytes wide and whose
+// 1024-thread workgroup has a CU to itself (round 2, 2^22 x 64 at log_blowup 4: that pass ran at VALU
+// busy 0.67 with 44 % of its wave-cycles parked at barriers and scale-table loads).  The extra one
+// or two stages go to the contiguous passes as radix-32 register rounds (13 = 5+4+4, 14 = 5+5+4):
+// still three LDS round trips per chunk.
 #include <stdlib.h>
 
 #include "kernels.hpp"
 
 namespace ts {
 
-constexpr int LOG_M = 12;          // contiguous chunk = 4096 elements
-constexpr int CHUNK = 1 << LOG_M;
-constexpr int NT = 256;            // threads per workgroup, contiguous kernels
+constexpr int LOG_M = 12;          // default contiguous chunk = 4096 elements
 constexpr int NT_MID = 512;        // threads per workgroup, middle kernel
+// threads per workgroup of the contiguous kernels: 16 elements per thread at LM = 12, 32 above
+constexpr int chunk_threads(int lm) { return lm == 14 ? 512 : 256; }
 constexpr int TILE_ELEMS = 8192;   // strided tile (generic plan)
 
 __device__ __forceinline__ uint32_t pad(uint32_t i) { return i + (i >> 4); }
@@ -189,18 +198,23 @@ __device__ __forceinline__ void tile_inverse_rt(uint32_t* s, unsigned log_len, u
 }
 
 // ------------------------------------------------------------------ contiguous passes (static plan)
-// 4096-element chunk, 12 stages = 3 radix-16 rounds with last-stage distances 256, 16, 1.
+// 2^LM-element chunk: LM = 12: 3 radix-16 rounds (last-stage distances 256, 16, 1); LM = 13: radix-32
+// (distance 256), radix-16 (16), radix-16 (1); LM = 14: radix-32 (512), radix-32 (16), radix-16 (1).
+template <int LM>
 __device__ __forceinline__ void chunk_load(uint32_t* s, const uint32_t* __restrict__ g) {
+    constexpr int NT = chunk_threads(LM);
     const uint4* g4 = reinterpret_cast<const uint4*>(g);
+    uint4 v[(1 << LM) / 4 / NT];
 #pragma unroll
-    for (int k = 0; k < CHUNK / 4 / NT; k++) {
+    for (int k = 0; k < (1 << LM) / 4 / NT; k++) v[k] = g4[threadIdx.x + (uint32_t)k * NT];
+#pragma unroll
+    for (int k = 0; k < (1 << LM) / 4 / NT; k++) {
         const uint32_t i4 = threadIdx.x + (uint32_t)k * NT;
-        const uint4 v = g4[i4];
         const uint32_t a = 4 * i4 + (i4 >> 2);  // pad(4*i4); the 4 words stay inside one 16-group
-        s[a] = v.x;
-        s[a + 1] = v.y;
-        s[a + 2] = v.z;
-        s[a + 3] = v.w;
+        s[a] = v[k].x;
+        s[a + 1] = v[k].y;
+        s[a + 2] = v[k].z;
+        s[a + 3] = v[k].w;
     }
     __syncthreads();
 }
@@ -208,11 +222,12 @@ __device__ __forceinline__ void chunk_load(uint32_t* s, const uint32_t* __restri
 // Between the passes of one transform the next pass reduces its inputs anyway (red2p on `a`, a
 // product with b < 2p is still < p 2^32), so intermediate images stay lazy: 2 VALU instructions per
 // element less, in kernels that are bound by VALU issue.
-template <bool CANON>
+template <int LM, bool CANON>
 __device__ __forceinline__ void chunk_store(const uint32_t* s, uint32_t* __restrict__ g) {
+    constexpr int NT = chunk_threads(LM);
     uint4* g4 = reinterpret_cast<uint4*>(g);
 #pragma unroll
-    for (int k = 0; k < CHUNK / 4 / NT; k++) {
+    for (int k = 0; k < (1 << LM) / 4 / NT; k++) {
         const uint32_t i4 = threadIdx.x + (uint32_t)k * NT;
         const uint32_t a = 4 * i4 + (i4 >> 2);
         if (CANON)
@@ -222,36 +237,88 @@ __device__ __forceinline__ void chunk_store(const uint32_t* s, uint32_t* __restr
     }
 }
 
-// chunk `c` of column blockIdx.y: global stages log_n-1 .. log_n-12 of the inverse (n > 4096)
-__global__ void __launch_bounds__(NT)
-k_intt_contig(uint32_t* __restrict__ data, uint64_t col_stride, unsigned log_n,
-              const uint32_t* __restrict__ Winv) {
-    __shared__ uint32_t s[padded(CHUNK)];
-    const uint32_t c = blockIdx.x;
-    uint32_t* g = data + (uint64_t)blockIdx.y * col_stride + ((uint64_t)c << LOG_M);
-    chunk_load(s, g);
-    const unsigned sb = log_n - LOG_M;
-    radix_round<4, true, 0, NT>(s, LOG_M, 8, sb, c, Winv);
-    radix_round<4, true, 4, NT>(s, LOG_M, 4, sb, c, Winv);
-    radix_round<4, true, 8, NT>(s, LOG_M, 0, sb, c, Winv);
-    chunk_store<false>(s, g);  // read next by k_lde_mid's inverse rounds
+// the LM local stages of a chunk, forward (u = 0 .. LM-1) or inverse (backwards)
+template <int LM, bool INV>
+__device__ __forceinline__ void chunk_rounds(uint32_t* s, unsigned sb, uint32_t c, const uint32_t* __restrict__ W) {
+    constexpr int NT = chunk_threads(LM);
+    constexpr int K0 = LM == 12 ? 4 : 5;   // stages 0 .. K0-1, distance 2^(LM - K0)
+    constexpr int K1 = LM == 14 ? 5 : 4;   // stages K0 .. K0+K1-1, distance 16
+    static_assert(K0 + K1 + 4 == LM, "chunk plan");
+    if (!INV) {
+        radix_round<K0, false, LM - K0, NT>(s, LM, 0, sb, c, W);
+        radix_round<K1, false, 4, NT>(s, LM, K0, sb, c, W);
+        radix_round<4, false, 0, NT>(s, LM, K0 + K1, sb, c, W);
+    } else {
+        radix_round<4, true, 0, NT>(s, LM, K0 + K1, sb, c, W);
+        radix_round<K1, true, 4, NT>(s, LM, K0, sb, c, W);
+        radix_round<K0, true, LM - K0, NT>(s, LM, 0, sb, c, W);
+    }
 }
 
-// in place on chunk `c` of coset block `beta` of column blockIdx.y: forward stages sA .. log_n-1
-__global__ void __launch_bounds__(NT)
+// chunk `c` of column blockIdx.y: global stages log_n-1 .. log_n-LM of the inverse (n > 2^LM)
+template <int LM>
+__global__ void __launch_bounds__(chunk_threads(LM))
+k_intt_contig(uint32_t* __restrict__ data, uint64_t col_stride, unsigned log_n,
+              const uint32_t* __restrict__ Winv) {
+    __shared__ uint32_t s[padded(1 << LM)];
+    const uint32_t c = blockIdx.x;
+    uint32_t* g = data + (uint64_t)blockIdx.y * col_stride + ((uint64_t)c << LM);
+    chunk_load<LM>(s, g);
+    chunk_rounds<LM, true>(s, log_n - LM, c, Winv);
+    chunk_store<LM, false>(s, g);  // read next by k_lde_mid's inverse rounds
+}
+
+// in place on chunk `c` of coset block `beta` of column blockIdx.y: forward stages sA .. log_n-1.
+// CPW > 1: a workgroup takes CPW consecutive chunks and loads chunk i+1 into registers while the
+// rounds of chunk i run (the 16384-element chunk leaves room for two workgroups per CU only, and with
+// 16 waves per CU nothing else covers a chunk's load latency: rocprofv3 SQ counters on 2^22 x 64,
+// log_blowup 4 showed VALU busy 0.86 with 28 % of the wave-cycles parked).
+template <int LM, int CPW = 1>
+__global__ void __launch_bounds__(chunk_threads(LM), CPW > 1 ? 4 : 1)  // CPW > 1: keep two 512-thread groups per CU
 k_lde_fwd_contig(uint32_t* __restrict__ out, uint64_t out_col_stride, unsigned log_n,
                  const uint32_t* __restrict__ W) {
-    __shared__ uint32_t s[padded(CHUNK)];
-    const uint32_t c = blockIdx.x;
+    __shared__ uint32_t s[padded(1 << LM)];
+    constexpr int NT = chunk_threads(LM);
+    constexpr int NV = (1 << LM) / 4 / NT;
     const uint32_t beta = blockIdx.z;
-    uint32_t* o = out + (uint64_t)blockIdx.y * out_col_stride + ((uint64_t)beta << log_n) +
-                  ((uint64_t)c << LOG_M);
-    chunk_load(s, o);
-    const unsigned sb = log_n - LOG_M;
-    radix_round<4, false, 8, NT>(s, LOG_M, 0, sb, c, W);
-    radix_round<4, false, 4, NT>(s, LOG_M, 4, sb, c, W);
-    radix_round<4, false, 0, NT>(s, LOG_M, 8, sb, c, W);
-    chunk_store<true>(s, o);
+    uint32_t* col = out + (uint64_t)blockIdx.y * out_col_stride + ((uint64_t)beta << log_n);
+    if constexpr (CPW == 1) {
+        const uint32_t c = blockIdx.x;
+        uint32_t* o = col + ((uint64_t)c << LM);
+        chunk_load<LM>(s, o);
+        chunk_rounds<LM, false>(s, log_n - LM, c, W);
+        chunk_store<LM, true>(s, o);
+    } else {
+        const uint32_t c0 = blockIdx.x * CPW;
+        uint4 v[NV];
+        {
+            const uint4* g4 = reinterpret_cast<const uint4*>(col + ((uint64_t)c0 << LM));
+#pragma unroll
+            for (int k = 0; k < NV; k++) v[k] = g4[threadIdx.x + (uint32_t)k * NT];
+        }
+#pragma unroll 1
+        for (int i = 0; i < CPW; i++) {
+            const uint32_t c = c0 + i;
+#pragma unroll
+            for (int k = 0; k < NV; k++) {
+                const uint32_t i4 = threadIdx.x + (uint32_t)k * NT;
+                const uint32_t a = 4 * i4 + (i4 >> 2);
+                s[a] = v[k].x;
+                s[a + 1] = v[k].y;
+                s[a + 2] = v[k].z;
+                s[a + 3] = v[k].w;
+            }
+            __syncthreads();
+            if (i + 1 < CPW) {
+                const uint4* g4 = reinterpret_cast<const uint4*>(col + ((uint64_t)(c + 1) << LM));
+#pragma unroll
+                for (int k = 0; k < NV; k++) v[k] = g4[threadIdx.x + (uint32_t)k * NT];
+            }
+            chunk_rounds<LM, false>(s, log_n - LM, c, W);
+            chunk_store<LM, true>(s, col + ((uint64_t)c << LM));
+            __syncthreads();  // the image is rewritten at the top of the loop
+        }
+    }
 }
 
 // ------------------------------------------------------------------ middle kernel
@@ -259,10 +326,11 @@ k_lde_fwd_contig(uint32_t* __restrict__ out, uint64_t out_col_stride, unsigned l
 // (row_shift = LOG_M for n > 4096, where rows are 4096 apart; 0 for n <= 4096 with log_T = 0, where
 // the tile is the whole column).  Finishes the inverse transform (stages log_len-1 .. 0), then for
 // each coset: scaled copy -> forward stages 0 .. log_len-1 -> block beta of `out`.
-// PLAN 0: generic (runtime round plan).  PLAN 1: log_len = 8, log_T = 5 (n = 2^20): two radix-16
-// rounds with compile-time distances 2^9 and 2^5.  PLAN 2: log_len = 10 (n = 2^22), rounds of 4, 3
+// PLAN 0: generic (runtime round plan).  PLAN 1: log_len = 8, log_T = 5 (n = 2^(LM + 8): 2^20 with
+// 4096-element chunks, 2^21 / 2^22 with LM = 13 / 14): two radix-16 rounds with compile-time
+// distances 2^9 and 2^5.  PLAN 2: log_len = 10 (n = 2^22), rounds of 4, 3
 // and 3 stages with compile-time distances; TILE elements per workgroup (log_T = log2(TILE) - 10).
-template <int PLAN, int TILE = TILE_ELEMS, int NTM = NT_MID>
+template <int PLAN, int TILE = TILE_ELEMS, int NTM = NT_MID, int LM = LOG_M>
 __global__ void __launch_bounds__(NTM)
 k_lde_mid(const uint32_t* __restrict__ evals, uint64_t in_col_stride, uint32_t* __restrict__ out,
           uint64_t out_col_stride, unsigned log_n, unsigned log_len, unsigned log_T,
@@ -291,8 +359,8 @@ k_lde_mid(const uint32_t* __restrict__ evals, uint64_t in_col_stride, uint32_t* 
         // a multiple of the 8 XCDs -- on the same XCD, so its L2 serves the slice to every column
         // instead of the Infinity Cache (measured fetch + write traffic 1.39x -> 1.11x of the
         // algorithmic bytes, same kernel time, 3.03-3.06 -> 3.00 ms/step for whole proofs)
-        const uint32_t ncols = gridDim.x >> 7;  // 2^(LOG_M - 5) = 128 tiles per column
-        bx = (blockIdx.x & 31) + 32 * (blockIdx.x / (32 * ncols));  // < 128
+        const uint32_t ncols = gridDim.x >> (LM - 5);  // 2^(LM - 5) tiles per column (128 at LM = 12)
+        bx = (blockIdx.x & 31) + 32 * (blockIdx.x / (32 * ncols));  // < 2^(LM - 5)
         col_id = (blockIdx.x >> 5) % ncols;
     }
     if constexpr (PLAN == 2) {
@@ -366,6 +434,22 @@ k_lde_mid(const uint32_t* __restrict__ evals, uint64_t in_col_stride, uint32_t* 
     }
     // cosets beta0 .. beta0 + n_cosets - 1 go to blocks 0 .. n_cosets - 1 of `out` (a rank of a
     // sharded prover owns a contiguous range of cosets)
+    // PLAN 1: the 16 scale-table entries of the NEXT coset are loaded while this coset is computed
+    // (the table of a big shape -- 268 MB at 2^22 rows, log_blowup 4 -- is served from L2 at best, and
+    // with one LDS round per coset there is little else to hide that latency behind): 16 more VGPRs
+    // (109 -> 125, still two workgroups per CU).
+    // (nontemporal stores of the coset blocks, to keep the table slices in L2, changed nothing at
+    // 2^22 x 64, log_blowup 4: 7.92 against 7.90 ms per launch.)
+    constexpr bool PREFETCH = PLAN == 1;
+    uint32_t scv[PREFETCH ? 16 : 1];
+    const uint32_t* scp = nullptr;  // this thread's first entry in coset block 0 of the table
+    if constexpr (PREFETCH) {
+        const uint32_t i0 = threadIdx.x;
+        scp = scale + ((uint64_t)(i0 >> 5) << LM) + (i0 & 31) + j2_0;
+#pragma unroll
+        for (int q = 0; q < 16; q++)
+            scv[q] = (scp + ((uint64_t)beta0 << log_n))[(uint64_t)q * (NTM >> 5) << LM];
+    }
     for (uint32_t bl = 0; bl < n_cosets; bl++) {
         const uint32_t beta = beta0 + bl;
         const uint32_t* sc = scale + ((uint64_t)beta << log_n);  // s_beta^k / n, one entry per coefficient
@@ -380,8 +464,16 @@ k_lde_mid(const uint32_t* __restrict__ evals, uint64_t in_col_stride, uint32_t* 
 #pragma unroll
                 for (int q = 0; q < 16; q++) {
                     const uint32_t i = threadIdx.x + (uint32_t)(j + GP * q) * NTM;
-                    const uint32_t kk = ((i >> LT) << LOG_M) + (i & ((1u << LT) - 1)) + j2_0;
-                    v[q] = mont_mul(coef[j + GP * q], sc[kk]);
+                    const uint32_t kk = ((i >> LT) << LM) + (i & ((1u << LT) - 1)) + j2_0;
+                    if constexpr (PREFETCH) v[q] = mont_mul(coef[j + GP * q], scv[q]);
+                    else v[q] = mont_mul(coef[j + GP * q], sc[kk]);
+                }
+                if constexpr (PREFETCH) {
+                    if (bl + 1 < n_cosets) {
+                        const uint32_t* nx = scp + ((uint64_t)(beta + 1) << log_n);
+#pragma unroll
+                        for (int q = 0; q < 16; q++) scv[q] = nx[(uint64_t)q * (NTM >> 5) << LM];
+                    }
                 }
                 radix_butterflies<4, false, true>(v, 0, 0, 0, 0, W);
 #pragma unroll
@@ -400,9 +492,9 @@ k_lde_mid(const uint32_t* __restrict__ evals, uint64_t in_col_stride, uint32_t* 
                 uint32_t t[PER_THREAD];
 #pragma unroll
                 for (int k = 0; k < PER_THREAD; k++) t[k] = s[pad(threadIdx.x + (uint32_t)k * NTM)];
-                uint32_t* ot = og + ((uint64_t)(threadIdx.x >> 5) << LOG_M) + (threadIdx.x & 31);
+                uint32_t* ot = og + ((uint64_t)(threadIdx.x >> 5) << LM) + (threadIdx.x & 31);
 #pragma unroll
-                for (int k = 0; k < PER_THREAD; k++) ot[(uint64_t)k * (NTM >> 5) << LOG_M] = t[k];
+                for (int k = 0; k < PER_THREAD; k++) ot[(uint64_t)k * (NTM >> 5) << LM] = t[k];
             } else {
                 radix_round<3, false, LOG_TILE - 7, NTM>(s, LOG_TILE, 4, 0, 0, W);
                 radix_round_fwd_to_global<3, LOG_TILE - 10, NTM>(s, LOG_TILE, 7, W, og, LOG_TILE - 10, LOG_M);
@@ -439,8 +531,16 @@ void coset_lde(Context& ctx, uint32_t* evals, uint64_t in_col_stride, uint32_t n
     if (ncols == 0) return;
     TS_REQUIRE(log_n + log_blowup <= 27, TS_ERR_INVALID, "coset_lde: log_n + log_blowup > 27");
     TS_REQUIRE(ncols >= 1 && ncols <= 65535, TS_ERR_INVALID, "coset_lde: bad column count");
-    const bool two_pass = log_n > (unsigned)LOG_M;
-    const unsigned sA = two_pass ? log_n - LOG_M : 0;  // stages done by the strided (middle) kernel
+    // chunk size of the contiguous passes: 2^12, or log_n - 8 for n = 2^21 / 2^22 (header comment);
+    // TS_LDE_LM=12 forces the round-2 plans for an A/B
+    static const int lm_env = [] {
+        const char* e = getenv("TS_LDE_LM");
+        return e ? atoi(e) : 0;
+    }();
+    unsigned LM = LOG_M;
+    if ((log_n == 21 || log_n == 22) && lm_env != 12) LM = log_n - 8;
+    const bool two_pass = log_n > LM;
+    const unsigned sA = two_pass ? log_n - LM : 0;  // stages done by the strided (middle) kernel
     // sA <= 13 fits the 8192-element tile; sA = 14 (n = 2^26, the longest trace a blowup of 2 leaves
     // room for below the two-adicity 27) takes a 16384-element tile (68 KB of LDS)
     TS_REQUIRE(sA <= 14, TS_ERR_INVALID, "coset_lde: log_n > 26");
@@ -480,18 +580,23 @@ void coset_lde(Context& ctx, uint32_t* evals, uint64_t in_col_stride, uint32_t n
             // (stage names: the sharded prover reports where a rank's time goes; this part is per
             // column, so it can be sharded by columns -- ShardOptions::column_sharded_inverse)
             StageTimer t(&ctx, "lde: inverse NTT, contiguous stages");
-            TS_LAUNCH(ctx, k_intt_contig, dim3(1u << sA, ncols), dim3(NT), 0, evals, in_col_stride, log_n,
-                      Winv);
+            const dim3 g(1u << sA, ncols);
+            if (LM == 12)
+                TS_LAUNCH(ctx, k_intt_contig<12>, g, dim3(chunk_threads(12)), 0, evals, in_col_stride, log_n, Winv);
+            else if (LM == 13)
+                TS_LAUNCH(ctx, k_intt_contig<13>, g, dim3(chunk_threads(13)), 0, evals, in_col_stride, log_n, Winv);
+            else
+                TS_LAUNCH(ctx, k_intt_contig<14>, g, dim3(chunk_threads(14)), 0, evals, in_col_stride, log_n, Winv);
         }
         if (phase == LDE_INVERSE_CONTIG) {
             TS_HIP(hipGetLastError());
             return;
         }
         StageTimer t_rest(&ctx, "lde: strided pass + forward NTT of the owned cosets");
-        const dim3 grid(1u << (LOG_M - log_T), ncols);
-        const dim3 grid1((1u << (LOG_M - log_T)) * ncols);  // PLAN 2: 1-D, see the kernel
+        const dim3 grid(1u << (LM - log_T), ncols);
+        const dim3 grid1((1u << (LM - log_T)) * ncols);  // PLAN 1 / 2: 1-D, see the kernel
 #define TS_MID_ARGS                                                                            \
-    (const uint32_t*)evals, in_col_stride, out, out_col_stride, log_n, sA, log_T, (unsigned)LOG_M, \
+    (const uint32_t*)evals, in_col_stride, out, out_col_stride, log_n, sA, log_T, (unsigned)LM, \
         beta0, n_beta, W, Winv, scale
         if (sA == 14)
             TS_LAUNCH(ctx, (k_lde_mid<0, 16384>), grid, dim3(NT_MID), 0, TS_MID_ARGS);
@@ -503,16 +608,32 @@ void coset_lde(Context& ctx, uint32_t* evals, uint64_t in_col_stride, uint32_t n
             TS_LAUNCH(ctx, (k_lde_mid<2, 16384>), grid1, dim3(NT_MID), 0, TS_MID_ARGS);
         else if (plan2)
             TS_LAUNCH(ctx, (k_lde_mid<2, 32768, 1024>), grid1, dim3(1024), 0, TS_MID_ARGS);
-        else if (sA == 8 && log_T == 5)
-            TS_LAUNCH(ctx, k_lde_mid<1>, dim3((1u << (LOG_M - 5)) * ncols), dim3(NT_MID), 0, (const uint32_t*)evals, in_col_stride,
-                      out, out_col_stride, log_n, sA, log_T, (unsigned)LOG_M, beta0, n_beta, W, Winv,
-                      scale);
+        else if (sA == 8 && log_T == 5 && LM == 12)
+            TS_LAUNCH(ctx, k_lde_mid<1>, grid1, dim3(NT_MID), 0, TS_MID_ARGS);
+        else if (sA == 8 && log_T == 5 && LM == 13)
+            TS_LAUNCH(ctx, (k_lde_mid<1, 8192, 512, 13>), grid1, dim3(NT_MID), 0, TS_MID_ARGS);
+        else if (sA == 8 && log_T == 5 && LM == 14)
+            TS_LAUNCH(ctx, (k_lde_mid<1, 8192, 512, 14>), grid1, dim3(NT_MID), 0, TS_MID_ARGS);
         else
-            TS_LAUNCH(ctx, k_lde_mid<0>, grid, dim3(NT_MID), 0, (const uint32_t*)evals, in_col_stride,
-                      out, out_col_stride, log_n, sA, log_T, (unsigned)LOG_M, beta0, n_beta, W, Winv,
-                      scale);
-        TS_LAUNCH(ctx, k_lde_fwd_contig, dim3(1u << sA, ncols, n_beta), dim3(NT), 0, out,
-                  out_col_stride, log_n, W);
+            TS_LAUNCH(ctx, k_lde_mid<0>, grid, dim3(NT_MID), 0, TS_MID_ARGS);
+        const dim3 gf(1u << sA, ncols, n_beta);
+        static const int fwd_cpw = [] {  // chunks per workgroup of the 16384-element forward pass (1, 2, 4)
+            const char* e = getenv("TS_LDE_FWD_CPW");
+            const int v = e ? atoi(e) : 4;  // measured 12.49 (1) / 13.34 (2: spills) / 12.22 ms (4) per proof
+            return v == 1 || v == 2 ? v : 4;
+        }();
+        if (LM == 12)
+            TS_LAUNCH(ctx, k_lde_fwd_contig<12>, gf, dim3(chunk_threads(12)), 0, out, out_col_stride, log_n, W);
+        else if (LM == 13)
+            TS_LAUNCH(ctx, k_lde_fwd_contig<13>, gf, dim3(chunk_threads(13)), 0, out, out_col_stride, log_n, W);
+        else if (fwd_cpw == 1)
+            TS_LAUNCH(ctx, k_lde_fwd_contig<14>, gf, dim3(chunk_threads(14)), 0, out, out_col_stride, log_n, W);
+        else if (fwd_cpw == 2)
+            TS_LAUNCH(ctx, (k_lde_fwd_contig<14, 2>), dim3(gf.x / 2, gf.y, gf.z), dim3(chunk_threads(14)), 0, out,
+                      out_col_stride, log_n, W);
+        else
+            TS_LAUNCH(ctx, (k_lde_fwd_contig<14, 4>), dim3(gf.x / 4, gf.y, gf.z), dim3(chunk_threads(14)), 0, out,
+                      out_col_stride, log_n, W);
     } else if (phase != LDE_INVERSE_CONTIG) {
         TS_LAUNCH(ctx, k_lde_mid<0>, dim3(1, ncols), dim3(NT_MID), 0, (const uint32_t*)evals,
                   in_col_stride, out, out_col_stride, log_n, log_n, 0u, 0u, beta0, n_beta, W, Winv, scale);

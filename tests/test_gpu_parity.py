@@ -40,7 +40,9 @@ def bitrev_perm(bits):
 # ------------------------------------------------------------------ commit: LDE + Merkle
 @pytest.mark.parametrize("log_n,w,log_blowup", [(0, 1, 1), (1, 2, 2), (3, 2, 2), (5, 7, 1), (6, 64, 2),
                                                 (10, 64, 2), (12, 5, 2), (13, 3, 2), (14, 64, 2),
-                                                (16, 2, 3), (11, 163, 2), (22, 1, 1)])
+                                                (16, 2, 3), (11, 163, 2), (22, 1, 1),
+                                                # 2^21 / 2^22: 8192- / 16384-element chunks (radix-32 rounds)
+                                                (21, 2, 2), (22, 2, 2), (21, 1, 4)])
 def test_commit_lde_and_merkle(ctx, orc, log_n, w, log_blowup):
     pcs = ts.TwoAdicFriPcs(ts.FriConfig(log_blowup, 4, 8), ctx)
     m = rand_mat(17 + log_n, 1 << log_n, w)

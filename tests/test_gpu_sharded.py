@@ -342,7 +342,7 @@ def test_local_group_timeout_is_configurable(ctx):
     buf = torch.zeros(64, dtype=torch.uint8, device="cuda:0")
     out = torch.zeros(128, dtype=torch.uint8, device="cuda:0")
     t0 = time.time()
-    rc = c.all_gather(c.user, buf.data_ptr(), out.data_ptr(), 64, ctx.stream())
+    rc = c.all_gather(c.user, buf.data_ptr(), out.data_ptr(), 64, ctx.stream)
     assert rc != 0 and time.time() - t0 < 10
     group.reset()
 
@@ -386,7 +386,7 @@ def test_rccl_native_comm_collective_shapes_of_config4(ctx):
     c = ts.Context(0)
     rc = tc.RcclComm(c, tc.rccl_unique_id(), 0, 1)
     cc = rc.c
-    stream = c.stream()
+    stream = c.stream
     g = torch.Generator(device="cuda:0")
     g.manual_seed(5)
     for nbytes in (128 << 20, 64 << 20, 32, 8 * 32, 16 * 4096, 4 * 21877, 12345, 1):

@@ -156,6 +156,7 @@ def algorithmic_bytes_per_proof(n: int, w: int, b: int, qd: int) -> dict:
     big_fri_elems = sum(2 * h for h in fri_leaves if h > (1 << TREE))
     return {
         "k_transpose_bitrev": 8 * n * w,
+        "k_transpose_bitrev_r16": 8 * n * w,
         "k_intt_contig": 8 * n * wall,
         "k_intt_contig_rm": 8 * n * w,
         "k_lde_mid<1>": 4 * n * wall + 4 * N * wall,
@@ -413,9 +414,9 @@ def main():
                     help="independent proofs in flight per GPU (one context = one HIP stream and one "
                          "host thread each); the K timed steps are shared among them")
     ap.add_argument("--stagger-ms", type=float, default=float(os.environ.get("TS_BENCH_STAGGER_MS", "-1")),
-                    help="lane l enters the timed region l * this many ms after lane 0, so that the lanes "
-                         "run in complementary phases from the first proof on instead of drifting there "
-                         "(-1 = auto: a quarter of one lane's proof period / number of lanes)")
+                    help="minimum spacing between the starts of two proofs on one GPU, so that the lanes run in "
+                         "complementary phases instead of lockstep (-1 = auto: a quarter of the time one "
+                         "proof takes alone, measured before the run; 0 = off)")
     ap.add_argument("--windows", type=int, default=3,
                     help="timed windows of K steps each, back to back; `value` is the FIRST (the contract's "
                          "K steps), the others are reported as spread")
@@ -589,11 +590,34 @@ def main():
                 m = ts.DeviceMatrix.upload(c, host_trace)
             else:
                 m = mats[i] if pregen else make_trace(c)
+            start_gate()
             last["proof"] = ts.prove(conf, ca, ts.BfChallenger(), m, pis)
             if pregen:
                 mats[i] = None  # the matrix handle is spent
 
+    # Start gate: two proofs never start within `stagger` ms of each other.  With every lane starting
+    # at the same instant the S proofs run in lockstep -- all of them in their latency-bound phases
+    # (Merkle tops, FRI rounds) at the same time -- and only drift into complementary phases after a
+    # few proofs (and can drift back: whole windows 10 % slower were seen).  Spacing the starts puts
+    # the lanes in complementary phases from the first proof on and keeps them there; the spacing is
+    # well under the steady-state distance between starts (one step), so it does not throttle, and
+    # the first lane starts at once (a proof alone fills the chip in its long kernels).
     stagger = {"ms": 0.0}
+    gate_lock = threading.Lock()
+    gate_last = [-1e9]
+
+    def start_gate():
+        d = stagger["ms"] * 1e-3
+        if d <= 0:
+            return
+        with gate_lock:
+            while True:
+                wait = gate_last[0] + d - time.perf_counter()
+                if wait <= 0:
+                    break
+                time.sleep(min(wait, 2e-4))
+            gate_last[0] = time.perf_counter()
+
     if S == 1:
         step = prove_one
         run_steps = None
@@ -603,19 +627,8 @@ def main():
         step = prove_one
 
         def run_steps(first, count):
-            # lane l proves steps first+l, first+l+S, ... in its own thread (ctypes drops the GIL).
-            # Staggered entry: with every lane starting at the same instant the S proofs run in
-            # lockstep -- all of them in their latency-bound phases (Merkle tops, FRI rounds) at the
-            # same time -- and only drift into complementary phases after a few proofs; entering
-            # lane l a little later puts the lanes there from the first proof on.  Lane 0 starts at
-            # once, and a proof alone fills the chip in its long kernels, so nothing idles meanwhile.
-            t_start = time.perf_counter()
-
+            # lane l proves steps first+l, first+l+S, ... in its own thread (ctypes drops the GIL)
             def lane_job(l):
-                delay = l * stagger["ms"] * 1e-3
-                if delay > 0 and first + l < first + count:
-                    while time.perf_counter() - t_start < delay:
-                        time.sleep(min(2e-4, max(0.0, delay - (time.perf_counter() - t_start))))
                 for i in range(first + l, first + count, S):
                     prove_one(i)
             list(pool.map(lane_job, range(S)))
@@ -686,8 +699,7 @@ def main():
                        "parallelism": (f"{n_groups} group(s) of {gsize} GPU(s), one proof sharded over each group, "
                                         f"collectives over {comm.backend}" if sharded else
                                        ("1 rank per GPU (replicas)" if env.world > 1 else "1 GPU")
-                                       + f", {S} proofs in flight per GPU, lane l entering the timed region "
-                                         f"{stagger['ms']:.2f} ms x l after lane 0"),
+                                       + f", {S} proofs in flight per GPU, starts spaced >= {stagger['ms']:.2f} ms"),
                        "quotient_kernel": "hiprtc-specialised" if cair.is_jit else "interpreter",
                        "proof_words": int(len(proof.words))},
             "proofs_per_sec": res["steps_per_sec"],

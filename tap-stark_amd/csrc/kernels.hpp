@@ -28,6 +28,12 @@ const uint32_t* coset_scale_table(Context& ctx, unsigned log_n, unsigned log_blo
 // src_width (0 = w): the row length of `src` when only w of its columns (starting at `src`) are taken
 void launch_transpose_bitrev(Context& ctx, const uint32_t* src, uint32_t* dst, unsigned log_n,
                              uint32_t w, uint64_t dst_col_stride, uint32_t src_width = 0);
+// The same with the first round (four stages) of the inverse transform folded in, for a matrix that
+// goes to coset_lde next (ntt_lde.hip).  Returns false -- and does nothing -- where coset_lde has no
+// contiguous inverse pass to shorten (small n): call launch_transpose_bitrev then; if true, pass
+// first_round_done = true to coset_lde.
+bool launch_transpose_bitrev_r16(Context& ctx, const uint32_t* src, uint32_t* dst, unsigned log_n, uint32_t w,
+                                 uint64_t dst_col_stride, uint32_t src_width = 0);
 // same without the bit reversal (rows stay where they are): BFMmcs::commit on given matrices
 void launch_transpose_plain(Context& ctx, const uint32_t* src, uint32_t* dst, uint64_t n, uint32_t w,
                             uint64_t dst_col_stride);
@@ -45,7 +51,8 @@ void launch_transpose_to_row_major(Context& ctx, const uint32_t* src, uint64_t c
 enum LdePhase { LDE_ALL = 0, LDE_INVERSE_CONTIG = 1, LDE_REST = 2 };
 void coset_lde(Context& ctx, uint32_t* evals, uint64_t in_col_stride, uint32_t ncols, unsigned log_n,
                unsigned log_blowup, uint32_t shift, uint32_t* out, uint64_t out_col_stride,
-               uint32_t beta0 = 0, uint32_t n_beta = 0, LdePhase phase = LDE_ALL);
+               uint32_t beta0 = 0, uint32_t n_beta = 0, LdePhase phase = LDE_ALL,
+               bool first_round_done = false);
 
 // ---- merkle.hip ------------------------------------------------------------------------------
 constexpr int MAX_BATCH_MATS = 64;

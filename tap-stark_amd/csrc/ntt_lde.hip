@@ -238,7 +238,8 @@ __device__ __forceinline__ void chunk_store(const uint32_t* s, uint32_t* __restr
 }
 
 // the LM local stages of a chunk, forward (u = 0 .. LM-1) or inverse (backwards)
-template <int LM, bool INV>
+// SKIP_R16 (inverse only): the round at distance 1 was done by k_transpose_bitrev_r16 already.
+template <int LM, bool INV, bool SKIP_R16 = false>
 __device__ __forceinline__ void chunk_rounds(uint32_t* s, unsigned sb, uint32_t c, const uint32_t* __restrict__ W) {
     constexpr int NT = chunk_threads(LM);
     constexpr int K0 = LM == 12 ? 4 : 5;   // stages 0 .. K0-1, distance 2^(LM - K0)
@@ -249,14 +250,14 @@ __device__ __forceinline__ void chunk_rounds(uint32_t* s, unsigned sb, uint32_t 
         radix_round<K1, false, 4, NT>(s, LM, K0, sb, c, W);
         radix_round<4, false, 0, NT>(s, LM, K0 + K1, sb, c, W);
     } else {
-        radix_round<4, true, 0, NT>(s, LM, K0 + K1, sb, c, W);
+        if (!SKIP_R16) radix_round<4, true, 0, NT>(s, LM, K0 + K1, sb, c, W);
         radix_round<K1, true, 4, NT>(s, LM, K0, sb, c, W);
         radix_round<K0, true, LM - K0, NT>(s, LM, 0, sb, c, W);
     }
 }
 
 // chunk `c` of column blockIdx.y: global stages log_n-1 .. log_n-LM of the inverse (n > 2^LM)
-template <int LM>
+template <int LM, bool SKIP_R16 = false>
 __global__ void __launch_bounds__(chunk_threads(LM))
 k_intt_contig(uint32_t* __restrict__ data, uint64_t col_stride, unsigned log_n,
               const uint32_t* __restrict__ Winv) {
@@ -264,8 +265,49 @@ k_intt_contig(uint32_t* __restrict__ data, uint64_t col_stride, unsigned log_n,
     const uint32_t c = blockIdx.x;
     uint32_t* g = data + (uint64_t)blockIdx.y * col_stride + ((uint64_t)c << LM);
     chunk_load<LM>(s, g);
-    chunk_rounds<LM, true>(s, log_n - LM, c, Winv);
+    chunk_rounds<LM, true, SKIP_R16>(s, log_n - LM, c, Winv);
     chunk_store<LM, false>(s, g);  // read next by k_lde_mid's inverse rounds
+}
+
+// The transpose of a row-major trace (src[r][c], natural rows -> dst[c][p], p = bitrev(r)) with the
+// first round of the inverse transform folded in.  That round works on groups of 16 consecutive p,
+// i.e. on the source rows bitrev(16 G + q): whole 256-byte row pieces whatever the group, so the
+// thread that owns (group, column) loads its 16 values coalesced across the 64 columns of the tile,
+// runs the four stages in registers and hands the results to the 64 x 64 LDS tile the transpose goes
+// through anyway.  The transpose alone is bound by memory (its VALU idles); k_intt_contig then has
+// two rounds and two LDS round trips left instead of three.
+__global__ void __launch_bounds__(256)
+k_transpose_bitrev_r16(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, unsigned log_n,
+                       uint32_t w, uint64_t dst_col_stride, uint32_t src_width,
+                       const uint32_t* __restrict__ Winv) {
+    __shared__ uint32_t tile[64][65];
+    const uint32_t p0 = blockIdx.x << 6;
+    const uint32_t c0 = blockIdx.y * 64;
+    const uint32_t tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    // bitrev(p0 + i) = bitrev(p0) + (bitrev6(i) << (log_n - 6)): p0 is a multiple of 64
+    const uint32_t rb = bitrev32(p0, log_n);
+    const uint64_t row_step = (uint64_t)src_width << (log_n - 6);
+    uint32_t v[16];
+    if (c0 + tx < w) {
+        const uint32_t* sp = src + (uint64_t)rb * src_width + c0 + tx;
+#pragma unroll
+        for (int q = 0; q < 16; q++) v[q] = sp[(uint64_t)(__brev(16 * ty + (uint32_t)q) >> 26) * row_step];
+    } else {
+#pragma unroll
+        for (int q = 0; q < 16; q++) v[q] = 0;
+    }
+    // global stages log_n-1 .. log_n-4 on group (p0 >> 4) + ty (lazy [0, 2p) values out)
+    radix_butterflies<4, true, false>(v, log_n - 4, 0, 0, (p0 >> 4) + ty, Winv);
+#pragma unroll
+    for (int q = 0; q < 16; q++) tile[16 * ty + q][tx] = v[q];
+    __syncthreads();
+    uint32_t t[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) t[k] = tile[tx][ty + 4 * k];
+    uint32_t* dp = dst + (uint64_t)(c0 + ty) * dst_col_stride + p0 + tx;
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        if (c0 + ty + 4 * k < w) dp[(uint64_t)(4 * k) * dst_col_stride] = t[k];
 }
 
 // in place on chunk `c` of coset block `beta` of column blockIdx.y: forward stages sA .. log_n-1.
@@ -525,20 +567,35 @@ k_lde_mid(const uint32_t* __restrict__ evals, uint64_t in_col_stride, uint32_t* 
 }
 
 // ------------------------------------------------------------------ host driver
-void coset_lde(Context& ctx, uint32_t* evals, uint64_t in_col_stride, uint32_t ncols, unsigned log_n,
-               unsigned log_blowup, uint32_t shift, uint32_t* out, uint64_t out_col_stride,
-               uint32_t beta0, uint32_t n_beta, LdePhase phase) {
-    if (ncols == 0) return;
-    TS_REQUIRE(log_n + log_blowup <= 27, TS_ERR_INVALID, "coset_lde: log_n + log_blowup > 27");
-    TS_REQUIRE(ncols >= 1 && ncols <= 65535, TS_ERR_INVALID, "coset_lde: bad column count");
-    // chunk size of the contiguous passes: 2^12, or log_n - 8 for n = 2^21 / 2^22 (header comment);
-    // TS_LDE_LM=12 forces the round-2 plans for an A/B
+// chunk size of the contiguous passes: 2^12, or log_n - 8 for n = 2^21 / 2^22 (header comment);
+// TS_LDE_LM=12 forces the round-2 plans for an A/B
+static unsigned lde_chunk_log(unsigned log_n) {
     static const int lm_env = [] {
         const char* e = getenv("TS_LDE_LM");
         return e ? atoi(e) : 0;
     }();
-    unsigned LM = LOG_M;
-    if ((log_n == 21 || log_n == 22) && lm_env != 12) LM = log_n - 8;
+    return ((log_n == 21 || log_n == 22) && lm_env != 12) ? log_n - 8 : (unsigned)LOG_M;
+}
+
+bool launch_transpose_bitrev_r16(Context& ctx, const uint32_t* src, uint32_t* dst, unsigned log_n, uint32_t w,
+                                 uint64_t dst_col_stride, uint32_t src_width) {
+    static const bool off = getenv("TS_LDE_NO_FUSED_TRANSPOSE") != nullptr;  // A/B
+    if (off || w == 0 || log_n <= lde_chunk_log(log_n)) return false;  // no contiguous inverse pass to shorten
+    ctx.ensure_twiddles(log_n);
+    TS_LAUNCH(ctx, k_transpose_bitrev_r16, dim3(1u << (log_n - 6), (w + 63) / 64), dim3(256), 0, src, dst, log_n, w,
+              dst_col_stride, src_width ? src_width : w, (const uint32_t*)ctx.d_twiddle_inv);
+    TS_HIP(hipGetLastError());
+    return true;
+}
+
+void coset_lde(Context& ctx, uint32_t* evals, uint64_t in_col_stride, uint32_t ncols, unsigned log_n,
+               unsigned log_blowup, uint32_t shift, uint32_t* out, uint64_t out_col_stride,
+               uint32_t beta0, uint32_t n_beta, LdePhase phase, bool first_round_done) {
+    if (ncols == 0) return;
+    TS_REQUIRE(log_n + log_blowup <= 27, TS_ERR_INVALID, "coset_lde: log_n + log_blowup > 27");
+    TS_REQUIRE(ncols >= 1 && ncols <= 65535, TS_ERR_INVALID, "coset_lde: bad column count");
+    const unsigned LM = lde_chunk_log(log_n);
+    TS_REQUIRE(!first_round_done || log_n > LM, TS_ERR_INVARIANT, "coset_lde: no contiguous inverse pass at this size");
     const bool two_pass = log_n > LM;
     const unsigned sA = two_pass ? log_n - LM : 0;  // stages done by the strided (middle) kernel
     // sA <= 13 fits the 8192-element tile; sA = 14 (n = 2^26, the longest trace a blowup of 2 leaves
@@ -581,12 +638,18 @@ void coset_lde(Context& ctx, uint32_t* evals, uint64_t in_col_stride, uint32_t n
             // column, so it can be sharded by columns -- ShardOptions::column_sharded_inverse)
             StageTimer t(&ctx, "lde: inverse NTT, contiguous stages");
             const dim3 g(1u << sA, ncols);
-            if (LM == 12)
-                TS_LAUNCH(ctx, k_intt_contig<12>, g, dim3(chunk_threads(12)), 0, evals, in_col_stride, log_n, Winv);
-            else if (LM == 13)
-                TS_LAUNCH(ctx, k_intt_contig<13>, g, dim3(chunk_threads(13)), 0, evals, in_col_stride, log_n, Winv);
-            else
-                TS_LAUNCH(ctx, k_intt_contig<14>, g, dim3(chunk_threads(14)), 0, evals, in_col_stride, log_n, Winv);
+#define TS_INTT(LMV)                                                                                          \
+    do {                                                                                                      \
+        if (first_round_done)                                                                                 \
+            TS_LAUNCH(ctx, (k_intt_contig<LMV, true>), g, dim3(chunk_threads(LMV)), 0, evals, in_col_stride, log_n, \
+                      Winv);                                                                                  \
+        else                                                                                                  \
+            TS_LAUNCH(ctx, k_intt_contig<LMV>, g, dim3(chunk_threads(LMV)), 0, evals, in_col_stride, log_n, Winv); \
+    } while (0)
+            if (LM == 12) TS_INTT(12);
+            else if (LM == 13) TS_INTT(13);
+            else TS_INTT(14);
+#undef TS_INTT
         }
         if (phase == LDE_INVERSE_CONTIG) {
             TS_HIP(hipGetLastError());

@@ -151,15 +151,17 @@ std::unique_ptr<PcsData> TwoAdicFriPcs::commit(std::vector<DeviceMatrix>& evals,
             const uint64_t Ni = n << fri_.log_blowup;
             DevBuf<uint32_t> colmajor;
             uint32_t* ev = m.buf.p;
+            bool r16 = false;  // the transpose already ran the first round of the inverse transform
             if (m.layout == DeviceMatrix::ROW_MAJOR) {
                 colmajor = DevBuf<uint32_t>(&ctx_, (size_t)m.width * n);
-                launch_transpose_bitrev(ctx_, m.buf.p, colmajor.p, log_n, m.width, n);
+                r16 = launch_transpose_bitrev_r16(ctx_, m.buf.p, colmajor.p, log_n, m.width, n);
+                if (!r16) launch_transpose_bitrev(ctx_, m.buf.p, colmajor.p, log_n, m.width, n);
                 ev = colmajor.p;
             }
             DevBuf<uint32_t> lde(&ctx_, (size_t)m.width * Ni);
             // two_adic_pcs.rs:235: shift = Val::generator() / domain.shift
             const uint32_t shift = mul(GENERATOR, inv_canon(domain_shifts[i]));
-            coset_lde(ctx_, ev, n, m.width, log_n, fri_.log_blowup, shift, lde.p, Ni);
+            coset_lde(ctx_, ev, n, m.width, log_n, fri_.log_blowup, shift, lde.p, Ni, 0, 0, LDE_ALL, r16);
             ColMat cm;
             cm.d = lde.p;
             cm.height = Ni;

@@ -90,14 +90,16 @@ std::unique_ptr<ShardedData> commit_sharded(Shard& sh, std::vector<DeviceMatrix>
                 DevBuf<uint32_t> mine(&ctx, (size_t)cpr * n);
                 {
                     StageTimer t(&ctx, "lde: transpose + inverse contiguous stages of the rank's columns");
+                    bool r16 = false;
                     if (m.layout == DeviceMatrix::ROW_MAJOR) {
-                        launch_transpose_bitrev(ctx, m.buf.p + c0, mine.p, log_n, c1 - c0, n, m.width);
+                        r16 = launch_transpose_bitrev_r16(ctx, m.buf.p + c0, mine.p, log_n, c1 - c0, n, m.width);
+                        if (!r16) launch_transpose_bitrev(ctx, m.buf.p + c0, mine.p, log_n, c1 - c0, n, m.width);
                     } else if (c1 > c0) {
                         TS_HIP(hipMemcpyAsync(mine.p, m.buf.p + (size_t)c0 * n, (size_t)(c1 - c0) * n * 4,
                                               hipMemcpyDeviceToDevice, ctx.stream));
                     }
                     coset_lde(ctx, mine.p, n, c1 - c0, log_n, sh.fri.log_blowup, shift, nullptr, rows, sh.beta0,
-                              sh.cosets, LDE_INVERSE_CONTIG);
+                              sh.cosets, LDE_INVERSE_CONTIG, r16);
                 }
                 colmajor = DevBuf<uint32_t>(&ctx, (size_t)cpr * sh.G * n);
                 {
@@ -107,13 +109,16 @@ std::unique_ptr<ShardedData> commit_sharded(Shard& sh, std::vector<DeviceMatrix>
                 coset_lde(ctx, colmajor.p, n, m.width, log_n, sh.fri.log_blowup, shift, lde.p, rows, sh.beta0,
                           sh.cosets, LDE_REST);
             } else {
+                bool r16 = false;
                 if (m.layout == DeviceMatrix::ROW_MAJOR) {
                     StageTimer t(&ctx, "lde: transpose (every column on every rank)");
                     colmajor = DevBuf<uint32_t>(&ctx, (size_t)m.width * n);
-                    launch_transpose_bitrev(ctx, m.buf.p, colmajor.p, log_n, m.width, n);
+                    r16 = launch_transpose_bitrev_r16(ctx, m.buf.p, colmajor.p, log_n, m.width, n);
+                    if (!r16) launch_transpose_bitrev(ctx, m.buf.p, colmajor.p, log_n, m.width, n);
                     ev = colmajor.p;
                 }
-                coset_lde(ctx, ev, n, m.width, log_n, sh.fri.log_blowup, shift, lde.p, rows, sh.beta0, sh.cosets);
+                coset_lde(ctx, ev, n, m.width, log_n, sh.fri.log_blowup, shift, lde.p, rows, sh.beta0, sh.cosets,
+                          LDE_ALL, r16);
             }
             ColMat cm;
             cm.d = lde.p;

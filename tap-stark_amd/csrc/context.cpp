@@ -22,6 +22,7 @@ Context::Context(int dev) : device(dev) {
 Context::~Context() {
     (void)hipSetDevice(device);
     if (stream) (void)hipStreamSynchronize(stream);
+    if (fri_graph_exec) (void)hipGraphExecDestroy(fri_graph_exec);
     if (d_twiddle_fwd) (void)hipFree(d_twiddle_fwd);
     if (d_twiddle_inv) (void)hipFree(d_twiddle_inv);
     for (auto& t : scale_tables) (void)hipFree(t.d);

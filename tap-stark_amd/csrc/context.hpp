@@ -106,6 +106,10 @@ struct Context {
     // name -> (launch count, total ms)
     std::map<std::string, std::pair<uint64_t, double>> take_kernel_timings();
 
+    // TS_FRI_GRAPH (prover.cpp): the instantiated graph of the FRI commit phase, updated per proof
+    hipGraphExec_t fri_graph_exec = nullptr;
+    uint64_t fri_graph_proofs = 0, fri_graph_shape = ~0ull;
+
     explicit Context(int dev);
     ~Context();
     Context(const Context&) = delete;

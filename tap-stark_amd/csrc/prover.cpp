@@ -7,6 +7,7 @@
 //   fri/src/prover.rs:19-141            bf_prove / bf_commit_phase / bf_answer_query
 // The GPU owns the data from the uploaded trace to the opened rows; the host owns the transcript
 // (one 32-byte root down, one challenge up per commitment).
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -563,7 +564,46 @@ void TwoAdicFriPcs::fri_prove(std::vector<DevBuf<Ef>>& inputs, const std::vector
         StageTimer t(&ctx, "FRI commit phase");
         fri_commit_begin(ctx, fri, log_max_height, challenger, st);
         DevBuf<Ef> first = std::move(inputs[0]);
-        fri_commit_rounds(ctx, fri, std::move(first), 1ull << log_max_height, inputs, log_lens, 1, st);
+        // TS_FRI_GRAPH=1 (measurement knob, DESIGN.md "Why no hipGraph"): the commit phase -- the
+        // launch-bound loop of the path, ~20 dependent launches with no host interaction -- is captured
+        // into a hipGraph and replayed; the instantiated graph is kept per context and updated in place
+        // (hipGraphExecUpdate) when a proof of the same shape comes with other buffer addresses.  The
+        // first proofs of a context run eagerly: the device pool must be warm, a capture cannot hipMalloc.
+        static const bool want_graph = getenv("TS_FRI_GRAPH") != nullptr && atoi(getenv("TS_FRI_GRAPH")) != 0;
+        if (want_graph && ctx.fri_graph_shape != log_max_height + 64 * inputs.size()) {  // another shape: other blocks
+            ctx.fri_graph_shape = log_max_height + 64 * inputs.size();
+            ctx.fri_graph_proofs = 0;
+        }
+        const bool use_graph = want_graph && !ctx.timing && !ctx.kernel_timing && ++ctx.fri_graph_proofs > 2;
+        if (use_graph) {
+            TS_HIP(hipStreamBeginCapture(ctx.stream, hipStreamCaptureModeThreadLocal));
+            hipGraph_t g = nullptr;
+            try {
+                fri_commit_rounds(ctx, fri, std::move(first), 1ull << log_max_height, inputs, log_lens, 1, st);
+            } catch (...) {
+                (void)hipStreamEndCapture(ctx.stream, &g);
+                if (g) (void)hipGraphDestroy(g);
+                throw;
+            }
+            TS_HIP(hipStreamEndCapture(ctx.stream, &g));
+            bool ready = false;
+            if (ctx.fri_graph_exec) {
+                hipGraphNode_t err_node = nullptr;
+                hipGraphExecUpdateResult res;
+                ready = hipGraphExecUpdate(ctx.fri_graph_exec, g, &err_node, &res) == hipSuccess &&
+                        res == hipGraphExecUpdateSuccess;
+                if (!ready) {
+                    (void)hipGetLastError();
+                    (void)hipGraphExecDestroy(ctx.fri_graph_exec);
+                    ctx.fri_graph_exec = nullptr;
+                }
+            }
+            if (!ready) TS_HIP(hipGraphInstantiate(&ctx.fri_graph_exec, g, nullptr, nullptr, 0));
+            TS_HIP(hipGraphLaunch(ctx.fri_graph_exec, ctx.stream));
+            (void)hipGraphDestroy(g);
+        } else {
+            fri_commit_rounds(ctx, fri, std::move(first), 1ull << log_max_height, inputs, log_lens, 1, st);
+        }
         final_poly = fri_commit_finish(ctx, fri, challenger, st);
     }
     std::vector<FriRound>& rounds = st.rounds;

@@ -7,7 +7,7 @@ import numpy as np
 import tapstark_amd as ts
 import bench
 
-tag = {k: os.environ[k] for k in ("TS_TREE_MAX_LOG", "TS_FRI_ROUND_LOG") if k in os.environ}
+tag = {k: os.environ[k] for k in ("TS_TREE_MAX_LOG", "TS_FRI_ROUND_LOG", "TS_FRI_GRAPH") if k in os.environ}
 ctx = ts.default_context()
 for name in sys.argv[1:] or ("config3", "config2"):
     air, _, pis, desc, cfg, shape, gen = bench.workload(name, 20, False)

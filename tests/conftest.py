@@ -10,6 +10,8 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu via gpurun)")
+    config.addinivalue_line("markers", "slow: soak tests; the default form is short (seconds), "
+                                       "TS_SOAK_PROOFS=1500 gives the long one")
 
 
 @pytest.fixture(scope="session")

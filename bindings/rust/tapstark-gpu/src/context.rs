@@ -12,7 +12,7 @@ unsafe impl Send for GpuContext {}
 
 impl GpuContext {
     pub fn new(device: i32) -> Self {
-        assert_eq!(unsafe { ts_abi_version() }, 2, "libtapstark_hip ABI version");
+        assert_eq!(unsafe { ts_abi_version() }, 3, "libtapstark_hip ABI version");
         let mut raw = ptr::null_mut();
         let rc = unsafe { ts_ctx_create(device, &mut raw) };
         assert_eq!(rc, TS_OK, "ts_ctx_create({device}) failed: {}", last_error(ptr::null()));
@@ -60,6 +60,17 @@ impl<'c> DeviceMatrix<'c> {
         );
         Self { ctx, raw }
     }
+    /// The PCIe-rate path: the copy is enqueued on the context's stream and returns at once; `src`
+    /// must stay untouched until the context's next blocking call (e.g. the `ts_prove` that consumes
+    /// the matrix), which the borrow of `src` for `'c` does not express -- see `prove_gpu_stream`.
+    pub fn upload_async(ctx: &'c GpuContext, src: &PinnedTrace) -> Self {
+        let mut raw = ptr::null_mut();
+        ctx.check(
+            unsafe { ts_matrix_upload_async(ctx.raw, src.ptr, src.height as u64, src.width as u32, &mut raw) },
+            "ts_matrix_upload_async",
+        );
+        Self { ctx, raw }
+    }
     pub(crate) fn into_raw(mut self) -> *mut ts_matrix {
         core::mem::replace(&mut self.raw, ptr::null_mut())
     }
@@ -70,6 +81,34 @@ impl Drop for DeviceMatrix<'_> {
         if !self.raw.is_null() {
             unsafe { ts_matrix_free(self.ctx.raw, self.raw) }
         }
+    }
+}
+
+/// A row-major trace in page-locked host memory (`ts_host_alloc`): what a trace generator should
+/// write into if the trace is born on the host.  Pageable memory (`Vec<u32>`) uploads through a
+/// staging copy at roughly half the rate.
+pub struct PinnedTrace {
+    pub(crate) ptr: *mut u32,
+    pub height: usize,
+    pub width: usize,
+}
+unsafe impl Send for PinnedTrace {}
+
+impl PinnedTrace {
+    pub fn new(height: usize, width: usize) -> Self {
+        let mut p: *mut core::ffi::c_void = ptr::null_mut();
+        let rc = unsafe { ts_host_alloc(height * width * 4, &mut p) };
+        assert_eq!(rc, TS_OK, "ts_host_alloc({} bytes)", height * width * 4);
+        Self { ptr: p as *mut u32, height, width }
+    }
+    /// canonical u32 values, row-major
+    pub fn as_mut_slice(&mut self) -> &mut [u32] {
+        unsafe { core::slice::from_raw_parts_mut(self.ptr, self.height * self.width) }
+    }
+}
+impl Drop for PinnedTrace {
+    fn drop(&mut self) {
+        unsafe { ts_host_free(self.ptr as *mut core::ffi::c_void) }
     }
 }
 

@@ -1,4 +1,4 @@
-//! `extern "C"` declarations of include/tapstark.h (ABI version 2).  One line per entry point the
+//! `extern "C"` declarations of include/tapstark.h (ABI version 3).  One line per entry point the
 //! Rust side uses; the header is the authority for argument meaning.
 #![allow(non_camel_case_types)]
 use core::ffi::{c_char, c_int, c_void};
@@ -39,6 +39,18 @@ pub struct ts_shard_options {
     pub column_sharded_inverse: u32,
 }
 
+#[repr(C)]
+#[derive(Clone, Copy, Default, Debug)]
+pub struct ts_rccl_info {
+    pub rank: c_int,
+    pub world: c_int,
+    pub comm_count: c_int,
+    pub comm_user_rank: c_int,
+    pub comm_device: c_int,
+    pub rccl_version: c_int,
+    pub aborted: c_int,
+}
+
 extern "C" {
     pub fn ts_abi_version() -> u32;
     pub fn ts_ctx_create(device: c_int, out: *mut *mut ts_ctx) -> ts_status;
@@ -48,6 +60,11 @@ extern "C" {
 
     pub fn ts_matrix_upload(ctx: *mut ts_ctx, host_row_major: *const u32, height: u64, width: u32,
                             out: *mut *mut ts_matrix) -> ts_status;
+    /// page-locked host memory + asynchronous upload on the context's stream (the PCIe-rate path)
+    pub fn ts_host_alloc(bytes: usize, out: *mut *mut c_void) -> ts_status;
+    pub fn ts_host_free(p: *mut c_void);
+    pub fn ts_matrix_upload_async(ctx: *mut ts_ctx, host_pinned: *const u32, height: u64, width: u32,
+                                  out: *mut *mut ts_matrix) -> ts_status;
     pub fn ts_matrix_download(ctx: *mut ts_ctx, m: *const ts_matrix, host_row_major: *mut u32) -> ts_status;
     pub fn ts_matrix_dims(m: *const ts_matrix, height: *mut u64, width: *mut u32) -> ts_status;
     pub fn ts_matrix_free(ctx: *mut ts_ctx, m: *mut ts_matrix);
@@ -96,6 +113,11 @@ extern "C" {
                      verdict: *mut c_int) -> ts_status;
     pub fn ts_proof_to_postcard(proof: *const u32, n_words: usize, out: *mut u8, cap_bytes: usize,
                                 n_bytes_out: *mut usize) -> ts_status;
+    /// tspf_version: 0 infer, 1 / 2 explicit (a taptree proof with one query needs 2)
+    pub fn ts_proof_from_postcard_v(bytes: *const u8, n_bytes: usize, tspf_version: c_int, proof_out: *mut u32,
+                                    cap_words: usize, n_words_out: *mut usize) -> ts_status;
+    pub fn ts_fri_fold_device(ctx: *mut ts_ctx, in_dev: *const u32, h: u64, beta: *const u32,
+                              out_dev: *mut u32) -> ts_status;
 
     // the reference's own MMCS: TapTreeMmcs (csrc/taptree.cpp, tap_prover.cpp)
     pub fn ts_tapleaf_hash(script: *const u8, len: usize, out: *mut u8) -> ts_status;
@@ -132,6 +154,9 @@ extern "C" {
     pub fn ts_comm_rccl_create(ctx: *mut ts_ctx, unique_id: *const u8, rank: c_int, world: c_int,
                                out: *mut ts_comm, handle: *mut *mut ts_rccl_comm) -> ts_status;
     pub fn ts_comm_rccl_destroy(handle: *mut ts_rccl_comm);
+    pub fn ts_comm_rccl_info(handle: *const ts_rccl_comm, out: *mut ts_rccl_info) -> ts_status;
+    pub fn ts_comm_local_group_reset(group: *mut ts_comm_group) -> ts_status;
+    pub fn ts_comm_local_group_set_timeout(group: *mut ts_comm_group, seconds: c_int) -> ts_status;
     pub fn ts_comm_local_group_create(world: c_int, out: *mut *mut ts_comm_group) -> ts_status;
     pub fn ts_comm_local_get(group: *mut ts_comm_group, rank: c_int, out: *mut ts_comm) -> ts_status;
     pub fn ts_comm_local_group_destroy(group: *mut ts_comm_group);

@@ -15,7 +15,7 @@ use uni_stark::SymbolicAirBuilder;
 use basic::bf_pcs::Pcs;
 
 use crate::air::serialize_constraints;
-use crate::context::{DeviceMatrix, GpuChallenger, GpuContext};
+use crate::context::{DeviceMatrix, GpuChallenger, GpuContext, PinnedTrace};
 use crate::ffi::*;
 use crate::pcs::{FriConfig, GpuFriPcs};
 use crate::proof::{Challenge, Commitments, OpenedValues, Proof, Val};
@@ -73,6 +73,67 @@ where
     );
     unsafe { ts_matrix_free(ctx.raw, raw_m) };
     Proof::from_tspf(&out[..n])
+}
+
+/// A stream of proofs from HOST traces at the PCIe-inclusive rate (INTEGRATION.md "Three rates").
+///
+/// `prove_gpu` above uploads synchronously from pageable memory: the GPU idles during the copy and
+/// the copy runs at about half the link rate.  Here `lanes` contexts (2 is enough to hide the
+/// upload; 4 also hides the latency-bound phases of a proof, as bench.py does) each own a pinned
+/// buffer: `fill(i, buf)` writes trace `i` into the lane's buffer (canonical u32, row-major), the
+/// upload is enqueued asynchronously on the lane's stream and `ts_prove` follows on the same
+/// stream, so the upload of one lane overlaps the proofs of the others.  Mirrors bench.py's
+/// `h2d_inclusive` leg (6.1-6.4 ms per 2^20 x 64 proof = the 43 GB/s the link gives; 2.8 ms when
+/// the trace is born on the device).  One host thread per lane, as the library requires.
+pub fn prove_gpu_stream<A, F>(device: i32, fri: FriConfig, air: &A, num_public_values: usize, height: usize,
+                              width: usize, n_proofs: usize, lanes: usize, fill: F,
+                              public_values: &(dyn Fn(usize) -> Vec<Val> + Sync)) -> Vec<Proof>
+where
+    A: Air<SymbolicAirBuilder<Val>> + Sync,
+    F: Fn(usize, &mut [u32]) + Sync,
+{
+    use std::sync::atomic::{AtomicUsize, Ordering};
+    use std::sync::Mutex;
+
+    let next = AtomicUsize::new(0);
+    let proofs: Mutex<Vec<Option<Proof>>> = Mutex::new((0..n_proofs).map(|_| None).collect());
+    std::thread::scope(|s| {
+        for _ in 0..lanes.max(1) {
+            s.spawn(|| {
+                let ctx = GpuContext::new(device);
+                let pcs = GpuFriPcs { ctx: &ctx, fri };
+                let cair = CompiledAir::new(&ctx, air, num_public_values);
+                let mut buf = PinnedTrace::new(height, width);
+                let cfg = fri.raw();
+                let mut out = vec![0u32; proof_capacity(&pcs.fri, height, width, 1 << cair.log_quotient_degree)];
+                loop {
+                    let i = next.fetch_add(1, Ordering::Relaxed);
+                    if i >= n_proofs {
+                        break;
+                    }
+                    // the previous ts_prove on this context has returned (it blocks until the proof is on
+                    // the host), so the lane's buffer is free to overwrite
+                    fill(i, buf.as_mut_slice());
+                    let pis: Vec<u32> = public_values(i).iter().map(|v| v.as_canonical_u32()).collect();
+                    let raw_m = DeviceMatrix::upload_async(&ctx, &buf).into_raw();
+                    let mut challenger = GpuChallenger::new();
+                    let mut n = 0usize;
+                    ctx.check(
+                        unsafe {
+                            ts_prove(ctx.raw, &cfg, cair.raw, challenger.raw, raw_m,
+                                     if pis.is_empty() { ptr::null() } else { pis.as_ptr() }, pis.len() as u32,
+                                     out.as_mut_ptr(), out.len(), &mut n)
+                        },
+                        "ts_prove",
+                    );
+                    unsafe { ts_matrix_free(ctx.raw, raw_m) };
+                    proofs.lock().unwrap()[i] = Some(Proof::from_tspf(&out[..n]));
+                    let _ = &mut challenger;
+                }
+            });
+        }
+    });
+    proofs.into_inner().unwrap().into_iter().map(|p| p.expect("every proof index was taken")).collect()
 }
 
 /// Form 2: the body of uni-stark/src/prover.rs:40-118 over the `Pcs` trait.

@@ -524,9 +524,10 @@ k_lde_mid(const uint32_t* __restrict__ evals, uint64_t in_col_stride, uint32_t* 
             __syncthreads();
             uint32_t* og = out + (uint64_t)col_id * out_col_stride + ((uint64_t)bl << log_n) + j2_0;
             if constexpr (PLAN == 1) {
-                // (writing this round's results straight to HBM, as PLAN 2 does below, costs 16 more
-                // VGPRs here -- 137, one workgroup per CU instead of two -- and measured 0.85 ms
-                // against 0.64; forced back to 128 VGPRs it spills)
+                // (writing this round's results straight to HBM, as PLAN 2 does below: round 2 it needed
+                // 137 VGPRs -- one workgroup per CU -- and ran 0.85 ms against 0.64; since the scale
+                // prefetch simplified the addressing it fits in 123 and runs 0.584-0.591 ms per proof
+                // against 0.588-0.601: within the noise of whole proofs, so the LDS round stays)
                 radix_round<4, false, 5, NTM>(s, 13, 4, 0, 0, W);
                 // lazy values: k_lde_fwd_contig reads them next.  Unrolled: 16 LDS reads in flight, then
                 // 16 stores whose addresses differ by constants (as a run-time loop each iteration

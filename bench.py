@@ -794,6 +794,11 @@ def rank0_legs(ts, args, env, ctx, config, cair, lanes, S, pool, local_sync, mak
             return alg["k_lde_mid<1>"]
         if name == "k_merkle_level<1>" and "k_merkle_level<2>" not in kt:
             return alg["k_merkle_level<1>"] + alg["k_merkle_level<2>"]
+        if "k_intt_contig" in name:  # with the fused transpose the trace and the chunk columns are separate launches
+            fused = any("k_intt_contig" in k and "true" in k for k in kt)
+            if "true" in name:
+                return 8 * n * w
+            return 8 * n * 4 * qd if fused else alg["k_intt_contig"]
         if name in alg:
             return alg[name]
         stem = name.strip("()").split("<")[0]  # "k_lde_fwd_contig<14, 4>" -> "k_lde_fwd_contig"

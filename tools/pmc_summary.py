@@ -5,7 +5,12 @@ passes) of tools/prof_prove.py.
 
 Units and corrections follow /opt/skills/guides/MI355X_MICROARCH.md (HBM / rocprofv3 section): both
 counters are in KiB; on gfx950 FETCH_SIZE reports half of the bytes of wide coalesced streaming reads,
-so it is doubled before comparing with a byte count.
+so it is doubled before comparing with a byte count.  Round 3 settled the doubling per kernel with
+the raw request counters (tools/pmc_fetch_raw.py, profiles/r03_fetch_raw_config{3,4}.json): counting
+every non-32-byte read request as 128 bytes reproduces the exactly known read bytes of the in-place
+and single-pass kernels to 0-3 % at both shapes; where it says more than the data (the contiguous NTT
+passes at 2^22 rows: 1.12-1.26x) the surplus is real -- twiddle words missing the XCD's L2 (they are
+counted whether the Infinity Cache or HBM serves them).
 """
 import csv
 import json
@@ -48,7 +53,7 @@ def main():
     kernels = {}
     for k in sorted(fetch, key=lambda k: -(fetch[k] + write.get(k, 0))):
         a = (alg.get(k) or alg.get(f"({k})") or (alg["k_lde_mid<1>"] if "k_lde_mid" in k else None)
-             or (alg["k_merkle_tree"] if "k_merkle_tree" in k else None))
+             or (alg["k_merkle_tree"] if "k_merkle_tree" in k else None) or alg.get(k.split("<")[0]))
         kernels[k] = {"launches_per_proof": cnt[k] / n_proofs,
                       "fetch_bytes_per_proof_corrected": 2 * 1024 * fetch[k] / n_proofs,
                       "write_bytes_per_proof": 1024 * write.get(k, 0.0) / n_proofs,

@@ -15,5 +15,5 @@ cd $R
 find $O -name "*.csv" -size +20M -delete
 find $O -name "*.db" -delete
 F=$(find $O/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1); W=$(find $O/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1)
-python3 tools/pmc_summary.py $F $W 2 $O/traffic.json $CFG | head -14
+python3 tools/pmc_summary.py $F $W 2 $O/traffic.json $CFG > $O/traffic.txt; head -12 $O/traffic.txt
 tail -8 $O/sq_table.txt

@@ -731,6 +731,7 @@ def main():
                 emit(out)
             os._exit(0)  # the record carries the error; a non-zero exit would void the replicas line too
 
+        env.dist.barrier()  # rank 0 comes here later than the others (its roofline legs): start the clocks together
         wd = Watchdog(limit, on_timeout)
         try:
             blk = sharded_config4_block(ts, env, ctx, dev, wd)

@@ -130,3 +130,21 @@ def test_bench_without_gpu_fails_loudly():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1"], env=env,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and r.stdout.strip() == ""
+
+
+def test_bench_under_torch_distributed_run():
+    # the driver's own launch line for N > 1 (one rank per GPU): the process IS a rank, no self-launch
+    import json
+
+    env = dict(os.environ, TS_BENCH_STUB="1", TS_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR", "LOCAL_WORLD_SIZE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["self_launched"] is False

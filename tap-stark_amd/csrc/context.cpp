@@ -1,3 +1,5 @@
+#include <stdio.h>
+#include <stdlib.h>
 #include "context.hpp"
 
 #include <string.h>
@@ -55,6 +57,8 @@ void* Context::alloc(size_t bytes) {
         free_blocks.erase(it);
     } else {
         TS_HIP(hipSetDevice(device));
+        static const bool pool_debug = getenv("TS_POOL_DEBUG") != nullptr;
+        if (pool_debug) fprintf(stderr, "[ts pool %p] hipMalloc %zu MiB (reserved %zu MiB)\n", (void*)this, sz >> 20, bytes_reserved >> 20);
         hipError_t e = hipMalloc(&p, sz);
         if (e != hipSuccess) {
             // drop the cache and retry once

@@ -333,15 +333,26 @@ def test_native_pcs_verify_on_oracle_openings(lib, orc, log_blowup, shape):
 
 
 # ------------------------------------------------------------------ compiled-language host (C++)
-def _build_example(tmp_path):
+def _build_example(tmp_path, name="fib_air"):
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = str(tmp_path / "fib_air")
+    exe = str(tmp_path / name)
     libdir = os.path.join(root, "tap-stark_amd", "lib")
-    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-I", os.path.join(root, "include"),
-                           os.path.join(root, "examples", "fib_air.cpp"), "-L", libdir, "-ltapstark_hip",
+    subprocess.check_call(["g++", "-std=c++17", "-pthread", "-Wall", "-Werror", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "examples", name + ".cpp"), "-L", libdir, "-ltapstark_hip",
                            f"-Wl,-rpath,{libdir}", "-o", exe])
     return exe
+
+
+def test_cpp_stream_example_builds_with_plain_gxx(lib, tmp_path):
+    # examples/prove_stream.cpp (several lanes, start gate, pinned uploads) links against the C ABI with
+    # plain g++; without a GPU it must fail loudly at ts_ctx_create, not fall back
+    import subprocess
+    exe = _build_example(tmp_path, "prove_stream")
+    import torch
+    if not torch.cuda.is_available():
+        r = subprocess.run([exe, "10", "4", "2"], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 2 and "no MI355X context" in r.stderr
 
 
 def test_cpp_air_capture_matches_python(lib, tmp_path):

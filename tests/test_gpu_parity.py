@@ -525,6 +525,28 @@ def test_cpp_example_runs_the_reference_test_through_the_c_abi(ctx, orc, tmp_pat
         assert len(words) == len(want) and (words == want).all()
 
 
+def test_cpp_stream_example_lanes_gate_and_pinned_uploads(ctx, orc, tmp_path):
+    """examples/prove_stream.cpp: S lanes (one thread + one context each), the start gate, traces born
+    on the device or uploaded asynchronously from page-locked host memory -- what the (unbuilt) Rust
+    prove_gpu_stream does, from a compiled language over include/tapstark.h only.  Every proof of the
+    run equals the oracle's proof of that trace."""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_abi_cpu import _build_example
+    exe = _build_example(tmp_path, "prove_stream")
+    log_n = 11
+    trace = generate_synth_mul_trace(1 << log_n)
+    want = orc.prove(orc.FriConfig(2, 28, 8), ts.air_tape(SynthMulAir(64), 0), trace, [])
+    for mode in ("device", "pinned"):
+        out_bin = str(tmp_path / f"stream_{mode}.bin")
+        r = subprocess.run([exe, str(log_n), "12", "3", mode, out_bin], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "all proofs identical" in r.stdout and "verify -> 0" in r.stdout
+        words = np.fromfile(out_bin, dtype=np.uint32)
+        assert len(words) == len(want) and (words == want).all(), mode
+
+
 # ------------------------------------------------------------------ FRI alone (fri/tests/fri.rs)
 @pytest.mark.parametrize("perm,ext,cfg,degs", [
     (1, False, (1, 10, 8), range(1, 10)),        # test_compelte_fri_process, fri.rs:51-147

@@ -715,7 +715,7 @@ def main():
         }
     if env.rank == 0 and not args.headline_only:
         out.update(rank0_legs(ts, args, env, ctx, config, cair, lanes, S, pool if S > 1 else None, local_sync,
-                              make_trace, pis, cfg, n, w, qd, res, sharded))
+                              make_trace, pis, cfg, n, w, qd, res, sharded, start_gate))
 
     # ---- N > 1: BASELINE config 4 as one sharded proof, in the same lease
     if env.world > 1 and not sharded and not args.no_sharded_block:
@@ -757,7 +757,7 @@ def latest_profile(pattern: str):
 
 
 def rank0_legs(ts, args, env, ctx, config, cair, lanes, S, pool, local_sync, make_trace, pis, cfg, n, w, qd,
-               res, sharded) -> dict:
+               res, sharded, start_gate=lambda: None) -> dict:
     """Everything on the record beside the headline: measured on rank 0 after the timed region."""
     import hashlib
 
@@ -918,14 +918,21 @@ def rank0_legs(ts, args, env, ctx, config, cair, lanes, S, pool, local_sync, mak
     # asynchronous upload on each lane's stream, the upload of one lane overlapping the proofs of the others
     def h2d_leg(lanes_, make_trace_, pis_, n_, w_):
         try:
-            pin = ts.PinnedHostMatrix(n_, w_)
-            pin.array[:] = make_trace_(lanes_[0][0]).download()
+            host = make_trace_(lanes_[0][0]).download()
+            pins = []
+            for _ in lanes_:  # one page-locked buffer per lane, as a host with S trace generators would have
+                pins.append(ts.PinnedHostMatrix(n_, w_))
+                pins[-1].array[:] = host
+            del host
             k2 = 6 * len(lanes_)
 
             def h2d_job(l):
                 c, conf, ca = lanes_[l]
+                pin = pins[l]
                 for _ in range(k2 // len(lanes_)):
-                    ts.prove(conf, ca, ts.BfChallenger(), ts.DeviceMatrix.upload_async(c, pin), pis_)
+                    m = ts.DeviceMatrix.upload_async(c, pin)
+                    start_gate()
+                    ts.prove(conf, ca, ts.BfChallenger(), m, pis_)
             list(pool.map(h2d_job, range(len(lanes_))))  # warm-up
             local_sync()
             t0 = time.perf_counter()
@@ -958,6 +965,7 @@ def rank0_legs(ts, args, env, ctx, config, cair, lanes, S, pool, local_sync, mak
                     def job(l):
                         c, conf, ca = lanes2[l]
                         for i in range(first + l, first + k2, len(lanes2)):
+                            start_gate()
                             ts.prove(conf, ca, ts.BfChallenger(), mats2[i], pis2)
                     return job
                 list(pool.map(dev_job(0), range(len(lanes2))))

@@ -481,7 +481,9 @@ k_lde_mid(const uint32_t* __restrict__ evals, uint64_t in_col_stride, uint32_t* 
     // with one LDS round per coset there is little else to hide that latency behind): 16 more VGPRs
     // (109 -> 125, still two workgroups per CU).
     // (nontemporal stores of the coset blocks, to keep the table slices in L2, changed nothing at
-    // 2^22 x 64, log_blowup 4: 7.92 against 7.90 ms per launch.)
+    // 2^22 x 64, log_blowup 4: 7.92 against 7.90 ms per launch.  Nor did two LDS images used in turn,
+    // which make the barrier at the top of the coset loop unnecessary (3 -> 2 barriers per coset, but
+    // 114 VGPRs and run-time image addresses): 0.61 against 0.59-0.60 ms at C3, 8.19 against 7.9-8.1.)
     constexpr bool PREFETCH = PLAN == 1;
     uint32_t scv[PREFETCH ? 16 : 1];
     const uint32_t* scp = nullptr;  // this thread's first entry in coset block 0 of the table

@@ -50,6 +50,19 @@ __device__ inline uint32_t dc_pop(DevChallenger* c) {
     uint32_t v = c->out_buf[--c->n_out];
     return v % P;
 }
+// The sponge is a chain of dependent, dynamically indexed word accesses (in_buf[n_in++], out_buf[--n_out],
+// state[i]); run straight on the copy in device memory every one of them is a global round trip.  The
+// kernels therefore work on a copy in LDS (one lane) and write it back once.
+constexpr int DC_WORDS = sizeof(DevChallenger) / 4;  // 36
+__device__ inline void dc_copy(DevChallenger* dst, const DevChallenger* src) {
+    const uint32_t* s = reinterpret_cast<const uint32_t*>(src);
+    uint32_t* d = reinterpret_cast<uint32_t*>(dst);
+    uint32_t t[DC_WORDS];
+#pragma unroll
+    for (int i = 0; i < DC_WORDS; i++) t[i] = s[i];  // independent loads, all in flight
+#pragma unroll
+    for (int i = 0; i < DC_WORDS; i++) d[i] = t[i];
+}
 // observe a commitment, then sample one challenge (fri/src/prover.rs:114-116)
 __device__ inline Ef dc_observe_root_and_sample(DevChallenger* c, const uint32_t* root) {
     for (int i = 0; i < 8; i++) dc_observe(c, root[i]);

@@ -266,13 +266,16 @@ void launch_gather_ef_pairs(Context& ctx, const Ef* vec, const uint32_t* d_indic
 // Merkle kernels just wrote, sample beta, leave both where the host will collect them later.
 __global__ void k_chal_round(DevChallenger* __restrict__ ch, const uint32_t* __restrict__ root,
                              uint32_t* __restrict__ root_out, Ef* __restrict__ beta_out) {
+    __shared__ DevChallenger lc;
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     uint32_t r[8];
     for (int i = 0; i < 8; i++) {
         r[i] = root[i];
         root_out[i] = r[i];
     }
-    Ef beta = dc_observe_root_and_sample(ch, r);
+    dc_copy(&lc, ch);
+    Ef beta = dc_observe_root_and_sample(&lc, r);
+    dc_copy(ch, &lc);
     store_ef(beta_out, beta);
 }
 void launch_chal_round(Context& ctx, DevChallenger* ch, const uint32_t* root, uint32_t* root_out,
@@ -303,6 +306,8 @@ k_fri_tail(const Ef* __restrict__ in, uint32_t L0, uint32_t blowup, DevChallenge
     __shared__ uint32_t digA[8 * TAIL_STRIDE];
     __shared__ uint32_t digB[8 * TAIL_STRIDE];
     __shared__ Ef s_beta;
+    __shared__ DevChallenger s_ch;  // the sponge's working copy (chal_dev.hpp); lane 0 only
+    if (threadIdx.x == 0) dc_copy(&s_ch, ch);
     const uint32_t j = threadIdx.x & 3;
     uint32_t moff[28], lidx[28], lmask = 0;  // tree-node offsets; leaf word indices and their validity
     {
@@ -368,7 +373,7 @@ k_fri_tail(const Ef* __restrict__ in, uint32_t L0, uint32_t blowup, DevChallenge
                 root[k] = src[k * TAIL_STRIDE];
                 roots_out[8 * t + k] = root[k];
             }
-            const Ef beta = dc_observe_root_and_sample(ch, root);
+            const Ef beta = dc_observe_root_and_sample(&s_ch, root);
             s_beta = beta;
             store_ef(betas_out + t, beta);
         }
@@ -386,6 +391,7 @@ k_fri_tail(const Ef* __restrict__ in, uint32_t L0, uint32_t blowup, DevChallenge
         t++;
     }
     for (uint32_t i = threadIdx.x; i < L; i += TAIL_NT) store_ef(final_out + i, cur[i]);
+    if (threadIdx.x == 0) dc_copy(ch, &s_ch);  // only lane 0 ever touched the copy
 }
 
 void launch_fri_tail(Context& ctx, const Ef* in, uint32_t L0, uint32_t blowup, DevChallenger* ch,

@@ -249,7 +249,10 @@ k_shard_top(const uint32_t* __restrict__ subroots, uint32_t G, uint32_t* __restr
             root[k] = top[8 * off + k];
             root_out[k] = root[k];
         }
-        const Ef beta = dc_observe_root_and_sample(ch, root);
+        __shared__ DevChallenger lc;  // the sponge runs on a copy in LDS (chal_dev.hpp)
+        dc_copy(&lc, ch);
+        const Ef beta = dc_observe_root_and_sample(&lc, root);
+        dc_copy(ch, &lc);
         *reinterpret_cast<uint4*>(beta_out) = make_uint4(beta.c[0], beta.c[1], beta.c[2], beta.c[3]);
     }
 }

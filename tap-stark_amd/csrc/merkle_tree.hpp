@@ -210,7 +210,11 @@ __device__ __forceinline__ void tree_body(Lds& lds, uint32_t& s_last, Producer& 
             root[k] = top[k * CH];
             root_out[k] = root[k];
         }
-        const Ef beta = dc_observe_root_and_sample(ch, root);
+        // (the parked-node image is free by now: the sponge runs on a copy there, see chal_dev.hpp)
+        DevChallenger* lc = reinterpret_cast<DevChallenger*>(lds.keep);
+        dc_copy(lc, ch);
+        const Ef beta = dc_observe_root_and_sample(lc, root);
+        dc_copy(ch, lc);
         *reinterpret_cast<uint4*>(beta_out) = make_uint4(beta.c[0], beta.c[1], beta.c[2], beta.c[3]);
     }
 }

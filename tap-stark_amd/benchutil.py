@@ -95,6 +95,9 @@ def run_timed(env: DistEnv, step: Callable[[int], None], steps: int, warmup: int
     for k in range(1 + max(0, extra_windows)):
         env.barrier(local_sync)
         t0 = time.perf_counter()
+        if os.environ.get("TS_POOL_DEBUG"):  # same clock as the library's pool trace (CLOCK_MONOTONIC)
+            import sys
+            print(f"[bench t={time.monotonic() * 1e3:.3f} ms] timed window {k} starts", file=sys.stderr, flush=True)
         run_steps(warmup + k * steps, steps)
         env.barrier(local_sync)
         windows.append(env.max_over_ranks(time.perf_counter() - t0))

@@ -1,4 +1,5 @@
 #include <stdio.h>
+#include <time.h>
 #include <stdlib.h>
 #include "context.hpp"
 
@@ -58,7 +59,12 @@ void* Context::alloc(size_t bytes) {
     } else {
         TS_HIP(hipSetDevice(device));
         static const bool pool_debug = getenv("TS_POOL_DEBUG") != nullptr;
-        if (pool_debug) fprintf(stderr, "[ts pool %p] hipMalloc %zu MiB (reserved %zu MiB)\n", (void*)this, sz >> 20, bytes_reserved >> 20);
+        if (pool_debug) {
+            struct timespec ts_;
+            clock_gettime(CLOCK_MONOTONIC, &ts_);
+            fprintf(stderr, "[ts pool %p t=%.3f ms] hipMalloc %zu KiB (reserved %zu MiB)\n", (void*)this,
+                    ts_.tv_sec * 1e3 + ts_.tv_nsec * 1e-6, sz >> 10, bytes_reserved >> 20);
+        }
         hipError_t e = hipMalloc(&p, sz);
         if (e != hipSuccess) {
             // drop the cache and retry once

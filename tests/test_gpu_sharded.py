@@ -203,6 +203,8 @@ LOCAL_CASES = [
     ("ext25", 9, (4, 5, 8), 8, 2, False),
     ("fib", 11, (3, 9, 8), 8, 1, False),
     ("mul64", 11, (2, 28, 8), 4, 4, False),    # the headline config's FRI parameters over 4 ranks
+    ("mul7", 22, (2, 7, 8), 4, 12, True),      # 2^22 rows: 16384-element NTT chunks, one coset per rank
+    ("mul7", 21, (3, 7, 8), 4, 12, False),     # 2^21 rows: 8192-element chunks, two cosets per rank, row-sliced
 ]
 
 
@@ -210,7 +212,8 @@ LOCAL_CASES = [
     ("mul64", 13, (4, 16, 8), 8, True),    # config 4's split; 64 columns -> 8 per rank, 8 chunk columns -> 1 per rank
     ("mul64", 14, (2, 28, 8), 4, False),   # row-sliced input: rows all-gathered, then columns sharded
     ("mul7", 13, (3, 7, 8), 8, True),      # 7 columns over 8 ranks: one rank owns no trace column
-], ids=["config4-split", "sliced", "fewer-columns-than-ranks"])
+    ("mul7", 21, (2, 7, 8), 4, True),      # 8192-element chunks: the fused transpose on a column range, then LDE_REST
+], ids=["config4-split", "sliced", "fewer-columns-than-ranks", "2p21-chunks"])
 def test_sharded_column_sharded_inverse(ctx, orc, air, log_n, cfg, world, repl):
     # transposes and the per-column stages of the inverse NTT on
     # w/G columns per rank + an all-gather of the half-transformed columns; same proof, and the

@@ -169,6 +169,10 @@ PROOF_CASES = [
                               __import__("tapstark_amd").airs.generate_high_degree_trace(1 << 6)), False, (5, 6, 4)),
     ("deg50_2p4_b6", lambda: (__import__("tapstark_amd").airs.HighDegreeAir(50),
                               __import__("tapstark_amd").airs.generate_high_degree_trace(1 << 4)), False, (6, 3, 4)),
+    # whole proofs through the 8192- / 16384-element NTT chunk plans (2^21 / 2^22 rows), narrow so that
+    # the oracle prover finishes in seconds
+    ("mul7_2p21_b2", lambda: (SynthMulAir(7), generate_synth_mul_trace(1 << 21, 7)), False, (2, 7, 8)),
+    ("fib_2p22_b1", lambda: (FibonacciAir(), generate_fibonacci_trace(1, 2, 1 << 22)), True, (1, 5, 8)),
 ]
 
 

@@ -68,9 +68,10 @@ def init_dist(backend: Optional[str] = None) -> DistEnv:
         "nccl" if torch.cuda.is_available() else "gloo")
     device = None
     if backend == "nccl":
-        torch.cuda.set_device(local_rank)
-        device = f"cuda:{local_rank}"
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dev = 0 if os.environ.get("TS_BENCH_SHARE_GPU") else local_rank  # rehearsal: every rank on GPU 0
+        torch.cuda.set_device(dev)
+        device = f"cuda:{dev}"
+        dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
     else:
         dist.init_process_group(backend)
     return DistEnv(rank, local_rank, world, dist, device)

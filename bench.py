@@ -257,6 +257,86 @@ def cpu_baseline(target_seconds: float = 20.0) -> dict:
 
 
 # ------------------------------------------------------------------------------------------------
+def fold_benchmark(args):
+    """The reference's only benchmark, fri/benches/fold_even_odd.rs:14-46 (a fold over vectors of
+    2^12 .. 2^22 elements), on this hardware: FriGenericConfig::fold_matrix (two_adic_pcs.rs:116-147, the
+    fold the prover runs) on EF4 vectors of those sizes, device-resident (ts_fri_fold_device ->
+    k_fri_fold_pairs), timed with HIP events around every launch on the library's stream.  Bytes per fold:
+    2h EF4 read + h EF4 written + h twiddles = 52 h.  cpu_baseline leg: the oracle's fold_matrix on one
+    host core beside it (and the check that the device result equals it)."""
+    import ctypes as C
+
+    import numpy as np
+    import torch
+
+    import tapstark_amd as ts
+    from tapstark_amd import _lib
+
+    P = 0x78000001
+    ctx = ts.default_context()
+    l = _lib.lib()
+    rng = np.random.default_rng(3)
+    beta = rng.integers(0, P, 4, dtype=np.uint32)
+    bp = beta.ctypes.data_as(C.POINTER(C.c_uint32))
+    rows, held = [], []
+    for log_size in (12, 14, 16, 18, 20, 22):  # the reference's sweep: elements of the INPUT vector
+        n = 1 << log_size
+        h = n // 2
+        vec = rng.integers(0, P, (n, 4), dtype=np.uint32)
+        d_in = torch.from_numpy(vec.view(np.int32)).to("cuda:0")
+        d_out = torch.zeros((h, 4), dtype=torch.int32, device="cuda:0")
+        torch.cuda.synchronize()
+
+        def fold():
+            ctx.check(l.ts_fri_fold_device(ctx.h, d_in.data_ptr(), h, bp, d_out.data_ptr()))
+        fold()
+        ctx.synchronize()
+        reps = max(args.steps, 10)
+        ctx.set_kernel_timing(True)
+        for _ in range(reps):
+            fold()
+        kt = ctx.take_kernel_timings()
+        ctx.set_kernel_timing(False)
+        name = next(k for k in kt if "fold" in k)
+        us = 1e3 * kt[name][1] / kt[name][0]
+        nbytes = 52 * h
+        rows.append({"log_size": log_size, "elements_in": n, "kernel": name, "kernel_us": round(us, 3),
+                     "alg_bytes": nbytes, "GB_per_s": round(nbytes / (us * 1e-6) / 1e9, 1),
+                     "frac_of_8TBps": round(nbytes / (us * 1e-6) / HBM_PEAK, 4),
+                     "elements_per_s_gpu": round(n / (us * 1e-6))})
+        held.append((vec, d_out.cpu().numpy().view(np.uint32)))
+    # ---- cpu_baseline leg (the only place the oracle is touched): host timing + result check
+    cpu = None
+    if not args.no_cpu_baseline:
+        from oracle import oracle_py as orc
+        crow = []
+        for r, (vec, got) in zip(rows, held):
+            best, want = 1e9, None
+            for _ in range(5):
+                t0 = time.perf_counter()
+                want = orc.fold_matrix(vec, beta)
+                best = min(best, time.perf_counter() - t0)
+            assert (got == want).all(), f"device fold of 2^{r['log_size']} differs from the oracle"
+            crow.append({"log_size": r["log_size"], "oracle_host_us": round(1e6 * best, 1),
+                         "elements_per_s_host": round(r["elements_in"] / best)})
+        cpu = {"value": crow[-1]["elements_per_s_host"], "unit": "input elements/sec", "cores": 1, "kind": "port",
+               "sample": "oracle fold_matrix (C, one thread), best of 5 per size; value = the 2^22 row", "rows": crow}
+    big = rows[-1]
+    rec = {"metric": "fold_matrix on EF4 vectors (fri/benches/fold_even_odd.rs:14-46 sizes), input elements/sec at 2^22",
+           "value": big["elements_per_s_gpu"], "unit": "input elements/sec", "n_gpus": 1, "steps": max(args.steps, 10),
+           "warmup": 1, "ms_per_step": big["kernel_us"] * 1e-3, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "u32", "data": "synthetic (uniform field elements, resident in HBM)",
+           "config": {"workload": "fold_matrix, EF4 vectors of 2^12 .. 2^22 elements, one launch each"},
+           "roofline": {"bound": "hbm", "kernel": big["kernel"], "achieved": big["GB_per_s"], "peak": HBM_PEAK / 1e9,
+                        "unit": "GB/s", "frac": big["frac_of_8TBps"], "traffic": None,
+                        "alg_bytes_per_launch": big["alg_bytes"], "avg_launch_ms": big["kernel_us"] * 1e-3},
+           "cpu_baseline": cpu, "rows": rows,
+           "note": "below ~2^19 elements a launch is at the ~7 us floor HIP events see for any kernel; the prover "
+                   "never launches such folds alone (rounds with <= 2^17 leaves fold inside k_fri_round / k_fri_tail)"}
+    print(json.dumps(rec), flush=True)
+
+
+# ------------------------------------------------------------------------------------------------
 class Watchdog:
     """Bounds a block that contains collectives nobody has run on more than one rank yet: if it is
     still running at the deadline, `on_timeout` runs on the watchdog thread (rank 0 prints the record
@@ -398,7 +478,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5,
                     help="untimed proofs before the timed region, dealt to the lanes in turn; at least one "
                          "per lane is always run (tables, device pools and code objects are per context)")
-    ap.add_argument("--workload", default="config3", choices=["config3", "config2", "config4", "config5"])
+    ap.add_argument("--workload", default="config3", choices=["config3", "config2", "config4", "config5", "fold"],
+                    help="fold: the reference's only benchmark (fri/benches/fold_even_odd.rs:14-46) on this "
+                         "hardware -- fold_matrix on EF4 vectors of 2^12 .. 2^22 elements, N = 1 only")
     ap.add_argument("--log-n", type=int, default=None, help="default 20 (22 for config4)")
     ap.add_argument("--mode", default="replicas", choices=["replicas", "sharded"],
                     help="N > 1: independent proofs per GPU (default) or one proof over all GPUs")
@@ -431,6 +513,11 @@ def main():
     if env_world is not None and int(env_world) != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={env_world}: refusing to run "
                          "(launch N ranks, or run `python bench.py --gpus N` as a plain command)")
+
+    if args.workload == "fold":
+        if args.gpus != 1:
+            raise SystemExit("bench.py --workload fold runs on one GPU")
+        return fold_benchmark(args)
 
     # Native libraries print to stdout on their own (RCCL's version banner at communicator creation):
     # everything but the one JSON line goes to stderr, the line itself to the real stdout at the end.

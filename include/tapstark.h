@@ -193,7 +193,7 @@ ts_status ts_fri_verify(const ts_fri_config* cfg, ts_challenger* chal, const uin
 ts_status ts_fri_fold(ts_ctx* ctx, const uint32_t* in, uint64_t h, const uint32_t beta[4],
                       uint32_t* out);
 /* The same on DEVICE vectors (16-byte aligned), enqueued on the context's stream: what a caller that
- * keeps its FRI vectors in HBM binds, and what tools/bench_fold.py times against the reference's only
+ * keeps its FRI vectors in HBM binds, and what `bench.py --workload fold` times against the reference's only
  * benchmark (fri/benches/fold_even_odd.rs:14-46). */
 ts_status ts_fri_fold_device(ts_ctx* ctx, const uint32_t* in_dev, uint64_t h, const uint32_t beta[4],
                              uint32_t* out_dev);

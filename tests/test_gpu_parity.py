@@ -551,6 +551,32 @@ def test_cpp_stream_example_lanes_gate_and_pinned_uploads(ctx, orc, tmp_path):
         assert len(words) == len(want) and (words == want).all(), mode
 
 
+def test_fri_fold_device_vectors_match_oracle(ctx, orc):
+    # ts_fri_fold_device: fold_matrix (two_adic_pcs.rs:116-147) on vectors that already live in HBM,
+    # the entry point `bench.py --workload fold` times (fri/benches/fold_even_odd.rs sizes)
+    import ctypes as C
+
+    import torch
+
+    from tapstark_amd import _lib
+    l = _lib.lib()
+    rng = np.random.default_rng(5)
+    for log_size in (1, 2, 5, 12, 17):
+        n = 1 << log_size
+        vec = rng.integers(0, P, (n, 4), dtype=np.uint32)
+        beta = rng.integers(0, P, 4, dtype=np.uint32)
+        d_in = torch.from_numpy(vec.view(np.int32)).to("cuda:0")
+        d_out = torch.zeros((n // 2, 4), dtype=torch.int32, device="cuda:0")
+        torch.cuda.synchronize()
+        ctx.check(l.ts_fri_fold_device(ctx.h, d_in.data_ptr(), n // 2, beta.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                       d_out.data_ptr()))
+        ctx.synchronize()
+        assert (d_out.cpu().numpy().view(np.uint32) == orc.fold_matrix(vec, beta)).all(), log_size
+    # misaligned device pointers are refused (EF4 = 16-byte accesses)
+    rc = l.ts_fri_fold_device(ctx.h, d_in.data_ptr() + 4, 1, beta.ctypes.data_as(C.POINTER(C.c_uint32)), d_out.data_ptr())
+    assert rc == 1
+
+
 # ------------------------------------------------------------------ FRI alone (fri/tests/fri.rs)
 @pytest.mark.parametrize("perm,ext,cfg,degs", [
     (1, False, (1, 10, 8), range(1, 10)),        # test_compelte_fri_process, fri.rs:51-147

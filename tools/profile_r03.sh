@@ -16,7 +16,7 @@ python3 bench.py --workload config4 --streams 1 --steps 6 --warmup 2 --windows 1
 python3 bench.py --workload config5 --streams 2 --steps 8 --warmup 2 --windows 2 --no-cpu-baseline > $O/bench_config5.json 2>> $O/bench.err
 python3 bench.py --workload config4 --mode sharded --steps 4 --warmup 1 --windows 1 --no-cpu-baseline --headline-only > $O/bench_config4_sharded_world1.json 2>> $O/bench.err
 TS_BENCH_SHARE_GPU=1 python3 bench.py --gpus 2 --steps 8 --warmup 2 --headline-only > $O/bench_gpus2_shared_gpu_rehearsal.json 2>> $O/bench.err
-python3 tools/bench_fold.py > $O/fold_even_odd.json 2>> $O/bench.err
+python3 bench.py --workload fold > $O/fold_even_odd.json 2>> $O/bench.err
 echo "benches done"
 for cfg in config3 config4; do
   bash tools/pmc_sq.sh $cfg > $O/sq_$cfg.log 2>&1 || { tail -20 $O/sq_$cfg.log; exit 1; }

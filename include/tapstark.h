@@ -67,6 +67,11 @@ ts_status ts_ctx_take_timings(ts_ctx* ctx, char* buf, size_t cap);
  * (resolved lazily, no sync per kernel); take writes "kernel=launches:total_ms;..." */
 ts_status ts_ctx_set_kernel_timing(ts_ctx* ctx, int enabled);
 ts_status ts_ctx_take_kernel_timings(ts_ctx* ctx, char* buf, size_t cap);
+/* TS_FRI_GRAPH knob (the FRI commit phase, fri/src/prover.rs:93-141, replayed as a hipGraph):
+ * out[0] = commit phases replayed from a graph, out[1] = captures abandoned for the eager path
+ * (an allocation the pool could not serve inside the capture), out[2] = shapes whose block sizes
+ * are known, out[3] = bytes the context's device pool holds.  Diagnostics only. */
+ts_status ts_ctx_graph_stats(ts_ctx* ctx, uint64_t out[4]);
 
 /* ------------------------------------------------------------------ matrices */
 /* RowMajorMatrix<Val>::new(values, width): host row-major canonical values -> device */

@@ -19,7 +19,7 @@ voidpp = C.POINTER(C.c_void_p)
 ABI_SYMBOLS = [
     "ts_abi_version", "ts_ctx_create", "ts_ctx_destroy", "ts_last_error", "ts_ctx_synchronize",
     "ts_ctx_stream", "ts_ctx_set_timing", "ts_ctx_take_timings", "ts_ctx_set_kernel_timing",
-    "ts_ctx_take_kernel_timings", "ts_matrix_upload",
+    "ts_ctx_take_kernel_timings", "ts_ctx_graph_stats", "ts_matrix_upload",
     "ts_matrix_from_device", "ts_trace_fibonacci", "ts_trace_synth_mul", "ts_trace_synth_ext", "ts_matrix_dims", "ts_matrix_download", "ts_matrix_free",
     "ts_air_compile", "ts_air_info", "ts_air_is_jit", "ts_air_free", "ts_pcs_commit", "ts_mmcs_commit", "ts_pcs_data_lde",
     "ts_pcs_data_info", "ts_pcs_data_matrix_info", "ts_pcs_data_digests", "ts_pcs_open_batch", "ts_pcs_data_free",
@@ -182,6 +182,7 @@ def lib() -> C.CDLL:
         u64p = C.POINTER(C.c_uint64)
         szp = C.POINTER(C.c_size_t)
         l.ts_bench_alu.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
+        l.ts_ctx_graph_stats.argtypes = [C.c_void_p, u64p]
         l.ts_host_alloc.argtypes = [C.c_size_t, voidpp]
         l.ts_host_free.argtypes = [C.c_void_p]
         l.ts_host_free.restype = None

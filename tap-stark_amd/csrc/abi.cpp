@@ -203,6 +203,15 @@ ts_status ts_ctx_take_kernel_timings(ts_ctx* ctx, char* buf, size_t cap) {
     });
 }
 
+ts_status ts_ctx_graph_stats(ts_ctx* ctx, uint64_t out[4]) {
+    if (!ctx || !out) return TS_ERR_INVALID;
+    out[0] = ctx->ctx.fri_graph_replays;
+    out[1] = ctx->ctx.fri_graph_fallbacks;
+    out[2] = ctx->ctx.fri_graph_sizes.size();
+    out[3] = ctx->ctx.bytes_reserved;
+    return TS_OK;
+}
+
 ts_status ts_bench_alu(ts_ctx* ctx, int kind, double* units_per_second) {
     if (!ctx || !units_per_second) return TS_ERR_INVALID;
     return guard(ctx, [&] { *units_per_second = ts::alu_ceiling(ctx->ctx, kind); });

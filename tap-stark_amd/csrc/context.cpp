@@ -53,10 +53,12 @@ void* Context::alloc(size_t bytes) {
     const size_t sz = round_block(bytes);
     auto it = free_blocks.find(sz);
     void* p = nullptr;
+    if (alloc_log) alloc_log->push_back(sz);
     if (it != free_blocks.end()) {
         p = it->second;
         free_blocks.erase(it);
     } else {
+        if (capturing) throw CaptureMiss{};  // hipMalloc / release_cache are illegal inside a capture
         TS_HIP(hipSetDevice(device));
         static const bool pool_debug = getenv("TS_POOL_DEBUG") != nullptr;
         if (pool_debug) {
@@ -85,10 +87,53 @@ void Context::free(void* p) {
     if (!p) return;
     auto it = live_blocks.find(p);
     if (it == live_blocks.end()) return;
+    if (capturing) {  // nothing captured has run: keep the block out of circulation until the capture ends
+        deferred_free.push_back(p);
+        return;
+    }
     // All work is enqueued on the single stream, so a recycled block is only touched by kernels
     // that run after every earlier user of it.
     free_blocks.emplace(it->second, p);
     live_blocks.erase(it);
+}
+
+bool Context::reserve(const std::vector<size_t>& sizes) {
+    std::map<size_t, size_t> need;
+    for (size_t s : sizes) need[s]++;
+    for (auto& kv : need) {
+        for (size_t have = free_blocks.count(kv.first); have < kv.second; have++) {
+            void* p = nullptr;
+            (void)hipSetDevice(device);
+            if (hipMalloc(&p, kv.first) != hipSuccess) {
+                (void)hipGetLastError();
+                return false;
+            }
+            bytes_reserved += kv.first;
+            free_blocks.emplace(kv.first, p);
+        }
+    }
+    return true;
+}
+
+std::vector<void*> Context::flush_deferred(const std::vector<void*>& revive) {
+    std::vector<void*> revived;
+    std::vector<void*> parked;
+    parked.swap(deferred_free);
+    for (void* p : parked) {
+        bool keep = false;
+        for (void* r : revive) keep = keep || r == p;
+        if (keep) {
+            bool seen = false;
+            for (void* r : revived) seen = seen || r == p;
+            if (!seen) revived.push_back(p);
+            continue;
+        }
+        auto it = live_blocks.find(p);
+        if (it == live_blocks.end()) continue;
+        free_blocks.emplace(it->second, p);
+        live_blocks.erase(it);
+    }
+    return revived;
 }
 
 void Context::release_cache() {
@@ -111,6 +156,7 @@ uint32_t* Context::ticket() {
 const void* Context::stage(const void* src, size_t bytes) {
     const size_t need = (bytes + 63) & ~(size_t)63;
     if (need > h_arena_bytes / 2) {  // (re)allocate: rare, at most a few times per context
+        if (capturing) throw CaptureMiss{};
         sync();
         if (h_arena) (void)hipHostFree(h_arena);
         h_arena = nullptr;
@@ -121,6 +167,7 @@ const void* Context::stage(const void* src, size_t bytes) {
         h_arena_off = 0;
     }
     if (h_arena_off + need > h_arena_bytes) {  // wrap: everything staged so far must have been consumed
+        if (capturing) throw CaptureMiss{};
         sync();
         h_arena_off = 0;
     }

@@ -106,9 +106,25 @@ struct Context {
     // name -> (launch count, total ms)
     std::map<std::string, std::pair<uint64_t, double>> take_kernel_timings();
 
-    // TS_FRI_GRAPH (prover.cpp): the instantiated graph of the FRI commit phase, updated per proof
+    // TS_FRI_GRAPH (prover.cpp): the instantiated graph of the FRI commit phase, updated per proof.
+    // A stream capture must not reach hipMalloc / hipFree / a stream sync, so while `capturing`:
+    // alloc() only serves from the free list and throws CaptureMiss otherwise (no HIP call made);
+    // free() parks the block in `deferred_free` (it stays live: nothing captured has run yet, and a
+    // fallback to the eager path may need the buffer's contents); stage() throws CaptureMiss instead
+    // of wrapping its arena.  `alloc_log`, when set, records every rounded size alloc() hands out:
+    // the first (eager) proof of a shape records what the commit phase needs, reserve() then makes
+    // the free list hold all of it at once before a capture starts.
+    struct CaptureMiss {};
     hipGraphExec_t fri_graph_exec = nullptr;
-    uint64_t fri_graph_proofs = 0, fri_graph_shape = ~0ull;
+    bool capturing = false;
+    std::vector<void*> deferred_free;
+    std::vector<size_t>* alloc_log = nullptr;
+    std::map<std::vector<uint32_t>, std::vector<size_t>> fri_graph_sizes;  // shape key -> block sizes
+    uint64_t fri_graph_replays = 0, fri_graph_fallbacks = 0;
+    bool reserve(const std::vector<size_t>& sizes);
+    // ends the deferral: blocks in `revive` stay live (returned: which of them had been parked),
+    // every other parked block goes back to the free list
+    std::vector<void*> flush_deferred(const std::vector<void*>& revive);
 
     explicit Context(int dev);
     ~Context();
@@ -133,6 +149,12 @@ struct DevBuf {
     size_t n = 0;
     DevBuf() = default;
     DevBuf(Context* c, size_t count) : ctx(c), p(c->alloc_n<T>(count)), n(count) {}
+    // takes over a block that is still live in the context's pool (Context::flush_deferred)
+    static DevBuf adopt(Context* c, T* ptr, size_t count) {
+        DevBuf b;
+        b.ctx = c; b.p = ptr; b.n = count;
+        return b;
+    }
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
     DevBuf(DevBuf&& o) noexcept : ctx(o.ctx), p(o.p), n(o.n) { o.p = nullptr; }

@@ -564,46 +564,98 @@ void TwoAdicFriPcs::fri_prove(std::vector<DevBuf<Ef>>& inputs, const std::vector
         StageTimer t(&ctx, "FRI commit phase");
         fri_commit_begin(ctx, fri, log_max_height, challenger, st);
         DevBuf<Ef> first = std::move(inputs[0]);
-        // TS_FRI_GRAPH=1 (measurement knob, DESIGN.md "Why no hipGraph"): the commit phase -- the
-        // launch-bound loop of the path, ~20 dependent launches with no host interaction -- is captured
-        // into a hipGraph and replayed; the instantiated graph is kept per context and updated in place
-        // (hipGraphExecUpdate) when a proof of the same shape comes with other buffer addresses.  The
-        // first proofs of a context run eagerly: the device pool must be warm, a capture cannot hipMalloc.
-        static const bool want_graph = getenv("TS_FRI_GRAPH") != nullptr && atoi(getenv("TS_FRI_GRAPH")) != 0;
-        if (want_graph && ctx.fri_graph_shape != log_max_height + 64 * inputs.size()) {  // another shape: other blocks
-            ctx.fri_graph_shape = log_max_height + 64 * inputs.size();
-            ctx.fri_graph_proofs = 0;
-        }
-        const bool use_graph = want_graph && !ctx.timing && !ctx.kernel_timing && ++ctx.fri_graph_proofs > 2;
-        if (use_graph) {
-            TS_HIP(hipStreamBeginCapture(ctx.stream, hipStreamCaptureModeThreadLocal));
-            hipGraph_t g = nullptr;
-            try {
-                fri_commit_rounds(ctx, fri, std::move(first), 1ull << log_max_height, inputs, log_lens, 1, st);
-            } catch (...) {
-                (void)hipStreamEndCapture(ctx.stream, &g);
-                if (g) (void)hipGraphDestroy(g);
-                throw;
-            }
-            TS_HIP(hipStreamEndCapture(ctx.stream, &g));
-            bool ready = false;
-            if (ctx.fri_graph_exec) {
-                hipGraphNode_t err_node = nullptr;
-                hipGraphExecUpdateResult res;
-                ready = hipGraphExecUpdate(ctx.fri_graph_exec, g, &err_node, &res) == hipSuccess &&
-                        res == hipGraphExecUpdateSuccess;
-                if (!ready) {
+        // TS_FRI_GRAPH=1 (measurement knob, DESIGN.md "hipGraph"): the commit phase -- the launch-bound
+        // loop of the path, ~20 dependent launches with no host interaction -- is captured into a
+        // hipGraph and replayed; the instantiated graph is kept per context and updated in place
+        // (hipGraphExecUpdate) when a proof of the same shape comes with other buffer addresses.
+        // A capture cannot hipMalloc, so: the first proof of a SHAPE (log_blowup + every input height:
+        // what the block sizes depend on) runs eagerly and records the sizes the phase allocates;
+        // before a capture the pool is made to hold all of them at once (Context::reserve); and an
+        // allocation that still misses inside the capture (Context::CaptureMiss: no HIP call was made)
+        // ends the capture and re-runs the phase eagerly from the untouched inputs.
+        // TS_FRI_GRAPH=2 skips the reservation: the test hook that exercises that fall-back.
+        const char* genv = getenv("TS_FRI_GRAPH");
+        const int want_graph = (genv && !ctx.timing && !ctx.kernel_timing) ? atoi(genv) : 0;
+        const uint64_t len0 = 1ull << log_max_height;
+        bool done = false;
+        if (want_graph) {
+            std::vector<uint32_t> key{fri.log_blowup};
+            for (unsigned l : log_lens) key.push_back(l);
+            auto known = ctx.fri_graph_sizes.find(key);
+            if (known == ctx.fri_graph_sizes.end()) {  // first proof of this shape: eager, recording
+                std::vector<size_t> sizes;
+                ctx.alloc_log = &sizes;
+                try {
+                    fri_commit_rounds(ctx, fri, std::move(first), len0, inputs, log_lens, 1, st);
+                } catch (...) {
+                    ctx.alloc_log = nullptr;
+                    throw;
+                }
+                ctx.alloc_log = nullptr;
+                ctx.fri_graph_sizes[key] = std::move(sizes);
+                done = true;
+            } else if (want_graph == 2 || ctx.reserve(known->second)) {
+                hipGraph_t g = nullptr;
+                bool miss = false;
+                TS_HIP(hipStreamBeginCapture(ctx.stream, hipStreamCaptureModeThreadLocal));
+                ctx.capturing = true;
+                try {
+                    fri_commit_rounds(ctx, fri, std::move(first), len0, inputs, log_lens, 1, st);
+                } catch (Context::CaptureMiss&) {
+                    miss = true;
+                } catch (...) {
+                    (void)hipStreamEndCapture(ctx.stream, &g);
+                    if (g) (void)hipGraphDestroy(g);
+                    ctx.capturing = false;
+                    ctx.flush_deferred({});
+                    throw;
+                }
+                const hipError_t ec = hipStreamEndCapture(ctx.stream, &g);
+                if (miss || ec != hipSuccess) {
+                    // nothing captured has run.  Drop the half-built round state while frees are still
+                    // parked, take the input vectors back (the rounds had moved some of them into the
+                    // state), return every other parked block to the pool, then run eagerly.
                     (void)hipGetLastError();
-                    (void)hipGraphExecDestroy(ctx.fri_graph_exec);
-                    ctx.fri_graph_exec = nullptr;
+                    if (g) (void)hipGraphDestroy(g);
+                    st.rounds.clear();
+                    st.keep_vecs.clear();
+                    st.keep_trees.clear();
+                    std::vector<void*> mine;
+                    for (const Ef* q : in_ptr) mine.push_back(const_cast<Ef*>(q));
+                    ctx.capturing = false;
+                    const std::vector<void*> back = ctx.flush_deferred(mine);
+                    for (void* q : back)
+                        for (size_t k = 0; k < in_ptr.size(); k++)
+                            if (q == (const void*)in_ptr[k]) {
+                                DevBuf<Ef> b = DevBuf<Ef>::adopt(&ctx, static_cast<Ef*>(q), 1ull << log_lens[k]);
+                                if (k == 0) first = std::move(b);
+                                else inputs[k] = std::move(b);
+                            }
+                    ctx.fri_graph_fallbacks++;
+                } else {
+                    ctx.capturing = false;
+                    ctx.flush_deferred({});
+                    bool ready = false;
+                    if (ctx.fri_graph_exec) {
+                        hipGraphNode_t err_node = nullptr;
+                        hipGraphExecUpdateResult res;
+                        ready = hipGraphExecUpdate(ctx.fri_graph_exec, g, &err_node, &res) == hipSuccess &&
+                                res == hipGraphExecUpdateSuccess;
+                        if (!ready) {
+                            (void)hipGetLastError();
+                            (void)hipGraphExecDestroy(ctx.fri_graph_exec);
+                            ctx.fri_graph_exec = nullptr;
+                        }
+                    }
+                    if (!ready) TS_HIP(hipGraphInstantiate(&ctx.fri_graph_exec, g, nullptr, nullptr, 0));
+                    TS_HIP(hipGraphLaunch(ctx.fri_graph_exec, ctx.stream));
+                    (void)hipGraphDestroy(g);
+                    ctx.fri_graph_replays++;
+                    done = true;
                 }
             }
-            if (!ready) TS_HIP(hipGraphInstantiate(&ctx.fri_graph_exec, g, nullptr, nullptr, 0));
-            TS_HIP(hipGraphLaunch(ctx.fri_graph_exec, ctx.stream));
-            (void)hipGraphDestroy(g);
-        } else {
-            fri_commit_rounds(ctx, fri, std::move(first), 1ull << log_max_height, inputs, log_lens, 1, st);
         }
+        if (!done) fri_commit_rounds(ctx, fri, std::move(first), len0, inputs, log_lens, 1, st);
         final_poly = fri_commit_finish(ctx, fri, challenger, st);
     }
     std::vector<FriRound>& rounds = st.rounds;

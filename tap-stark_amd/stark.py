@@ -90,6 +90,13 @@ class Context:
                 out[k] = (int(cnt), float(ms))
         return out
 
+    def graph_stats(self) -> dict:
+        """TS_FRI_GRAPH diagnostics (``ts_ctx_graph_stats``)."""
+        out = (C.c_uint64 * 4)()
+        self.check(self._l.ts_ctx_graph_stats(self.h, out))
+        return {"replays": int(out[0]), "fallbacks": int(out[1]), "shapes": int(out[2]),
+                "pool_bytes": int(out[3])}
+
     def close(self):
         if self.h:
             self._l.ts_ctx_destroy(self.h)

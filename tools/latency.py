@@ -36,4 +36,5 @@ for name in sys.argv[1:] or ("config3", "config2"):
     fri = sum(v[1] for k, v in kt.items() if "fri" in k or "merkle" in k) / 3
     import hashlib
     print(f"{name} {tag}: latency median {sorted(lat)[len(lat)//2]:.3f} ms  min {min(lat):.3f}  "
-          f"kernels {ksum:.3f} ms in {nk} launches  (fri+merkle kernels {fri:.3f})  proof sha {hashlib.sha256(ref).hexdigest()[:12]}")
+          f"kernels {ksum:.3f} ms in {nk} launches  (fri+merkle kernels {fri:.3f})  proof sha {hashlib.sha256(ref).hexdigest()[:12]}"
+          f"  graph {ctx.graph_stats()}")

@@ -68,7 +68,12 @@ def init_dist(backend: Optional[str] = None) -> DistEnv:
         "nccl" if torch.cuda.is_available() else "gloo")
     device = None
     if backend == "nccl":
-        dev = 0 if os.environ.get("TS_BENCH_SHARE_GPU") else local_rank  # rehearsal: every rank on GPU 0
+        if os.environ.get("TS_BENCH_SHARE_GPU"):
+            # RCCL refuses two ranks on one device ("Duplicate GPU detected"): the shared-GPU rehearsal
+            # covers the launch protocol and the host-staged (gloo) collectives only
+            raise SystemExit("TS_BENCH_SHARE_GPU=1 needs TS_BENCH_BACKEND=gloo: RCCL cannot put two "
+                             "ranks on one GPU")
+        dev = local_rank
         torch.cuda.set_device(dev)
         device = f"cuda:{dev}"
         dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
@@ -107,3 +112,96 @@ def run_timed(env: DistEnv, step: Callable[[int], None], steps: int, warmup: int
     return {"elapsed_s": elapsed, "ms_per_step": 1e3 * elapsed / steps,
             "value": total_units / elapsed, "steps_per_sec": env.world * steps / elapsed,
             "windows_ms_per_step": [1e3 * e / steps for e in windows]}
+
+
+def split_stage_timings(items) -> tuple[dict, list]:
+    """``Context.take_timings()`` of a sharded proof -> (stage name -> summed ms, collectives table).
+    Every collective leaves an entry "collective: <kind> <bytes> B... (<site>)" (csrc/sharded.cpp);
+    the table has one row per (kind, bytes, site): count, total and largest ms."""
+    stages, coll = {}, {}
+    for k, v in items:
+        if k.startswith("collective: "):
+            row = coll.setdefault(k[len("collective: "):], {"count": 0, "ms_total": 0.0, "ms_max": 0.0})
+            row["count"] += 1
+            row["ms_total"] += v
+            row["ms_max"] = max(row["ms_max"], v)
+        else:
+            stages[k] = round(stages.get(k, 0.0) + v, 3)
+    table = []
+    for k, row in coll.items():
+        kind, rest = k.split(" ", 1)
+        nbytes = int(rest.split(" ", 1)[0])
+        table.append({"collective": kind, "what": k, "bytes": nbytes, "count": row["count"],
+                      "ms_total": round(row["ms_total"], 3), "ms_max": round(row["ms_max"], 3)})
+    return stages, table
+
+
+class GpuSampler:
+    """Samples shader clock (per XCD), socket power and hotspot temperature of one GPU from a thread
+    (amdsmi, readable by an ordinary user on the GPU box; ~0.5 ms per sample).  Used OUTSIDE the timed
+    region: a sustained run of the same workload is sampled so that the clock the chip holds under
+    this load is a measurement on the record, not an inference from SQ_BUSY_CYCLES."""
+
+    def __init__(self, device_index: int = 0, interval_s: float = 0.01):
+        self.interval = interval_s
+        self.samples = []
+        self.error = None
+        self._stop = None
+        self._thread = None
+        try:
+            import amdsmi
+            self._smi = amdsmi
+            amdsmi.amdsmi_init()
+            self._h = amdsmi.amdsmi_get_processor_handles()[device_index]
+        except Exception as e:  # noqa: BLE001 -- the sampler is optional everywhere
+            self._smi = None
+            self.error = repr(e)
+
+    def read(self):
+        m = self._smi.amdsmi_get_gpu_metrics_info(self._h)
+        clks = [c for c in m.get("current_gfxclks", []) if isinstance(c, int) and 0 < c < 10000]
+        return {"t": time.perf_counter(), "gfxclk_mhz": clks or [m.get("current_gfxclk")],
+                "socket_power_w": m.get("current_socket_power"), "hotspot_c": m.get("temperature_hotspot"),
+                "uclk_mhz": m.get("current_uclk")}
+
+    def __enter__(self):
+        import threading
+        self.samples = []
+        if self._smi is None:
+            return self
+        self._stop = threading.Event()
+
+        def run():
+            while not self._stop.is_set():
+                try:
+                    self.samples.append(self.read())
+                except Exception as e:  # noqa: BLE001
+                    self.error = repr(e)
+                    return
+                self._stop.wait(self.interval)
+
+        self._thread = threading.Thread(target=run, daemon=True)
+        self._thread.start()
+        return self
+
+    def __exit__(self, *a):
+        if self._thread is not None:
+            self._stop.set()
+            self._thread.join(timeout=2)
+
+    def summary(self) -> dict:
+        if not self.samples:
+            return {"error": self.error or "no samples"}
+
+        def med(xs):
+            xs = sorted(x for x in xs if isinstance(x, (int, float)))
+            return xs[len(xs) // 2] if xs else None
+        per = [sum(s["gfxclk_mhz"]) / len(s["gfxclk_mhz"]) for s in self.samples if s["gfxclk_mhz"] and s["gfxclk_mhz"][0]]
+        return {"samples": len(self.samples), "gfxclk_mhz_median": med(per),
+                "gfxclk_mhz_min": min(per) if per else None, "gfxclk_mhz_max": max(per) if per else None,
+                "socket_power_w_median": med([s["socket_power_w"] for s in self.samples]),
+                "socket_power_w_max": max([s["socket_power_w"] for s in self.samples
+                                           if isinstance(s["socket_power_w"], (int, float))], default=None),
+                "hotspot_c_max": max([s["hotspot_c"] for s in self.samples
+                                      if isinstance(s["hotspot_c"], (int, float))], default=None),
+                "uclk_mhz_median": med([s["uclk_mhz"] for s in self.samples])}

@@ -1,8 +1,22 @@
 // Coset LDE kernels (see the header of ntt.hip for the block-twiddle formulation).
 //
 // Execution: up to 4 stages at a time are done in registers (a thread owns the 16 elements of a
-// radix-16 group), with one LDS exchange between such rounds; the LDS image is padded by one word
-// per 16 so that every round's access pattern is bank-conflict free.  Three kernels:
+// radix-16 group), with one LDS exchange between such rounds.  LDS image: element i lives at word
+// i + (i >> 5).  On gfx950 a ds_read_b32 / ds_write_b32 is served in two 32-lane groups over 32
+// banks ((byte address / 4) mod 32), so an access is conflict-free when the 32 lanes of a half-wave
+// hit 32 distinct words mod 32.  With one pad word per 32:
+//   - 32 consecutive elements from a multiple of 32 (tile loads, rounds at distance >= 32): one pad
+//     value for the run -> 32 consecutive banks;
+//   - the 16 g + q pattern of the distance-1 round (lane = group g): 16 g + (g >> 1) mod 32 takes
+//     every value once over 32 consecutive g;
+//   - the distance-16 round (16 lanes = consecutive elements, the other 16 = another block `hi`):
+//     a block step moves the bank by 2^(K-1) mod 32, so the two halves of a half-wave take blocks
+//     2^(5-K) apart (radix_round swaps two bits of the lane -> group map for that);
+//   - the 16-byte chunk loads / stores (lane t: words 4 t + j): 4 t + j + (t >> 3) mod 32, distinct.
+// (Rounds 1-3 padded one word per 16, right for 16-lane groups: rocprofv3 showed
+// SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.33 / 0.50 / 0.40 for the three big kernels,
+// profiles/r03_config3_sq_counters.txt -- lanes 0 and 31 of every 32-element run met on one bank.)
+// Three kernels:
 //   k_intt_contig    stages log_n-1 .. sA of the inverse on 4096-element chunks   (only n > 4096)
 //   k_lde_mid        the strided stages of the inverse (sA-1 .. 0), then for every coset: scale
 //                    coefficient k by s_beta^k / n and run the strided stages of the forward
@@ -30,8 +44,8 @@ constexpr int NT_MID = 512;        // threads per workgroup, middle kernel
 constexpr int chunk_threads(int lm) { return lm == 14 ? 512 : 256; }
 constexpr int TILE_ELEMS = 8192;   // strided tile (generic plan)
 
-__device__ __forceinline__ uint32_t pad(uint32_t i) { return i + (i >> 4); }
-constexpr int padded(int n) { return n + (n >> 4); }
+__device__ __forceinline__ uint32_t pad(uint32_t i) { return i + (i >> 5); }
+constexpr int padded(int n) { return n + (n >> 5); }
 
 // The LDS image `s` (padded) holds 2^log_total elements: a transform of 2^log_len points whose
 // element e occupies the 2^log_T consecutive slots [e << log_T, (e+1) << log_T) (log_T = 0 for a
@@ -101,7 +115,15 @@ __device__ __forceinline__ void radix_round(uint32_t* s, unsigned log_total, uns
     constexpr int R = 1 << K;
     const unsigned log_dl = LOG_DL >= 0 ? (unsigned)LOG_DL : log_total - u0 - K;
     const uint32_t n_groups = 1u << (log_total - K);
-    for (uint32_t g = threadIdx.x; g < n_groups; g += NTH) {
+    for (uint32_t g0 = threadIdx.x; g0 < n_groups; g0 += NTH) {
+        uint32_t g = g0;
+        if (LOG_DL == 4 && K < 5) {
+            // distance 16: lanes 0-15 of a half-wave are the 16 `lo` of one block, lanes 16-31 those
+            // of the block 2^(5-K) further (header comment): swap bits 4 and 9-K of the group index
+            constexpr uint32_t B = 9 - K;
+            const uint32_t x = ((g >> 4) ^ (g >> B)) & 1u;
+            g ^= (x << 4) | (x << B);
+        }
         const uint32_t lo = g & ((1u << log_dl) - 1);
         const uint32_t hi = g >> log_dl;  // block index at stage u0
         const uint32_t base = (hi << (K + log_dl)) + lo;
@@ -109,10 +131,12 @@ __device__ __forceinline__ void radix_round(uint32_t* s, unsigned log_total, uns
         uint32_t addr[R];
 #pragma unroll
         for (int q = 0; q < R; q++) {
-            if (LOG_DL >= 4)
-                addr[q] = pbase + (uint32_t)q * ((1u << (LOG_DL >= 4 ? LOG_DL : 4)) +
-                                                 (1u << (LOG_DL >= 4 ? LOG_DL - 4 : 0)));
-            else if (LOG_DL == 0 && K == 4)
+            if (LOG_DL >= 5)  // base + (q << d) with d >= 5: the pad grows by q << (d - 5)
+                addr[q] = pbase + (uint32_t)q * ((1u << (LOG_DL >= 5 ? LOG_DL : 5)) +
+                                                 (1u << (LOG_DL >= 5 ? LOG_DL - 5 : 0)));
+            else if (LOG_DL == 4)  // lo < 16 and the block offset is a multiple of 32
+                addr[q] = pbase + 16u * (uint32_t)q + ((uint32_t)q >> 1);
+            else if (LOG_DL == 0 && K == 4)  // the group's 16 words share one pad value
                 addr[q] = pbase + (uint32_t)q;
             else
                 addr[q] = pad(base + ((uint32_t)q << log_dl));
@@ -210,7 +234,7 @@ __device__ __forceinline__ void chunk_load(uint32_t* s, const uint32_t* __restri
 #pragma unroll
     for (int k = 0; k < (1 << LM) / 4 / NT; k++) {
         const uint32_t i4 = threadIdx.x + (uint32_t)k * NT;
-        const uint32_t a = 4 * i4 + (i4 >> 2);  // pad(4*i4); the 4 words stay inside one 16-group
+        const uint32_t a = 4 * i4 + (i4 >> 3);  // pad(4*i4); the 4 words stay inside one 32-group
         s[a] = v[k].x;
         s[a + 1] = v[k].y;
         s[a + 2] = v[k].z;
@@ -229,7 +253,7 @@ __device__ __forceinline__ void chunk_store(const uint32_t* s, uint32_t* __restr
 #pragma unroll
     for (int k = 0; k < (1 << LM) / 4 / NT; k++) {
         const uint32_t i4 = threadIdx.x + (uint32_t)k * NT;
-        const uint32_t a = 4 * i4 + (i4 >> 2);
+        const uint32_t a = 4 * i4 + (i4 >> 3);
         if (CANON)
             g4[i4] = make_uint4(red2p(s[a]), red2p(s[a + 1]), red2p(s[a + 2]), red2p(s[a + 3]));
         else
@@ -344,7 +368,7 @@ k_lde_fwd_contig(uint32_t* __restrict__ out, uint64_t out_col_stride, unsigned l
 #pragma unroll
             for (int k = 0; k < NV; k++) {
                 const uint32_t i4 = threadIdx.x + (uint32_t)k * NT;
-                const uint32_t a = 4 * i4 + (i4 >> 2);
+                const uint32_t a = 4 * i4 + (i4 >> 3);
                 s[a] = v[k].x;
                 s[a + 1] = v[k].y;
                 s[a + 2] = v[k].z;

@@ -17,6 +17,7 @@
 //   5. all-gather of the answered queries.
 // The transcript is replicated: every rank observes the same roots and samples the same challenges.
 // Proofs are bit-identical to prove()'s (tests/test_gpu_sharded.py).
+#include <stdio.h>
 #include <string.h>
 
 #include "fri_internal.hpp"
@@ -42,11 +43,29 @@ struct ShardedData {
     uint32_t root[8];
 };
 
+// Every collective of a proof goes through these two.  With the stage timers on (ts_ctx_set_timing)
+// each call leaves one entry "collective: <kind> <bytes> B (<site>)" = ms between two events on the
+// context's stream around the call (enqueue -> complete, the wait for the slowest peer included), so
+// that a run on real GPUs says per collective where the time went (bench.py: `collectives`).
+void coll_all_gather(Context& ctx, const Comm& comm, const char* site, const void* send, void* recv,
+                     size_t bytes_per_rank) {
+    char name[160];
+    snprintf(name, sizeof name, "collective: all_gather %zu B/rank (%s)", bytes_per_rank, site);
+    StageTimer t(&ctx, name);
+    comm.all_gather(send, recv, bytes_per_rank, ctx.stream);
+}
+void coll_broadcast(Context& ctx, const Comm& comm, const char* site, void* buf, size_t bytes, int root) {
+    char name[160];
+    snprintf(name, sizeof name, "collective: broadcast %zu B (%s)", bytes, site);
+    StageTimer t(&ctx, name);
+    comm.broadcast(buf, bytes, root, ctx.stream);
+}
+
 // sub-root of this rank -> gathered sub-roots -> top levels (+ challenger step) on the device
-void gather_top(Shard& sh, const uint32_t* d_subroot, uint32_t* d_top, DevChallenger* dch,
+void gather_top(Shard& sh, const char* site, const uint32_t* d_subroot, uint32_t* d_top, DevChallenger* dch,
                 uint32_t* d_root_out, Ef* d_beta_out) {
     DevBuf<uint32_t> all(&sh.ctx, 8 * (size_t)sh.G);
-    sh.comm.all_gather(d_subroot, all.p, 32, sh.ctx.stream);
+    coll_all_gather(sh.ctx, sh.comm, site, d_subroot, all.p, 32);
     launch_shard_top(sh.ctx, all.p, sh.G, d_top, dch, d_root_out, d_beta_out);
 }
 
@@ -104,7 +123,7 @@ std::unique_ptr<ShardedData> commit_sharded(Shard& sh, std::vector<DeviceMatrix>
                 colmajor = DevBuf<uint32_t>(&ctx, (size_t)cpr * sh.G * n);
                 {
                     StageTimer t(&ctx, "all-gather half-transformed columns");
-                    sh.comm.all_gather(mine.p, colmajor.p, (size_t)cpr * n * 4, ctx.stream);
+                    coll_all_gather(ctx, sh.comm, "half-transformed columns", mine.p, colmajor.p, (size_t)cpr * n * 4);
                 }
                 coset_lde(ctx, colmajor.p, n, m.width, log_n, sh.fri.log_blowup, shift, lde.p, rows, sh.beta0,
                           sh.cosets, LDE_REST);
@@ -141,8 +160,8 @@ std::unique_ptr<ShardedData> commit_sharded(Shard& sh, std::vector<DeviceMatrix>
         launch_leaf_hash(ctx, loc.leaf_mats(), rows, loc.tree.p);
         launch_merkle_levels(ctx, loc.tree.p, log_rows);
         DevBuf<uint32_t> d_top(&ctx, 8 * (size_t)(2 * sh.G - 1));
-        gather_top(sh, loc.tree.p + 8 * (merkle_total_digests(log_rows) - 1), d_top.p, nullptr, nullptr,
-                   nullptr);
+        gather_top(sh, "commit sub-roots", loc.tree.p + 8 * (merkle_total_digests(log_rows) - 1), d_top.p,
+                   nullptr, nullptr, nullptr);
         data->top.resize(8 * (size_t)(2 * sh.G - 1));
         d2h_sync(ctx, data->top.data(), d_top.p, data->top.size() * 4);  // also covers `cols`
         memcpy(data->root, &data->top[8 * (size_t)(2 * sh.G - 2)], 32);
@@ -208,7 +227,7 @@ std::vector<uint32_t> prove_sharded(TwoAdicFriPcs& pcs, const Comm& comm, const 
         trace.height = n;
         trace.width = w;
         trace.layout = DeviceMatrix::ROW_MAJOR;
-        comm.all_gather(trace_rows.buf.p, trace.buf.p, (size_t)trace_rows.height * w * 4, ctx.stream);
+        coll_all_gather(ctx, comm, "trace rows", trace_rows.buf.p, trace.buf.p, (size_t)trace_rows.height * w * 4);
         trace_rows.buf.reset();
     }
 
@@ -227,7 +246,7 @@ std::vector<uint32_t> prove_sharded(TwoAdicFriPcs& pcs, const Comm& comm, const 
         StageTimer t(&ctx, "broadcast quotient chunks");
         for (uint32_t c = 0; c < qd; c++) {
             const uint32_t owner = bitrev32(c, lqd) / sh.cosets;
-            comm.broadcast(chunks[c].buf.p, (size_t)n * 16, (int)owner, ctx.stream);
+            coll_broadcast(ctx, comm, "quotient chunk", chunks[c].buf.p, (size_t)n * 16, (int)owner);
         }
     }
     std::vector<uint32_t> qshifts(qd);
@@ -275,7 +294,8 @@ std::vector<uint32_t> prove_sharded(TwoAdicFriPcs& pcs, const Comm& comm, const 
             const size_t ri = st.rounds.size();
             launch_merkle_levels(ctx, tree.p, r.log_leaves);  // the slab's sub-tree
             // exchange 3; the top kernel observes the root and samples beta on every rank alike
-            gather_top(sh, tree.p + 8 * (merkle_total_digests(r.log_leaves) - 1), d_tops.p + top_words * ri,
+            gather_top(sh, "FRI round sub-roots", tree.p + 8 * (merkle_total_digests(r.log_leaves) - 1),
+                       d_tops.p + top_words * ri,
                        st.dch(), st.d_roots.p + 8 * ri, st.d_betas.p + ri);
             DevBuf<Ef> out(&ctx, h_loc);
             uint32_t* nd = nullptr;
@@ -299,7 +319,7 @@ std::vector<uint32_t> prove_sharded(TwoAdicFriPcs& pcs, const Comm& comm, const 
         }
         // exchange 4: the rest is short; every rank folds the whole vector
         DevBuf<Ef> full(&ctx, len);
-        comm.all_gather(folded.p, full.p, (size_t)loc * sizeof(Ef), ctx.stream);
+        coll_all_gather(ctx, comm, "FRI vector", folded.p, full.p, (size_t)loc * sizeof(Ef));
         st.keep_vecs.push_back(std::move(folded));
         std::vector<DevBuf<Ef>> no_inputs;
         fri_commit_rounds(ctx, fri, std::move(full), len, no_inputs, {}, 0, st);
@@ -415,7 +435,7 @@ std::vector<uint32_t> prove_sharded(TwoAdicFriPcs& pcs, const Comm& comm, const 
     if (Q) {
         DevBuf<uint32_t> d_seg(&ctx, seg.size()), d_all(&ctx, all_seg.size());
         h2d(ctx, d_seg.p, seg.data(), seg.size() * 4);
-        comm.all_gather(d_seg.p, d_all.p, seg.size() * 4, ctx.stream);
+        coll_all_gather(ctx, comm, "query answers", d_seg.p, d_all.p, seg.size() * 4);
         d2h_sync(ctx, all_seg.data(), d_all.p, all_seg.size() * 4);
     }
 

@@ -148,3 +148,72 @@ def test_bench_under_torch_distributed_run():
     assert len(lines) == 1, r.stdout[-1000:]
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["self_launched"] is False
+
+
+def test_stub_line_names_both_sharded_blocks():
+    import json
+
+    r = _run_bench(["--gpus", "2", "--steps", "4", "--warmup", "1"], {})
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rec["sharded_config4"] == {"skipped": "stub"} and rec["sharded_config5"] == {"skipped": "stub"}
+
+
+def test_collectives_table_from_stage_timings():
+    sys.path.insert(0, ROOT)
+    from tapstark_amd.benchutil import split_stage_timings
+
+    items = [("coset_lde", 1.5), ("collective: all_gather 32 B/rank (commit sub-roots)", 0.02),
+             ("merkle_commit", 0.5), ("coset_lde", 0.25),
+             ("collective: all_gather 32 B/rank (commit sub-roots)", 0.04),
+             ("collective: broadcast 67108864 B (quotient chunk)", 1.0),
+             ("collective: all_gather 32 B/rank (FRI round sub-roots)", 0.03)]
+    stages, table = split_stage_timings(items)
+    assert stages == {"coset_lde": 1.75, "merkle_commit": 0.5}
+    rows = {r["what"]: r for r in table}
+    assert rows["all_gather 32 B/rank (commit sub-roots)"]["count"] == 2
+    assert abs(rows["all_gather 32 B/rank (commit sub-roots)"]["ms_total"] - 0.06) < 1e-9
+    assert rows["all_gather 32 B/rank (commit sub-roots)"]["ms_max"] == 0.04
+    assert rows["broadcast 67108864 B (quotient chunk)"]["bytes"] == 67108864
+    assert rows["broadcast 67108864 B (quotient chunk)"]["collective"] == "broadcast"
+    assert len(table) == 3
+
+
+def test_shared_gpu_rehearsal_refuses_nccl():
+    # with every rank on GPU 0 RCCL fails with "Duplicate GPU detected"; say so up front
+    import pytest
+
+    sys.path.insert(0, ROOT)
+    from tapstark_amd import benchutil
+
+    old = dict(os.environ)
+    os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", TS_BENCH_SHARE_GPU="1")
+    try:
+        with pytest.raises(SystemExit, match="TS_BENCH_BACKEND=gloo"):
+            benchutil.init_dist(backend="nccl")
+    finally:
+        os.environ.clear()
+        os.environ.update(old)
+
+
+def test_watchdog_fires_on_its_thread_and_names_the_phase():
+    import time
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    seen = []
+    wd = bench.Watchdog(0.05, seen.append)
+    wd.phase = "sharded_config4: replicated: timed proofs"
+    time.sleep(0.3)
+    assert seen == ["sharded_config4: replicated: timed proofs"]
+    quiet = []
+    wd2 = bench.Watchdog(0.05, quiet.append)
+    wd2.done()
+    time.sleep(0.2)
+    assert quiet == []
+    # the timeout handler of the N > 1 block leaves with a NON-zero code (a hang must be visible)
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    body = src[src.index("def on_timeout(phase):"):src.index("env.dist.barrier()  # rank 0 comes here later")]
+    assert "os._exit(3)" in body and "os._exit(0)" not in body
+    assert "except BaseException" not in src[src.index("# ---- N > 1: BASELINE configs 4 and 5"):]

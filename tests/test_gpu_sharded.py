@@ -453,3 +453,66 @@ def test_config4_as_specified_eight_ranks_full_shape(ctx, orc):
     for r in range(G):
         assert errors[r] is None, f"rank {r}: {errors[r]!r}"
         assert len(proofs[r]) == len(want.words) and (proofs[r] == want.words).all(), f"rank {r} differs"
+
+
+# ------------------------------------------------------------------ BASELINE config 5 over 8 ranks
+def _thread_ranks(G, rank_fn):
+    import threading
+
+    out, errors = [None] * G, [None] * G
+
+    def main(r):
+        try:
+            out[r] = rank_fn(r)
+        except BaseException as e:  # noqa: BLE001
+            errors[r] = e
+
+    threads = [threading.Thread(target=main, args=(r,)) for r in range(G)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert not any(t.is_alive() for t in threads), "a rank is stuck in a collective"
+    for r in range(G):
+        assert errors[r] is None, f"rank {r}: {errors[r]!r}"
+    return out
+
+
+@pytest.mark.parametrize("log_n,mode", [(10, "replicated"), (10, "sliced"), (12, "replicated"), (12, "sliced"),
+                                        (13, "colshard"), (13, "colshard-sliced"), (14, "colshard")])
+def test_config5_air_sharded_over_eight_ranks(ctx, orc, log_n, mode):
+    """BASELINE config 5 ("... on 8 x MI355X", shape README.md:91,101): SynthExt-163 at log_blowup 4 /
+    16 queries as ONE proof over 8 ranks (two cosets each; threads on the box's GPU over the native
+    in-process communicator).  163 columns do not divide by 8: the column-sharded inverse deals 21
+    columns to ranks 0-6 and 16 to rank 7 of a matrix padded to 168, and the strided leaf hash runs on
+    a slab with a ragged last block.  Byte-identical to ts_prove AND to the oracle's proof."""
+    from tapstark_amd.airs import SynthExtAir, generate_synth_ext_trace
+    from tapstark_amd.comm import LocalCommGroup
+
+    G, cfg, n = 8, (4, 16, 8), 1 << log_n
+    air = SynthExtAir(163)
+    tape = ts.air_tape(air, 0)
+    trace = generate_synth_ext_trace(n, 163)
+    config = ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(*cfg), ctx))
+    ch = ts.BfChallenger()
+    want = ts.prove(config, ts.CompiledAir(ctx, tape), ch, trace.copy(), [])
+    oracle = orc.prove(orc.FriConfig(*cfg), tape, trace, [])
+    assert len(oracle) == len(want.words) and (oracle == want.words).all()
+    group = LocalCommGroup(G)
+    sliced = mode.endswith("sliced")
+
+    def rank(r):
+        c = ts.Context(0)
+        conf = ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(*cfg), c))
+        rows = trace[r * n // G:(r + 1) * n // G] if sliced else trace
+        chal = ts.BfChallenger()
+        p = ts.prove_sharded(conf, ts.CompiledAir(c, tape), chal, np.ascontiguousarray(rows), [], group.comm(r),
+                             min_local_log=3 + (r is None), trace_replicated=not sliced,
+                             column_sharded_inverse=mode.startswith("colshard"))
+        return p.words, chal.sample_bits(20)
+
+    res = _thread_ranks(G, rank)
+    bits = ch.sample_bits(20)
+    for r, (words, b) in enumerate(res):
+        assert len(words) == len(oracle) and (words == oracle).all(), f"rank {r}: proof differs from the oracle's"
+        assert b == bits, f"rank {r}: transcript state differs"

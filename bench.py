@@ -1187,6 +1187,20 @@ def rank0_legs(ts, args, env, ctx, config, cair, lanes, S, pool, local_sync, mak
                                   "sampled from a host thread every 10 ms, outside the timed region"}
         except Exception as e:  # noqa: BLE001
             clocks = {"error": repr(e)}
+    # the VALU-issue ceiling at the clock MEASURED in this run (the static 2.0 GHz above came from
+    # SQ_BUSY_CYCLES of an earlier counter pass)
+    try:
+        mhz = clocks["prover_sustained"]["gfxclk_mhz_median"]
+        if valu_issue and mhz:
+            fl = valu_issue["wave_instructions_per_proof"] * 4 / valu_issue["simds"] / (mhz * 1e6) * 1e3
+            valu_issue["measured_clock"] = {
+                "gfxclk_mhz_median_under_this_load": mhz, "ms_per_proof_at_ceiling": round(fl, 4),
+                "frac_of_ceiling": round(fl / res["ms_per_step"], 4),
+                "socket_power_w_median": clocks["prover_sustained"]["socket_power_w_median"],
+                "note": "amdsmi sample of a sustained run of the same workload in this process (`clocks`); the "
+                        "register-resident ALU loops hold the clock in `clocks.alu_loop_butterflies`"}
+    except Exception:  # noqa: BLE001
+        pass
     # (the contract: timed on rank 0 at N = 1 only)
     same = args.workload == "config3" and args.log_n == 20 and timed_proof is not None
     cpu = None if (args.no_cpu_baseline or env.world > 1) else cpu_baseline(timed_proof.words if same else None)

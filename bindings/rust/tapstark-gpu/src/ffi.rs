@@ -1,4 +1,4 @@
-//! `extern "C"` declarations of include/tapstark.h (ABI version 3).  One line per entry point the
+//! `extern "C"` declarations of include/tapstark.h (ABI version 4).  One line per entry point the
 //! Rust side uses; the header is the authority for argument meaning.
 #![allow(non_camel_case_types)]
 use core::ffi::{c_char, c_int, c_void};
@@ -49,10 +49,12 @@ pub struct ts_rccl_info {
     pub comm_device: c_int,
     pub rccl_version: c_int,
     pub aborted: c_int,
+    pub checked: c_int,
 }
 
 extern "C" {
     pub fn ts_abi_version() -> u32;
+    pub fn ts_ctx_graph_stats(ctx: *mut ts_ctx, out: *mut u64) -> ts_status;
     pub fn ts_ctx_create(device: c_int, out: *mut *mut ts_ctx) -> ts_status;
     pub fn ts_ctx_destroy(ctx: *mut ts_ctx);
     pub fn ts_last_error(ctx: *const ts_ctx) -> *const c_char;

@@ -266,6 +266,8 @@ typedef struct {
     int rank, world;                 /* as passed to ts_comm_rccl_create */
     int comm_count, comm_user_rank;  /* as RCCL reports them */
     int comm_device, rccl_version, aborted;
+    int checked;  /* 1: ts_comm_rccl_create confirmed rank / world with ncclCommUserRank / ncclCommCount;
+                   * 0: this librccl lacks them, the check could not run */
 } ts_rccl_info;
 ts_status ts_comm_rccl_info(const ts_rccl_comm* handle, ts_rccl_info* out);
 /* In-process group: `world` ranks = `world` host threads of one process, each with its own

@@ -69,7 +69,7 @@ class RcclInfoC(C.Structure):
     """``ts_rccl_info`` (include/tapstark.h)."""
     _fields_ = [("rank", C.c_int), ("world", C.c_int), ("comm_count", C.c_int),
                 ("comm_user_rank", C.c_int), ("comm_device", C.c_int), ("rccl_version", C.c_int),
-                ("aborted", C.c_int)]
+                ("aborted", C.c_int), ("checked", C.c_int)]
 
 
 class ShardOptionsC(C.Structure):

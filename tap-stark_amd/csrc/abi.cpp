@@ -145,7 +145,7 @@ ts_status ts_proof_from_postcard_v(const uint8_t* bytes, size_t n_bytes, int tsp
     });
 }
 
-uint32_t ts_abi_version(void) { return 3; }  // 3: ts_proof_from_postcard_v, ts_comm_rccl_info, ts_comm_local_group_reset/_set_timeout
+uint32_t ts_abi_version(void) { return 4; }  // 4: ts_rccl_info.checked (struct grew), ts_ctx_graph_stats
 
 ts_status ts_ctx_create(int device, ts_ctx** out) {
     if (!out) return TS_ERR_INVALID;

@@ -18,6 +18,7 @@
 // group is poisoned (every waiting or later rendezvous returns an error), the RCCL communicator is
 // aborted (ncclCommAbort makes pending collectives on the peers fail rather than hang).
 #include <dlfcn.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -28,6 +29,7 @@
 #include <vector>
 
 #include "../../include/tapstark.h"
+#include "abi_types.hpp"
 #include "context.hpp"
 
 // ------------------------------------------------------------------ in-process group
@@ -199,6 +201,7 @@ struct ts_rccl_comm {
     NcclComm comm = nullptr;
     int rank = 0, world = 1;
     std::atomic<bool> aborted{false};
+    bool checked = false;  // ncclCommCount / ncclCommUserRank confirmed rank and world at creation
 };
 
 namespace {
@@ -304,6 +307,7 @@ ts_status ts_comm_rccl_create(ts_ctx* ctx, const uint8_t unique_id[128], int ran
     memcpy(id.internal, unique_id, 128);
     if (rccl().comm_init_rank(&c->comm, world, id, rank) != 0) {
         delete c;
+        ctx->ctx.last_error = "ncclCommInitRank failed";
         return TS_ERR_COMM;
     }
     c->rank = rank;
@@ -312,12 +316,21 @@ ts_status ts_comm_rccl_create(ts_ctx* ctx, const uint8_t unique_id[128], int ran
     // another size or rank would exchange the wrong slabs without any error
     if (rccl().comm_count && rccl().comm_user_rank) {
         int n = -1, r = -1;
-        if (rccl().comm_count(c->comm, &n) != 0 || rccl().comm_user_rank(c->comm, &r) != 0 ||
-            n != world || r != rank) {
+        const bool asked = rccl().comm_count(c->comm, &n) == 0 && rccl().comm_user_rank(c->comm, &r) == 0;
+        if (!asked || n != world || r != rank) {
+            char msg[200];
+            snprintf(msg, sizeof msg,
+                     "RCCL communicator mismatch: asked for rank %d of %d, ncclCommUserRank = %d, ncclCommCount = %d%s",
+                     rank, world, r, n, asked ? "" : " (query failed)");
+            ctx->ctx.last_error = msg;
+            // abort so that the peers' first collective fails instead of blocking; a librccl without
+            // ncclCommAbort still gets its communicator destroyed rather than leaked
             if (rccl().comm_abort) rccl().comm_abort(c->comm);
+            else if (rccl().comm_destroy) rccl().comm_destroy(c->comm);
             delete c;
             return TS_ERR_COMM;
         }
+        c->checked = true;
     }
     memset(out, 0, sizeof *out);
     out->rank = rank;
@@ -337,6 +350,7 @@ ts_status ts_comm_rccl_info(const ts_rccl_comm* c, ts_rccl_info* out) {
     out->rank = c->rank;
     out->world = c->world;
     out->aborted = c->aborted ? 1 : 0;
+    out->checked = c->checked ? 1 : 0;
     if (rccl().get_version) rccl().get_version(&out->rccl_version);
     if (!c->comm || c->aborted) return TS_OK;
     if (rccl().comm_count) rccl().comm_count(c->comm, &out->comm_count);

@@ -32,7 +32,10 @@
 // busy 0.67 with 44 % of its wave-cycles parked at barriers and scale-table loads).  The extra one
 // or two stages go to the contiguous passes as radix-32 register rounds (13 = 5+4+4, 14 = 5+5+4):
 // still three LDS round trips per chunk.
+#include <stdio.h>
 #include <stdlib.h>
+
+#include <initializer_list>
 
 #include "kernels.hpp"
 
@@ -594,20 +597,56 @@ k_lde_mid(const uint32_t* __restrict__ evals, uint64_t in_col_stride, uint32_t* 
 }
 
 // ------------------------------------------------------------------ host driver
-// chunk size of the contiguous passes: 2^12, or log_n - 8 for n = 2^21 / 2^22 (header comment);
-// TS_LDE_LM=12 forces the round-2 plans for an A/B
-static unsigned lde_chunk_log(unsigned log_n) {
-    static const int lm_env = [] {
-        const char* e = getenv("TS_LDE_LM");
-        return e ? atoi(e) : 0;
+// Tuning knobs of the LDE plans (A/B measurements; the defaults are what the tables in DESIGN.md were
+// measured with).  Parsed ONCE per process, strictly: a value outside a knob's list is reported on
+// stderr and ignored, so a typo cannot silently select another plan.
+//   TS_LDE_LM=12                 n = 2^21 / 2^22 with the 4096-element chunk plans of round 2
+//   TS_LDE_NO_FUSED_TRANSPOSE=1  transpose without the fused first inverse round
+//   TS_LDE_TILE=0|8192|16384|32768, TS_LDE_THREADS=512|1024   PLAN 2 tile / workgroup (with TS_LDE_LM=12)
+//   TS_LDE_FWD_CPW=1|2|4         chunks per workgroup of the 16384-element forward pass
+struct LdeKnobs {
+    int lm = 0;                   // 0 = default plan choice
+    bool no_fused_transpose = false;
+    int plan2_tile = 16384, plan2_threads = 1024, fwd_cpw = 4;
+};
+static int knob_int(const char* name, int dflt, std::initializer_list<int> allowed) {
+    const char* e = getenv(name);
+    if (!e) return dflt;
+    char* end = nullptr;
+    const long v = strtol(e, &end, 10);
+    bool ok = end != e && *end == 0;
+    bool listed = false;
+    for (int a : allowed) listed = listed || a == v;
+    if (!ok || !listed) {
+        fprintf(stderr, "tapstark: %s=%s ignored (allowed:", name, e);
+        for (int a : allowed) fprintf(stderr, " %d", a);
+        fprintf(stderr, "); using %d\n", dflt);
+        return dflt;
+    }
+    return (int)v;
+}
+static const LdeKnobs& lde_knobs() {
+    static const LdeKnobs k = [] {
+        LdeKnobs x;
+        x.lm = knob_int("TS_LDE_LM", 0, {12});
+        x.no_fused_transpose = knob_int("TS_LDE_NO_FUSED_TRANSPOSE", 0, {0, 1}) != 0;
+        x.plan2_tile = knob_int("TS_LDE_TILE", 16384, {0, 8192, 16384, 32768});
+        x.plan2_threads = knob_int("TS_LDE_THREADS", 1024, {512, 1024});
+        x.fwd_cpw = knob_int("TS_LDE_FWD_CPW", 4, {1, 2, 4});
+        return x;
     }();
-    return ((log_n == 21 || log_n == 22) && lm_env != 12) ? log_n - 8 : (unsigned)LOG_M;
+    return k;
+}
+
+// chunk size of the contiguous passes: 2^12, or log_n - 8 for n = 2^21 / 2^22 (header comment).
+// The one place that decides it: the fused transpose and coset_lde both ask here.
+static unsigned lde_chunk_log(unsigned log_n) {
+    return ((log_n == 21 || log_n == 22) && lde_knobs().lm != 12) ? log_n - 8 : (unsigned)LOG_M;
 }
 
 bool launch_transpose_bitrev_r16(Context& ctx, const uint32_t* src, uint32_t* dst, unsigned log_n, uint32_t w,
                                  uint64_t dst_col_stride, uint32_t src_width) {
-    static const bool off = getenv("TS_LDE_NO_FUSED_TRANSPOSE") != nullptr;  // A/B
-    if (off || w == 0 || log_n <= lde_chunk_log(log_n)) return false;  // no contiguous inverse pass to shorten
+    if (lde_knobs().no_fused_transpose || w == 0 || log_n <= lde_chunk_log(log_n)) return false;  // no contiguous inverse pass to shorten
     ctx.ensure_twiddles(log_n);
     TS_LAUNCH(ctx, k_transpose_bitrev_r16, dim3(1u << (log_n - 6), (w + 63) / 64), dim3(256), 0, src, dst, log_n, w,
               dst_col_stride, src_width ? src_width : w, (const uint32_t*)ctx.d_twiddle_inv);
@@ -632,18 +671,11 @@ void coset_lde(Context& ctx, uint32_t* evals, uint64_t in_col_stride, uint32_t n
     const uint32_t* W = ctx.d_twiddle_fwd;
     const uint32_t* Winv = ctx.d_twiddle_inv;
     unsigned log_T = 0;
-    // TS_LDE_TILE (0 = generic plan / 8192 / 16384 / 32768) picks the PLAN 2 tile: a tuning knob.
-    // Measured on 2^22 x 64, log_blowup 4 (ms per launch): generic 19.1, 8192 15.7, 16384 13.8,
-    // 32768 30.3 (one workgroup per CU); with the register-resident outer rounds and the last round
-    // stored straight to HBM 16384 went 13.8 -> 11.7, and to 11.1 with 1024 threads (TS_LDE_THREADS)
-    static const int plan2_tile = [] {
-        const char* e = getenv("TS_LDE_TILE");
-        return e ? atoi(e) : 16384;
-    }();
-    static const int plan2_threads = [] {
-        const char* e = getenv("TS_LDE_THREADS");
-        return e ? atoi(e) : 1024;  // 114 VGPRs, 16 waves per CU; 512 threads: 191 VGPRs, 8 waves
-    }();
+    // PLAN 2 tile (TS_LDE_TILE).  Measured on 2^22 x 64, log_blowup 4 (ms per launch): generic 19.1,
+    // 8192 15.7, 16384 13.8, 32768 30.3 (one workgroup per CU); with the register-resident outer rounds
+    // and the last round stored straight to HBM 16384 went 13.8 -> 11.7, and to 11.1 with 1024 threads
+    // (TS_LDE_THREADS: 114 VGPRs, 16 waves per CU; 512 threads: 191 VGPRs, 8 waves)
+    const int plan2_tile = lde_knobs().plan2_tile, plan2_threads = lde_knobs().plan2_threads;
     const bool plan2 = two_pass && sA == 10 && plan2_tile != 0;
     if (two_pass && sA <= 13) {
         while ((1u << (sA + log_T + 1)) <= (unsigned)TILE_ELEMS && log_T < 6) log_T++;
@@ -707,11 +739,9 @@ void coset_lde(Context& ctx, uint32_t* evals, uint64_t in_col_stride, uint32_t n
         else
             TS_LAUNCH(ctx, k_lde_mid<0>, grid, dim3(NT_MID), 0, TS_MID_ARGS);
         const dim3 gf(1u << sA, ncols, n_beta);
-        static const int fwd_cpw = [] {  // chunks per workgroup of the 16384-element forward pass (1, 2, 4)
-            const char* e = getenv("TS_LDE_FWD_CPW");
-            const int v = e ? atoi(e) : 4;  // measured 12.49 (1) / 13.34 (2: spills) / 12.22 ms (4) per proof
-            return v == 1 || v == 2 ? v : 4;
-        }();
+        // chunks per workgroup of the 16384-element forward pass: measured 12.49 (1) / 13.34 (2: spills) /
+        // 12.22 ms (4) per proof
+        const int fwd_cpw = lde_knobs().fwd_cpw;
         if (LM == 12)
             TS_LAUNCH(ctx, k_lde_fwd_contig<12>, gf, dim3(chunk_threads(12)), 0, out, out_col_stride, log_n, W);
         else if (LM == 13)

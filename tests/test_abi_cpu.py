@@ -29,7 +29,7 @@ def test_header_symbols_all_exported(lib):
     assert declared == set(_lib.ABI_SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.ts_abi_version() == 3
+    assert lib.ts_abi_version() == 4
 
 
 def test_no_cpu_fallback_without_device(lib):

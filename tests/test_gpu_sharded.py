@@ -507,7 +507,7 @@ def test_config5_air_sharded_over_eight_ranks(ctx, orc, log_n, mode):
         rows = trace[r * n // G:(r + 1) * n // G] if sliced else trace
         chal = ts.BfChallenger()
         p = ts.prove_sharded(conf, ts.CompiledAir(c, tape), chal, np.ascontiguousarray(rows), [], group.comm(r),
-                             min_local_log=3 + (r is None), trace_replicated=not sliced,
+                             min_local_log=3, trace_replicated=not sliced,
                              column_sharded_inverse=mode.startswith("colshard"))
         return p.words, chal.sample_bits(20)
 

@@ -380,6 +380,8 @@ def sharded_block(name: str, ts, env, ctx, dev, watchdog: Watchdog | None, state
                    holds >= 2^12 values (min_local_log 12)
       mll16/mll20  the same with min_local_log 16 / 20: fewer sub-root all-gathers, more replicated
                    tail rounds (csrc/sharded.cpp)
+      localq       every rank evaluates the quotient on its own cosets: no chunk broadcast, no rank
+                   waiting for the owner of the quotient domain (ts_shard_options.local_quotient)
       colshard     + column-sharded inverse NTT (one more bulk all-gather)
       sliced       row slices in (adds the trace all-gather)
     Every variant reports ms/step, per-rank stage times and the table of its collectives (kind, bytes,
@@ -442,17 +444,17 @@ def sharded_block(name: str, ts, env, ctx, dev, watchdog: Watchdog | None, state
     def gen():
         return ts.DeviceMatrix.synth_mul(ctx, n, w) if spec["air"] == "mul64" else ts.DeviceMatrix.synth_ext(ctx, n, w)
 
-    variants = os.environ.get("TS_BENCH_SHARD_VARIANTS", "replicated,mll16,mll20,colshard").split(",")
+    variants = os.environ.get("TS_BENCH_SHARD_VARIANTS", "replicated,localq,mll16,mll20,colshard").split(",")
     out["variants"] = {}
     digests = set()
     for var in variants:
         var = var.strip()
-        if var not in ("replicated", "mll16", "mll20", "colshard", "sliced"):
+        if var not in ("replicated", "localq", "mll16", "mll20", "colshard", "sliced"):
             continue
         phase(f"{var}: inputs")
         sliced = var == "sliced"
         kw = dict(trace_replicated=not sliced, column_sharded_inverse=(var == "colshard"),
-                  min_local_log={"mll16": 16, "mll20": 20}.get(var, 12))
+                  local_quotient=(var == "localq"), min_local_log={"mll16": 16, "mll20": 20}.get(var, 12))
         if sliced:
             full = gen().download()
             rows = np.ascontiguousarray(full[grank * n // gsize:(grank + 1) * n // gsize])

@@ -37,6 +37,7 @@ pub struct ts_shard_options {
     pub min_local_log: u32,
     pub trace_replicated: u32,
     pub column_sharded_inverse: u32,
+    pub local_quotient: u32,
 }
 
 #[repr(C)]

@@ -298,6 +298,13 @@ typedef struct {
     uint32_t column_sharded_inverse; /* 1: transposes + the per-column stages of the inverse NTT run
                                   on w/G columns per rank, followed by an all-gather of the
                                   half-transformed columns */
+    uint32_t local_quotient;   /* 1: every rank evaluates the quotient (uni-stark/src/prover.rs:65-80) on
+                                  its OWN cosets and derives its slab of the chunk LDEs from that: no rank
+                                  waits for the owner of the quotient domain, no chunk broadcast.  Needs
+                                  2^log_blowup / world >= quotient degree (else ignored).  Same proof for
+                                  every trace that satisfies its constraints; for one that does not,
+                                  constraints / Z_H is no polynomial and the committed chunks differ from
+                                  ts_prove's (both proofs are rejected by the verifier) */
 } ts_shard_options;
 ts_status ts_prove_sharded(ts_ctx* ctx, const ts_fri_config* cfg, const ts_comm* comm,
                            const ts_air* air, ts_challenger* chal, ts_matrix* trace_rows,

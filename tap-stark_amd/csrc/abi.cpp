@@ -722,6 +722,7 @@ ts_status ts_prove_sharded(ts_ctx* ctx, const ts_fri_config* cfg, const ts_comm*
         }
         if (options) opt.trace_replicated = options->trace_replicated != 0;
         if (options) opt.column_sharded_inverse = options->column_sharded_inverse != 0;
+        if (options) opt.local_quotient = options->local_quotient != 0;
         ts::StageTimer t(&ctx->ctx, "prove");
         std::vector<uint32_t> proof;
         try {

@@ -74,6 +74,7 @@ struct Context {
     // quotient.hip): a function of (log_n, log_qd) only, so repeated proofs of one shape reuse it
     uint32_t* d_selectors = nullptr;
     unsigned sel_log_n = ~0u, sel_log_qd = ~0u;
+    uint32_t sel_shift = 0;
 
     // zero-initialised words (17 lines of 64 bytes) the "last workgroup done" kernels count in
     // (merkle.hip); each kernel leaves them at zero, and launches on the one stream run in order

@@ -115,9 +115,12 @@ public:
         uint64_t row0 = 0, rows = 0;  // rows = 0: the whole LDE
         uint32_t beta0 = 0;
     };
+    // domain_shift: the shift s of the quotient domain s * H_{n qd} the slab's first rows are the
+    // evaluations on (31 for the reference's own domain; a rank's own cosets otherwise)
     std::vector<DeviceMatrix> quotient_chunks_slab(const ColMat& lde_slab, unsigned log_n, const Slab& slab,
                                                    const AirProgram& air,
-                                                   const std::vector<uint32_t>& public_values, Ef alpha);
+                                                   const std::vector<uint32_t>& public_values, Ef alpha,
+                                                   uint32_t domain_shift = GENERATOR);
     DevBuf<Ef> open_reduce_slab(const PcsData& trace_data, const PcsData& quotient_data, unsigned log_N,
                                 const Slab& slab, Ef zeta, Ef batch_alpha, std::vector<Ef>& opened_values);
 
@@ -174,6 +177,13 @@ struct ShardOptions {
     // rank repeating them for every column.  Trades ~1/4 of a rank's LDE arithmetic for one more
     // bulk exchange: see DESIGN.md section 6 for when that pays.
     bool column_sharded_inverse = false;
+    // true: every rank evaluates the quotient on its OWN cosets and derives its slab of the chunk
+    // LDEs from that (sharded.cpp "local quotient"): no rank waits for the owner of the quotient
+    // domain, no chunk broadcast.  Needs 2^log_blowup / G >= quotient degree (else the broadcast
+    // path runs).  Identical proofs for every trace that satisfies its constraints; for a trace that
+    // does not (which a release build of the reference proves without complaint, prover.rs:40-41)
+    // constraints / Z_H is not a polynomial and the two paths commit to different chunks.
+    bool local_quotient = false;
 };
 // rank g owns the bit-reversed LDE rows [g N/G, (g+1) N/G) (whole cosets,
 // G <= 2^log_blowup) of every committed matrix and the matching Merkle sub-trees, FRI slabs and

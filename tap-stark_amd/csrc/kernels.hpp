@@ -102,7 +102,7 @@ inline uint64_t merkle_total_digests(unsigned log_leaves) { return ((uint64_t)2 
 // ---- quotient.hip ----------------------------------------------------------------------------
 struct AirProgram;  // air.hpp
 void launch_selectors(Context& ctx, unsigned log_n, unsigned log_qd, uint32_t* is_first,
-                      uint32_t* is_last, uint32_t* is_transition);
+                      uint32_t* is_last, uint32_t* is_transition, uint32_t shift = GENERATOR);
 // quotient chunks, each written column-major (4 columns x n) with bit-reversed rows:
 // coefficient k of chunk c at chunk[c][k * n + pos]
 constexpr int MAX_QUOTIENT_CHUNKS = 64;  // quotient_degree <= 64 (log_quotient_degree <= log_blowup <= 8)
@@ -115,7 +115,12 @@ struct QuotOut {
 void launch_quotient(Context& ctx, const AirProgram& air, const ColMat& trace_lde, unsigned log_n,
                      unsigned log_qd, const uint32_t* d_consts_mont, const uint32_t* d_alpha_pows_mont,
                      const uint32_t* is_first, const uint32_t* is_last, const uint32_t* is_transition,
-                     const QuotOut& out, uint64_t row_begin = 0, uint64_t row_end = 0);
+                     const QuotOut& out, uint64_t row_begin = 0, uint64_t row_end = 0,
+                     uint32_t shift = GENERATOR);
+// sharded.cpp "local quotient": in place on the slab LDEs of the qd chunk matrices (4 columns each),
+// out[c] = sum_c' mix[c * qd + c'] * in[c'] per row and per column (mix: Montgomery form, device)
+void launch_chunk_mix(Context& ctx, uint32_t* const* d_chunk_ptrs, uint32_t qd, uint64_t rows, uint64_t col_stride,
+                      const uint32_t* d_mix_mont);
 
 // check_constraints.rs:11-39 on the row-major trace; *d_violation (preset to ~0) receives
 // row * 2^16 + constraint index of the first violated constraint

@@ -189,7 +189,8 @@ std::vector<DeviceMatrix> TwoAdicFriPcs::quotient_chunks(const PcsData& trace_da
 
 std::vector<DeviceMatrix> TwoAdicFriPcs::quotient_chunks_slab(const ColMat& lde_slab, unsigned log_n,
                                                               const Slab& slab, const AirProgram& air,
-                                                              const std::vector<uint32_t>& pis, Ef alpha) {
+                                                              const std::vector<uint32_t>& pis, Ef alpha,
+                                                              uint32_t domain_shift) {
     StageTimer t(&ctx_, "compute quotient polynomial");
     TS_REQUIRE(lde_slab.width == air.width, TS_ERR_INVALID, "quotient: trace width != AIR width");
     TS_REQUIRE(pis.size() == air.n_public, TS_ERR_INVALID, "quotient: wrong number of public values");
@@ -207,15 +208,17 @@ std::vector<DeviceMatrix> TwoAdicFriPcs::quotient_chunks_slab(const ColMat& lde_
     TS_REQUIRE(row_begin % n == 0 && row_end % n == 0, TS_ERR_INVALID, "quotient: slab must hold whole cosets");
 
     // selectors depend on the shape only: kept in the context between proofs
-    if (ctx_.sel_log_n != log_n || ctx_.sel_log_qd != lqd) {
+    if (ctx_.sel_log_n != log_n || ctx_.sel_log_qd != lqd || ctx_.sel_shift != domain_shift) {
         ctx_.sync();  // an earlier launch may still read the old table
         if (ctx_.d_selectors) (void)hipFree(ctx_.d_selectors);
         ctx_.d_selectors = nullptr;
         ctx_.sel_log_n = ctx_.sel_log_qd = ~0u;
         TS_HIP(hipMalloc((void**)&ctx_.d_selectors, 3 * qn * sizeof(uint32_t)));
-        launch_selectors(ctx_, log_n, lqd, ctx_.d_selectors, ctx_.d_selectors + qn, ctx_.d_selectors + 2 * qn);
+        launch_selectors(ctx_, log_n, lqd, ctx_.d_selectors, ctx_.d_selectors + qn, ctx_.d_selectors + 2 * qn,
+                         domain_shift);
         ctx_.sel_log_n = log_n;
         ctx_.sel_log_qd = lqd;
+        ctx_.sel_shift = domain_shift;
     }
     struct { uint32_t* p; } sel{ctx_.d_selectors};
 
@@ -254,7 +257,7 @@ std::vector<DeviceMatrix> TwoAdicFriPcs::quotient_chunks_slab(const ColMat& lde_
         ColMat lde = lde_slab;
         lde.d = lde_slab.d - slab.row0;  // global row r of the slab's range lives at d[r]
         launch_quotient(ctx_, air, lde, log_n, lqd, d_consts.p, d_apow.p, sel.p, sel.p + qn, sel.p + 2 * qn,
-                        qo, row_begin, row_end);
+                        qo, row_begin, row_end, domain_shift);
     }
     return chunks;  // (the staged uploads live in the context's pinned arena: no sync needed)
 }

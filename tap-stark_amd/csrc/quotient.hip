@@ -15,7 +15,9 @@
 namespace ts {
 
 // ------------------------------------------------------------------ selectors
-// Storage index r <-> natural index i = bitrev_L(r); x_r = 31 * omega_{2^L}^i.
+// Storage index r <-> natural index i = bitrev_L(r); x_r = shift * omega_{2^L}^i (shift = 31, the
+// quotient domain of prover.rs:65-66; a rank of the sharded prover that evaluates the quotient on its
+// own cosets passes their shift, sharded.cpp "local quotient").
 // W is the block-twiddle table: omega_{2^L}^bitrev_L(r) = (r odd ? -1 : 1) * W[2^(L-1) + (r >> 1)].
 constexpr int SEL_BATCH = 8;
 
@@ -72,18 +74,18 @@ k_selectors(unsigned L, unsigned log_qd, const uint32_t* __restrict__ W, uint32_
 }
 
 void launch_selectors(Context& ctx, unsigned log_n, unsigned log_qd, uint32_t* is_first,
-                      uint32_t* is_last, uint32_t* is_transition) {
+                      uint32_t* is_last, uint32_t* is_transition, uint32_t shift) {
     const unsigned L = log_n + log_qd;
     TS_REQUIRE((1u << log_qd) <= (unsigned)MAX_QUOTIENT_CHUNKS, TS_ERR_UNSUPPORTED, "quotient degree > 64 not supported");
     ctx.ensure_twiddles(L == 0 ? 1 : L);
     SelConsts sc;
-    const uint32_t s_pow_n = pow_canon(GENERATOR, 1ull << log_n);
+    const uint32_t s_pow_n = pow_canon(shift, 1ull << log_n);
     const uint32_t gqd = two_adic_generator(log_qd);
     for (uint32_t c = 0; c < (1u << log_qd); c++)
         sc.zh_mont[c] = to_mont(sub(mul(s_pow_n, pow_canon(gqd, c)), 1));
     const uint32_t gn_inv = inv_canon(two_adic_generator(log_n));
     const uint64_t threads = (((uint64_t)1 << L) + SEL_BATCH - 1) / SEL_BATCH;
-    TS_LAUNCH(ctx, k_selectors, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, L, log_qd, ctx.d_twiddle_fwd, to_mont(GENERATOR), to_mont(gn_inv), sc, is_first,
+    TS_LAUNCH(ctx, k_selectors, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, L, log_qd, ctx.d_twiddle_fwd, to_mont(shift), to_mont(gn_inv), sc, is_first,
                        is_last, is_transition);
     TS_HIP(hipGetLastError());
 }
@@ -161,11 +163,11 @@ k_quotient(const uint32_t* __restrict__ code, uint32_t n_instr, uint32_t n_regs,
 void launch_quotient(Context& ctx, const AirProgram& air, const ColMat& trace_lde, unsigned log_n,
                      unsigned log_qd, const uint32_t* d_consts_mont, const uint32_t* d_alpha_pows_mont,
                      const uint32_t* is_first, const uint32_t* is_last, const uint32_t* is_transition,
-                     const QuotOut& out, uint64_t row_begin, uint64_t row_end) {
+                     const QuotOut& out, uint64_t row_begin, uint64_t row_end, uint32_t shift) {
     TS_REQUIRE(air.d_code != nullptr, TS_ERR_INVALID, "air program not uploaded");
     TS_REQUIRE(log_n + log_qd <= 31, TS_ERR_INVALID, "quotient domain too large");
     QuotConsts qc;
-    const uint32_t s_pow_n = pow_canon(GENERATOR, 1ull << log_n);
+    const uint32_t s_pow_n = pow_canon(shift, 1ull << log_n);
     const uint32_t gqd = two_adic_generator(log_qd);
     for (uint32_t c = 0; c < (1u << log_qd); c++)
         qc.inv_zh_canonical[c] = inv_canon(sub(mul(s_pow_n, pow_canon(gqd, c)), 1));
@@ -202,6 +204,45 @@ void launch_quotient(Context& ctx, const AirProgram& air, const ColMat& trace_ld
     else if (nthreads == 128) TS_LAUNCH_Q(128);
     else TS_LAUNCH_Q(64);
 #undef TS_LAUNCH_Q
+    TS_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------ chunk mix (sharded local quotient)
+// One thread per (row, base column j < 4) of the slab: v[c'] = chunk c' column j at this row, then
+// chunk c <- sum_c' mix[c][c'] v[c'].  Canonical values x Montgomery constants -> canonical.
+template <int QD>
+__global__ void __launch_bounds__(256)
+k_chunk_mix(uint32_t* const* __restrict__ chunks, uint64_t rows, uint64_t col_stride,
+            const uint32_t* __restrict__ mix) {
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= 4 * rows) return;
+    const uint64_t row = t % rows, j = t / rows;
+    uint32_t v[QD];
+#pragma unroll
+    for (int c = 0; c < QD; c++) v[c] = chunks[c][j * col_stride + row];
+#pragma unroll
+    for (int c = 0; c < QD; c++) {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int k = 0; k < QD; k++) acc = add(acc, mont_mul(v[k], mix[c * QD + k]));
+        chunks[c][j * col_stride + row] = acc;
+    }
+}
+
+void launch_chunk_mix(Context& ctx, uint32_t* const* d_chunk_ptrs, uint32_t qd, uint64_t rows, uint64_t col_stride,
+                      const uint32_t* d_mix_mont) {
+    const dim3 grid((unsigned)((4 * rows + 255) / 256));
+#define TS_MIX(Q) TS_LAUNCH(ctx, k_chunk_mix<Q>, grid, dim3(256), 0, d_chunk_ptrs, rows, col_stride, d_mix_mont)
+    switch (qd) {
+        case 2: TS_MIX(2); break;
+        case 4: TS_MIX(4); break;
+        case 8: TS_MIX(8); break;
+        case 16: TS_MIX(16); break;
+        case 32: TS_MIX(32); break;
+        case 64: TS_MIX(64); break;
+        default: TS_REQUIRE(false, TS_ERR_INVALID, "chunk mix: quotient degree must be 2 .. 64");
+    }
+#undef TS_MIX
     TS_HIP(hipGetLastError());
 }
 

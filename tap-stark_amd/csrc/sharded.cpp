@@ -70,8 +70,11 @@ void gather_top(Shard& sh, const char* site, const uint32_t* d_subroot, uint32_t
 }
 
 // two_adic_pcs.rs:227-245 for the owned cosets + the slab's sub-tree; `evals` are whole matrices
+// mix (local quotient, below): a qd x qd canonical matrix applied across the batch's matrices (the
+// chunk LDEs, 4 columns each) between the LDE and the leaf hashes
 std::unique_ptr<ShardedData> commit_sharded(Shard& sh, std::vector<DeviceMatrix>& evals,
-                                            const std::vector<uint32_t>& domain_shifts) {
+                                            const std::vector<uint32_t>& domain_shifts,
+                                            const std::vector<uint32_t>* mix = nullptr) {
     Context& ctx = sh.ctx;
     TS_REQUIRE(!evals.empty() && evals.size() <= (size_t)MAX_BATCH_MATS, TS_ERR_INVALID,
                "commit: between 1 and 16 matrices per batch");
@@ -149,6 +152,23 @@ std::unique_ptr<ShardedData> commit_sharded(Shard& sh, std::vector<DeviceMatrix>
             m.buf.reset();  // consumed
         }
     }
+    if (mix) {
+        StageTimer t(&ctx, "mix chunk LDEs (local quotient)");
+        const uint32_t qd = (uint32_t)evals.size();
+        TS_REQUIRE(mix->size() == (size_t)qd * qd, TS_ERR_INVARIANT, "chunk mix: matrix size");
+        std::vector<uint32_t*> ptrs;
+        for (auto& cm : loc.ldes) {
+            TS_REQUIRE(cm.width == 4 && cm.col_stride == rows, TS_ERR_INVARIANT, "chunk mix: chunk LDE shape");
+            ptrs.push_back(cm.d);
+        }
+        std::vector<uint32_t> mm(mix->size());
+        for (size_t i = 0; i < mm.size(); i++) mm[i] = to_mont((*mix)[i]);
+        DevBuf<uint32_t*> d_ptrs(&ctx, ptrs.size());
+        DevBuf<uint32_t> d_mix(&ctx, mm.size());
+        h2d(ctx, d_ptrs.p, ptrs.data(), ptrs.size() * sizeof(uint32_t*));
+        h2d(ctx, d_mix.p, mm.data(), mm.size() * 4);
+        launch_chunk_mix(ctx, d_ptrs.p, qd, rows, rows, d_mix.p);
+    }
     {
         StageTimer t(&ctx, "merkle_commit");
         loc.tree = DevBuf<uint32_t>(&ctx, merkle_total_digests(log_rows) * 8);
@@ -168,6 +188,72 @@ std::unique_ptr<ShardedData> commit_sharded(Shard& sh, std::vector<DeviceMatrix>
         memcpy(loc.root, &data->top[8 * (size_t)sh.rank], 32);
     }
     return data;
+}
+
+// ---- local quotient ------------------------------------------------------------------------------
+// The reference evaluates the quotient q = constraints / Z_H on the quotient domain 31 H_{n qd}
+// (prover.rs:65-77) -- in the sharded layout the first qd cosets, all on the low ranks -- splits the
+// values into qd chunks (chunk c = the values on D_c = 31 w^c H_n, w = omega_{n qd}; :78-80) and
+// commits to the LDE of each chunk's interpolant q_c (:82-83).  Writing q = sum_k X^(kn) Q_k with
+// deg Q_k < n, that interpolant is q mod (X^n - a_c) = sum_k a_c^k Q_k, a_c = (31 w^c)^n = 31^n w_qd^c.
+// A rank that owns cosets beta0 .. beta0 + qd - 1 (aligned) holds the trace LDE on s_g H_{n qd},
+// s_g = 31 omega_N^bitrev(beta0), in the same bit-reversed layout, so the SAME quotient kernel run on
+// its slab with shift s_g gives q there: the values on s_g w^c' H_n, whose interpolants are
+// r_c' = q mod (X^n - b_c') = sum_k b_c'^k Q_k, b_c' = s_g^n w_qd^c'.  Both families are the images of
+// (Q_k) under Vandermonde matrices, so q_c = sum_c' M[c][c'] r_c' with M = V(a) V(b)^-1, a qd x qd
+// matrix of base-field constants: the rank extends the r_c' to its cosets like any committed matrix
+// (coset_lde with the domain shift s_g w^c') and mixes the qd results row by row.  No rank waits for
+// the owner of the quotient domain and nothing is broadcast.  Exact field arithmetic: the chunk LDEs
+// are the reference's whenever q is a polynomial of degree < n qd, i.e. whenever the trace satisfies
+// its constraints (ShardOptions::local_quotient).
+std::vector<uint32_t> chunk_mix_matrix(uint32_t qd, unsigned log_n, uint32_t s_g) {
+    const unsigned lqd = log2_strict(qd);
+    const uint32_t gqd = two_adic_generator(lqd);
+    const uint32_t an = pow_canon(GENERATOR, 1ull << log_n), bn = pow_canon(s_g, 1ull << log_n);
+    std::vector<uint32_t> A((size_t)qd * qd), B((size_t)qd * qd), Binv((size_t)qd * qd, 0);
+    for (uint32_t c = 0; c < qd; c++) {
+        const uint32_t a = mul(an, pow_canon(gqd, c)), b = mul(bn, pow_canon(gqd, c));
+        uint32_t pa = 1, pb = 1;
+        for (uint32_t k = 0; k < qd; k++) {
+            A[(size_t)c * qd + k] = pa;
+            B[(size_t)c * qd + k] = pb;
+            pa = mul(pa, a);
+            pb = mul(pb, b);
+        }
+        Binv[(size_t)c * qd + c] = 1;
+    }
+    // Gauss-Jordan on [B | I] over the field (the b_c' are distinct: B is invertible)
+    for (uint32_t col = 0; col < qd; col++) {
+        uint32_t piv = col;
+        while (piv < qd && B[(size_t)piv * qd + col] == 0) piv++;
+        TS_REQUIRE(piv < qd, TS_ERR_INVARIANT, "chunk mix: singular Vandermonde");
+        if (piv != col)
+            for (uint32_t k = 0; k < qd; k++) {
+                std::swap(B[(size_t)piv * qd + k], B[(size_t)col * qd + k]);
+                std::swap(Binv[(size_t)piv * qd + k], Binv[(size_t)col * qd + k]);
+            }
+        const uint32_t inv = inv_canon(B[(size_t)col * qd + col]);
+        for (uint32_t k = 0; k < qd; k++) {
+            B[(size_t)col * qd + k] = mul(B[(size_t)col * qd + k], inv);
+            Binv[(size_t)col * qd + k] = mul(Binv[(size_t)col * qd + k], inv);
+        }
+        for (uint32_t r = 0; r < qd; r++) {
+            const uint32_t f = B[(size_t)r * qd + col];
+            if (r == col || f == 0) continue;
+            for (uint32_t k = 0; k < qd; k++) {
+                B[(size_t)r * qd + k] = sub(B[(size_t)r * qd + k], mul(f, B[(size_t)col * qd + k]));
+                Binv[(size_t)r * qd + k] = sub(Binv[(size_t)r * qd + k], mul(f, Binv[(size_t)col * qd + k]));
+            }
+        }
+    }
+    std::vector<uint32_t> M((size_t)qd * qd, 0);
+    for (uint32_t c = 0; c < qd; c++)
+        for (uint32_t cp = 0; cp < qd; cp++) {
+            uint32_t acc = 0;
+            for (uint32_t k = 0; k < qd; k++) acc = add(acc, mul(A[(size_t)c * qd + k], Binv[(size_t)k * qd + cp]));
+            M[(size_t)c * qd + cp] = acc;
+        }
+    return M;
 }
 
 // siblings of sub-tree `rank` in the top levels, leaf-most first
@@ -240,19 +326,34 @@ std::vector<uint32_t> prove_sharded(TwoAdicFriPcs& pcs, const Comm& comm, const 
 
     // :65-80 the quotient domain is the first qd cosets: chunk c = coset bitrev(c), computed by the
     // rank that owns that coset, then broadcast (exchange 2)
-    std::vector<DeviceMatrix> chunks =
-        pcs.quotient_chunks_slab(trace_data->local.ldes[0], log_degree, slab, air, public_values, alpha);
-    {
-        StageTimer t(&ctx, "broadcast quotient chunks");
-        for (uint32_t c = 0; c < qd; c++) {
-            const uint32_t owner = bitrev32(c, lqd) / sh.cosets;
-            coll_broadcast(ctx, comm, "quotient chunk", chunks[c].buf.p, (size_t)n * 16, (int)owner);
-        }
-    }
     std::vector<uint32_t> qshifts(qd);
     const uint32_t gq = two_adic_generator(log_degree + lqd);
-    for (uint32_t c = 0; c < qd; c++) qshifts[c] = mul(GENERATOR, pow_canon(gq, c));
-    std::unique_ptr<ShardedData> quotient_data = commit_sharded(sh, chunks, qshifts);  // :82-83
+    std::unique_ptr<ShardedData> quotient_data;
+    if (opt.local_quotient && sh.cosets >= qd) {
+        // every rank on its own cosets ("local quotient" above); with qd = 1 the values on the rank's
+        // first coset determine q itself and the mix is the identity
+        const uint32_t s_g =
+            mul(GENERATOR, pow_canon(two_adic_generator(log_N), bitrev32(sh.beta0, fri.log_blowup)));
+        std::vector<DeviceMatrix> chunks = pcs.quotient_chunks_slab(trace_data->local.ldes[0], log_degree,
+                                                                    TwoAdicFriPcs::Slab{}, air, public_values,
+                                                                    alpha, s_g);
+        for (uint32_t c = 0; c < qd; c++) qshifts[c] = mul(s_g, pow_canon(gq, c));
+        std::vector<uint32_t> mix;
+        if (qd > 1) mix = chunk_mix_matrix(qd, log_degree, s_g);
+        quotient_data = commit_sharded(sh, chunks, qshifts, qd > 1 ? &mix : nullptr);  // :82-83
+    } else {
+        std::vector<DeviceMatrix> chunks =
+            pcs.quotient_chunks_slab(trace_data->local.ldes[0], log_degree, slab, air, public_values, alpha);
+        {
+            StageTimer t(&ctx, "broadcast quotient chunks");
+            for (uint32_t c = 0; c < qd; c++) {
+                const uint32_t owner = bitrev32(c, lqd) / sh.cosets;
+                coll_broadcast(ctx, comm, "quotient chunk", chunks[c].buf.p, (size_t)n * 16, (int)owner);
+            }
+        }
+        for (uint32_t c = 0; c < qd; c++) qshifts[c] = mul(GENERATOR, pow_canon(gq, c));
+        quotient_data = commit_sharded(sh, chunks, qshifts);  // :82-83
+    }
     challenger.observe_commitment(quotient_data->root);                                 // :84
     const Ef zeta = challenger.sample();                                                // :91
 

@@ -686,13 +686,15 @@ def prove(config: StarkConfig, air, challenger: BfChallenger, trace, public_valu
 
 def prove_sharded(config: StarkConfig, air, challenger: BfChallenger, trace_rows, public_values,
                   comm, min_local_log: int = 0, trace_replicated: bool = False,
-                  column_sharded_inverse: bool = False) -> Proof:
+                  column_sharded_inverse: bool = False, local_quotient: bool = False) -> Proof:
     """One proof over ``comm.world`` GPUs (``ts_prove_sharded``).
 
     Every rank calls this with its own context, a challenger in the same state and its row slice
     ``trace_rows`` = natural rows [g n/G, (g+1) n/G) of the trace; every rank gets the whole proof,
     bit-identical to :func:`prove` on the whole trace.  ``comm`` is a ``dist.TorchComm``.
     ``trace_replicated``: ``trace_rows`` is the whole trace on every rank (no all-gather of it).
+    ``local_quotient``: every rank computes the quotient on its own cosets (no chunk broadcast; valid
+    traces only -- ``ts_shard_options.local_quotient`` in include/tapstark.h).
     """
     pcs = config.pcs
     ctx = pcs.ctx
@@ -713,7 +715,8 @@ def prove_sharded(config: StarkConfig, air, challenger: BfChallenger, trace_rows
     n_words = C.c_size_t()
     cfg = pcs.fri._c()
     pis_p = _p(pis) if len(pis) else None
-    opts = _lib.ShardOptionsC(min_local_log, int(trace_replicated), int(column_sharded_inverse))
+    opts = _lib.ShardOptionsC(min_local_log, int(trace_replicated), int(column_sharded_inverse),
+                              int(local_quotient))
     rc = ctx._l.ts_prove_sharded(ctx.h, C.byref(cfg), C.byref(comm.c), air.h, challenger.h,
                                  trace_rows.h, pis_p, len(pis), C.byref(opts), _p(out), cap,
                                  C.byref(n_words))

@@ -73,12 +73,15 @@ def test_full_size_proof_equals_oracle_digests(ctx, orc, name):
         assert (p2.words == proof.words).all()
 
 
-@pytest.mark.parametrize("name,G", [("config4", 8), ("config5", 8), ("config3", 4)])
-def test_full_size_sharded_proof_equals_oracle_digests(ctx, orc, name, G):
+@pytest.mark.parametrize("name,G,localq", [("config4", 8, False), ("config4", 8, True), ("config5", 8, False),
+                                           ("config5", 8, True), ("config3", 4, False), ("config3", 2, True)])
+def test_full_size_sharded_proof_equals_oracle_digests(ctx, orc, name, G, localq):
     """The same fixtures for ONE proof sharded over G ranks (threads on the box's one GPU, native
     in-process communicator): config 4 as BASELINE.json writes it (8 ranks,
     two cosets each), config 5's "on 8 x MI355X" half (163 columns over 8 ranks), and the headline
-    config over the 4 ranks its log_blowup allows."""
+    config over the 4 ranks its log_blowup allows -- with the chunk broadcast and with every rank
+    computing the quotient on its own cosets (local_quotient; config 3 then over 2 ranks: the
+    quotient degree 2 needs two cosets per rank)."""
     import threading
 
     from tapstark_amd.comm import LocalCommGroup
@@ -96,7 +99,7 @@ def test_full_size_sharded_proof_equals_oracle_digests(ctx, orc, name, G):
             conf = ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(*cfg), c))
             p = ts.prove_sharded(conf, ts.CompiledAir(c, tape), ts.BfChallenger(), device_trace(c, name, n),
                                  [], group.comm(r), trace_replicated=True,
-                                 column_sharded_inverse=(name == "config5"))
+                                 column_sharded_inverse=(name == "config5" and not localq), local_quotient=localq)
             proofs[r] = p.words
         except BaseException as e:  # noqa: BLE001
             errors[r] = e
@@ -109,6 +112,6 @@ def test_full_size_sharded_proof_equals_oracle_digests(ctx, orc, name, G):
     assert not any(t.is_alive() for t in threads), "a rank is stuck in a collective"
     for r in range(G):
         assert errors[r] is None, f"rank {r}: {errors[r]!r}"
-    assert_matches_fixture(proofs[0], want, f"{name} sharded over {G}, rank 0")
+    assert_matches_fixture(proofs[0], want, f"{name} sharded over {G}{' (local quotient)' if localq else ''}, rank 0")
     for r in range(1, G):
         assert (proofs[r] == proofs[0]).all(), f"rank {r} holds another proof"

@@ -516,3 +516,140 @@ def test_config5_air_sharded_over_eight_ranks(ctx, orc, log_n, mode):
     for r, (words, b) in enumerate(res):
         assert len(words) == len(oracle) and (words == oracle).all(), f"rank {r}: proof differs from the oracle's"
         assert b == bits, f"rank {r}: transcript state differs"
+
+
+# ------------------------------------------------------------------ local quotient
+class PowAir(ts.BaseAir):
+    """Test AIR: columns (a, c) with c = a^k (one constraint of degree k, a quotient that really has
+    degree ~ (k - 1) n: every block Q_k of its coefficients is non-zero) and a' = a + 1."""
+
+    def __init__(self, k):
+        self.k = k
+
+    def width(self):
+        return 2
+
+    def eval(self, builder):
+        main = builder.main()
+        local, nxt = main.row_slice(0), main.row_slice(1)
+        acc = local[0]
+        for _ in range(self.k - 1):
+            acc = acc * local[0]
+        builder.assert_zero(acc - local[1])
+        builder.when_transition().assert_eq(local[0] + 1, nxt[0])
+
+
+def pow_trace(n, k):
+    a = [(7 + i) % 0x78000001 for i in range(n)]
+    return np.array([[x, pow(x, k, 0x78000001)] for x in a], dtype=np.uint32)
+
+
+LOCALQ_CASES = [
+    # name, air/trace factory, log_n, (log_blowup, queries, pow), G, expect the local path (cosets/rank >= qd)
+    ("mul64-qd2-b4-G8", lambda n: (SynthMulAir64(), None), 10, (4, 16, 8), 8, True),
+    ("mul64-qd2-b2-G2", lambda n: (SynthMulAir64(), None), 13, (2, 28, 8), 2, True),
+    ("mul64-qd2-b2-G4-fallback", lambda n: (SynthMulAir64(), None), 10, (2, 28, 8), 4, False),
+    ("ext163-qd1-b4-G8", lambda n: ("ext163", None), 10, (4, 16, 8), 8, True),
+    ("pow5-qd4-b3-G2", lambda n: (PowAir(5), pow_trace(n, 5)), 9, (3, 12, 8), 2, True),
+    ("pow5-qd4-b3-G4-fallback", lambda n: (PowAir(5), pow_trace(n, 5)), 9, (3, 12, 8), 4, False),
+    ("pow9-qd8-b4-G2", lambda n: (PowAir(9), pow_trace(n, 9)), 8, (4, 10, 8), 2, True),
+    ("fib-qd1-b2-G4", lambda n: ("fib", None), 11, (2, 9, 8), 4, True),
+    ("mul64-qd2-b3-G1", lambda n: (SynthMulAir64(), None), 9, (3, 9, 8), 1, True),
+]
+
+
+def SynthMulAir64():
+    from tapstark_amd.airs import SynthMulAir
+    return SynthMulAir(64)
+
+
+@pytest.mark.parametrize("name,make,log_n,cfg,G,local", LOCALQ_CASES, ids=[c[0] for c in LOCALQ_CASES])
+def test_local_quotient_same_proof_no_broadcast(ctx, orc, name, make, log_n, cfg, G, local):
+    """ts_shard_options.local_quotient: every rank evaluates the quotient on its own cosets, extends
+    the per-coset interpolants to its slab and mixes them with the Vandermonde change-of-basis matrix
+    (csrc/sharded.cpp).  The proof must be the single-GPU proof (= the oracle's) word for word, and no
+    broadcast may happen -- except where a rank holds fewer cosets than the quotient degree, where the
+    option falls back to the broadcast path."""
+    from tapstark_amd import _lib
+    from tapstark_amd.airs import (FibonacciAir, SynthExtAir, fibonacci_public_values,
+                                   generate_fibonacci_trace, generate_synth_ext_trace, generate_synth_mul_trace)
+    from tapstark_amd.comm import LocalCommGroup
+
+    n = 1 << log_n
+    air, trace = make(n)
+    pis = np.zeros(0, dtype=np.uint32)
+    if air == "ext163":
+        air, trace = SynthExtAir(163), generate_synth_ext_trace(n, 163)
+    elif air == "fib":
+        air, trace = FibonacciAir(), generate_fibonacci_trace(0, 1, n)
+        pis = fibonacci_public_values(trace)
+    elif trace is None:
+        trace = generate_synth_mul_trace(n)
+    tape = ts.air_tape(air, len(pis))
+    config = ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(*cfg), ctx))
+    want = ts.prove(config, ts.CompiledAir(ctx, tape), ts.BfChallenger(), trace.copy(), pis).words
+    oracle = orc.prove(orc.FriConfig(*cfg), tape, trace, pis)
+    assert len(oracle) == len(want) and (oracle == want).all()
+    group = LocalCommGroup(G)
+    n_bcast = [0] * G
+
+    def rank(r):
+        c = ts.Context(0)
+        conf = ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(*cfg), c))
+        inner = group.comm(r)
+        ic = inner.c
+
+        def bc(_u, buf, nbytes, root, stream):  # count the broadcasts, then do them
+            n_bcast[r] += 1
+            return ic.broadcast(ic.user, buf, nbytes, root, stream)
+
+        class Counting:
+            pass
+        cc = Counting()
+        cc._bc = _lib.BROADCAST_FN(bc)
+        cc.c = _lib.CommC(ic.rank, ic.world, ic.user, ic.all_gather, cc._bc, ic.abort)
+        cc.rank, cc.world, cc.error, cc._keep = r, G, None, inner
+        rows = trace[r * n // G:(r + 1) * n // G]
+        p = ts.prove_sharded(conf, ts.CompiledAir(c, tape), ts.BfChallenger(), np.ascontiguousarray(rows), pis, cc,
+                             min_local_log=3, local_quotient=True)
+        return p.words
+
+    res = _thread_ranks(G, rank)
+    for r, words in enumerate(res):
+        assert len(words) == len(want) and (words == want).all(), \
+            f"rank {r}: {int((words != want).sum())} words differ from ts_prove"
+    qd = 1 << ts.CompiledAir(ctx, tape).log_quotient_degree
+    assert n_bcast == [0 if local else qd] * G, n_bcast
+
+
+def test_local_quotient_on_an_invalid_trace_is_still_rejected(ctx, orc):
+    """For a trace that violates its constraints, constraints / Z_H is not a polynomial of degree
+    < n qd: the reference (release build, prover.rs:40-41) and ts_prove commit to the interpolants of its
+    values on the quotient domain, the local-quotient ranks to those on their own cosets.  The default
+    sharded path stays word-identical to ts_prove; the local one differs -- and every one of the proofs
+    is rejected by the verifier, which is all that can be asked of an invalid statement."""
+    from tapstark_amd.airs import SynthMulAir, generate_synth_mul_trace
+    from tapstark_amd.comm import LocalCommGroup
+
+    G, cfg, n = 2, (2, 9, 8), 1 << 9
+    air = SynthMulAir(64)
+    tape = ts.air_tape(air, 0)
+    bad = generate_synth_mul_trace(n)
+    bad[9, 2] = (int(bad[9, 2]) + 1) % 0x78000001
+    config = ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(*cfg), ctx))
+    single = ts.prove(config, ts.CompiledAir(ctx, tape), ts.BfChallenger(), bad.copy(), []).words
+    assert orc.verify(orc.FriConfig(*cfg), tape, single, []) == 7  # OodEvaluationMismatch
+    for localq in (False, True):
+        group = LocalCommGroup(G)
+
+        def rank(r):
+            c = ts.Context(0)
+            conf = ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(*cfg), c))
+            return ts.prove_sharded(conf, ts.CompiledAir(c, tape), ts.BfChallenger(), bad.copy(), [], group.comm(r),
+                                    min_local_log=3, trace_replicated=True, local_quotient=localq).words
+
+        res = _thread_ranks(G, rank)
+        assert (res[0] == res[1]).all()
+        same = len(res[0]) == len(single) and bool((res[0] == single).all())
+        assert same == (not localq)
+        assert orc.verify(orc.FriConfig(*cfg), tape, res[0], []) != 0

@@ -15,7 +15,7 @@ What a one-GPU box cannot give is the cost of the collectives themselves over xG
 them with stated assumptions (latency per small collective, link bandwidth for the bulk ones).
 
     python tools/shard_stages.py config4 [G] [variant ...] > profiles/r04_config4_shard_stages.json
-    variants: replicated (min_local_log 12), mll16, mll20, colshard
+    variants: replicated (min_local_log 12), localq, mll16, mll20, colshard, localq16 (localq + mll16)
 """
 import ctypes as C
 import json
@@ -82,7 +82,8 @@ def run(name, G, variant):
     group = LocalCommGroup(G)
     token = threading.Lock()
     kw = dict(trace_replicated=True, column_sharded_inverse=(variant == "colshard"),
-              min_local_log={"mll16": 16, "mll20": 20}.get(variant, 12))
+              local_quotient=variant.startswith("localq"),
+              min_local_log={"mll16": 16, "mll20": 20, "localq16": 16}.get(variant, 12))
     out, errs = [None] * G, [None] * G
 
     def gen(ctx):
@@ -95,9 +96,9 @@ def run(name, G, variant):
             cair = ts.CompiledAir(ctx, tape)
             comm = TurnComm(group.comm(r), ctx, token)
             res = {}
-            # proof 0 builds tables and grows the pool; 1: segments (no timers); 2: stage timers
-            # (collectives table); 3: kernel timers
-            for mode in ("warm", "segments", "stages", "kernels"):
+            # proof 0 builds tables and grows the pool; 1-3: segments (no timers); then stage timers
+            # (collectives table); then kernel timers
+            for mode in ("warm", "segments", "segments", "segments", "stages", "kernels"):
                 m = gen(ctx)
                 ctx.synchronize()
                 ctx.set_timing(mode == "stages")
@@ -106,8 +107,10 @@ def run(name, G, variant):
                 comm.enter()
                 p = ts.prove_sharded(config, cair, ts.BfChallenger(), m, [], comm, **kw)
                 comm.leave()
-                if mode == "segments":
-                    res["segments_ms"] = [round(1e3 * s, 4) for s in comm.segments]
+                if mode == "segments":  # three passes, element-wise minimum: host hiccups drop out
+                    cur = [round(1e3 * s, 4) for s in comm.segments]
+                    prev = res.get("segments_ms")
+                    res["segments_ms"] = cur if prev is None or len(prev) != len(cur) else [min(a, b) for a, b in zip(prev, cur)]
                 if mode == "stages":
                     res["stages_ms"], res["collectives"] = split_stage_timings(ctx.take_timings())
                     ctx.set_timing(False)
@@ -153,7 +156,7 @@ def model(colls, G):
 def main():
     name = sys.argv[1] if len(sys.argv) > 1 else "config4"
     G = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-    variants = sys.argv[3:] or ["replicated", "mll16", "mll20", "colshard"]
+    variants = sys.argv[3:] or ["replicated", "localq", "mll16", "localq16", "mll20", "colshard"]
     res = {"_comment": __doc__.split("\n\n")[0] + " " + " ".join(__doc__.split("\n\n")[1].split()),
            "config": name, "ranks": G}
     shas = set()

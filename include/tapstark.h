@@ -302,9 +302,11 @@ typedef struct {
                                   its OWN cosets and derives its slab of the chunk LDEs from that: no rank
                                   waits for the owner of the quotient domain, no chunk broadcast.  Needs
                                   2^log_blowup / world >= quotient degree (else ignored).  Same proof for
-                                  every trace that satisfies its constraints; for one that does not,
-                                  constraints / Z_H is no polynomial and the committed chunks differ from
-                                  ts_prove's (both proofs are rejected by the verifier) */
+                                  every trace that satisfies its constraints; for one that does not
+                                  (ts_prove, like a release build of the reference, still hands out a proof,
+                                  which the verifier rejects) constraints / Z_H is no polynomial, the mixed
+                                  chunks are not low-degree and the call ends with TS_ERR_INVARIANT where the
+                                  reference asserts (fri/src/prover.rs:129-134) */
 } ts_shard_options;
 ts_status ts_prove_sharded(ts_ctx* ctx, const ts_fri_config* cfg, const ts_comm* comm,
                            const ts_air* air, ts_challenger* chal, ts_matrix* trace_rows,

@@ -182,7 +182,8 @@ struct ShardOptions {
     // domain, no chunk broadcast.  Needs 2^log_blowup / G >= quotient degree (else the broadcast
     // path runs).  Identical proofs for every trace that satisfies its constraints; for a trace that
     // does not (which a release build of the reference proves without complaint, prover.rs:40-41)
-    // constraints / Z_H is not a polynomial and the two paths commit to different chunks.
+    // constraints / Z_H is not a polynomial, the mixed chunks are not low-degree and FRI's
+    // final-polynomial assertion (fri/src/prover.rs:129-134) ends the proof with TS_ERR_INVARIANT.
     bool local_quotient = false;
 };
 // rank g owns the bit-reversed LDE rows [g N/G, (g+1) N/G) (whole cosets,

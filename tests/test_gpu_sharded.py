@@ -622,12 +622,15 @@ def test_local_quotient_same_proof_no_broadcast(ctx, orc, name, make, log_n, cfg
     assert n_bcast == [0 if local else qd] * G, n_bcast
 
 
-def test_local_quotient_on_an_invalid_trace_is_still_rejected(ctx, orc):
+def test_local_quotient_on_an_invalid_trace_refuses(ctx, orc):
     """For a trace that violates its constraints, constraints / Z_H is not a polynomial of degree
-    < n qd: the reference (release build, prover.rs:40-41) and ts_prove commit to the interpolants of its
-    values on the quotient domain, the local-quotient ranks to those on their own cosets.  The default
-    sharded path stays word-identical to ts_prove; the local one differs -- and every one of the proofs
-    is rejected by the verifier, which is all that can be asked of an invalid statement."""
+    < n qd.  The reference (release build, prover.rs:40-41) and ts_prove commit to the interpolants of
+    its values on the quotient domain and hand out a proof the verifier rejects (OodEvaluationMismatch);
+    the default sharded path does exactly the same, word for word.  The local-quotient ranks interpolate
+    the values on their OWN cosets: the mixed chunk LDEs are then not low-degree, FRI's final polynomial
+    is not constant, and the prover stops where the reference asserts (fri/src/prover.rs:129-134):
+    TS_ERR_INVARIANT on every rank, no proof."""
+    from tapstark_amd._lib import TsError
     from tapstark_amd.airs import SynthMulAir, generate_synth_mul_trace
     from tapstark_amd.comm import LocalCommGroup
 
@@ -645,11 +648,16 @@ def test_local_quotient_on_an_invalid_trace_is_still_rejected(ctx, orc):
         def rank(r):
             c = ts.Context(0)
             conf = ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(*cfg), c))
-            return ts.prove_sharded(conf, ts.CompiledAir(c, tape), ts.BfChallenger(), bad.copy(), [], group.comm(r),
-                                    min_local_log=3, trace_replicated=True, local_quotient=localq).words
+            try:
+                return ts.prove_sharded(conf, ts.CompiledAir(c, tape), ts.BfChallenger(), bad.copy(), [],
+                                        group.comm(r), min_local_log=3, trace_replicated=True,
+                                        local_quotient=localq).words
+            except TsError as e:
+                return e
 
         res = _thread_ranks(G, rank)
-        assert (res[0] == res[1]).all()
-        same = len(res[0]) == len(single) and bool((res[0] == single).all())
-        assert same == (not localq)
-        assert orc.verify(orc.FriConfig(*cfg), tape, res[0], []) != 0
+        if localq:
+            for r in res:
+                assert isinstance(r, TsError) and r.code == 5 and "final polynomial" in str(r), r
+        else:
+            assert len(res[0]) == len(single) and (res[0] == single).all() and (res[1] == single).all()

@@ -355,6 +355,17 @@ def test_cpp_stream_example_builds_with_plain_gxx(lib, tmp_path):
         assert r.returncode == 2 and "no MI355X context" in r.stderr
 
 
+def test_cpp_sharded_example_builds_with_plain_gxx(lib, tmp_path):
+    # examples/prove_sharded.cpp (G thread-ranks, in-process or native RCCL communicator, ts_prove_sharded)
+    # links against the C ABI with plain g++; without a GPU it fails loudly at ts_ctx_create
+    import subprocess
+    exe = _build_example(tmp_path, "prove_sharded")
+    import torch
+    if not torch.cuda.is_available():
+        r = subprocess.run([exe, "10", "2"], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 2 and "no MI355X context" in r.stderr
+
+
 def test_cpp_air_capture_matches_python(lib, tmp_path):
     """include/tapstark_air.hpp (the C++ SymbolicAirBuilder) captures FibonacciAir::eval into the
     very tape the Python front-end produces; the example links against the C ABI with plain g++."""

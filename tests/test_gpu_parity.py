@@ -551,6 +551,28 @@ def test_cpp_stream_example_lanes_gate_and_pinned_uploads(ctx, orc, tmp_path):
         assert len(words) == len(want) and (words == want).all(), mode
 
 
+def test_cpp_sharded_example_eight_ranks_through_the_c_abi(ctx, orc, tmp_path):
+    """examples/prove_sharded.cpp: ONE proof over G thread-ranks from a compiled language over
+    include/tapstark.h only (what the unbuilt Rust prove_gpu_sharded does): config 4's split (log_blowup
+    4, two cosets per rank at G = 8), the in-process communicator, quotient chunks broadcast or computed
+    locally.  The program itself checks every rank against ts_prove; here its proof is also the oracle's."""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_abi_cpu import _build_example
+    exe = _build_example(tmp_path, "prove_sharded")
+    log_n = 11
+    trace = generate_synth_mul_trace(1 << log_n)
+    want = orc.prove(orc.FriConfig(4, 16, 8), ts.air_tape(SynthMulAir(64), 0), trace, [])
+    for G, mode in ((8, "bcast"), (8, "localq"), (2, "localq")):
+        out_bin = str(tmp_path / f"sharded_{G}_{mode}.bin")
+        r = subprocess.run([exe, str(log_n), str(G), "local", mode, out_bin], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "every rank's proof equals ts_prove's" in r.stdout and "verify -> 0" in r.stdout
+        words = np.fromfile(out_bin, dtype=np.uint32)
+        assert len(words) == len(want) and (words == want).all(), (G, mode)
+
+
 def test_fri_fold_device_vectors_match_oracle(ctx, orc):
     # ts_fri_fold_device: fold_matrix (two_adic_pcs.rs:116-147) on vectors that already live in HBM,
     # the entry point `bench.py --workload fold` times (fri/benches/fold_even_odd.rs sizes)

@@ -71,10 +71,11 @@ void gather_top(Shard& sh, const char* site, const uint32_t* d_subroot, uint32_t
 
 // two_adic_pcs.rs:227-245 for the owned cosets + the slab's sub-tree; `evals` are whole matrices
 // mix (local quotient, below): a qd x qd canonical matrix applied across the batch's matrices (the
-// chunk LDEs, 4 columns each) between the LDE and the leaf hashes
+// chunk LDEs, 4 columns each) between the LDE and the leaf hashes; mix_local: `evals` are this rank's
+// own matrices (they differ from rank to rank), so the column-sharded inverse does not apply
 std::unique_ptr<ShardedData> commit_sharded(Shard& sh, std::vector<DeviceMatrix>& evals,
                                             const std::vector<uint32_t>& domain_shifts,
-                                            const std::vector<uint32_t>* mix = nullptr) {
+                                            const std::vector<uint32_t>* mix = nullptr, bool mix_local = false) {
     Context& ctx = sh.ctx;
     TS_REQUIRE(!evals.empty() && evals.size() <= (size_t)MAX_BATCH_MATS, TS_ERR_INVALID,
                "commit: between 1 and 16 matrices per batch");
@@ -100,7 +101,9 @@ std::unique_ptr<ShardedData> commit_sharded(Shard& sh, std::vector<DeviceMatrix>
             uint32_t* ev = m.buf.p;
             DevBuf<uint32_t> lde(&ctx, (size_t)m.width * rows);
             const uint32_t shift = mul(GENERATOR, inv_canon(domain_shifts[i]));  // two_adic_pcs.rs:235
-            if (sh.column_sharded_inverse && sh.G > 1 && log_n > 12) {
+            // (not for the per-rank matrices of the local quotient: there every rank transforms its OWN
+            // evaluations, there is nothing to share)
+            if (sh.column_sharded_inverse && !mix_local && sh.G > 1 && log_n > 12) {
                 // the per-column part of the inverse transform (the
                 // transpose and the contiguous stages) is done for w/G columns per rank, then the
                 // half-transformed columns are all-gathered; the strided pass and the forward
@@ -340,7 +343,7 @@ std::vector<uint32_t> prove_sharded(TwoAdicFriPcs& pcs, const Comm& comm, const 
         for (uint32_t c = 0; c < qd; c++) qshifts[c] = mul(s_g, pow_canon(gq, c));
         std::vector<uint32_t> mix;
         if (qd > 1) mix = chunk_mix_matrix(qd, log_degree, s_g);
-        quotient_data = commit_sharded(sh, chunks, qshifts, qd > 1 ? &mix : nullptr);  // :82-83
+        quotient_data = commit_sharded(sh, chunks, qshifts, qd > 1 ? &mix : nullptr, true);  // :82-83
     } else {
         std::vector<DeviceMatrix> chunks =
             pcs.quotient_chunks_slab(trace_data->local.ldes[0], log_degree, slab, air, public_values, alpha);

@@ -555,6 +555,9 @@ LOCALQ_CASES = [
     ("pow9-qd8-b4-G2", lambda n: (PowAir(9), pow_trace(n, 9)), 8, (4, 10, 8), 2, True),
     ("fib-qd1-b2-G4", lambda n: ("fib", None), 11, (2, 9, 8), 4, True),
     ("mul64-qd2-b3-G1", lambda n: (SynthMulAir64(), None), 9, (3, 9, 8), 1, True),
+    # two-pass LDE (n > 4096) together with the column-sharded inverse: the per-rank chunk matrices of
+    # the local quotient must NOT go through the column-sharded path (tools/soak_sharded.py found it)
+    ("mul64-qd2-b3-G4-colshard", lambda n: (SynthMulAir64(), None), 14, (3, 9, 8), 4, True),
 ]
 
 
@@ -611,7 +614,7 @@ def test_local_quotient_same_proof_no_broadcast(ctx, orc, name, make, log_n, cfg
         cc.rank, cc.world, cc.error, cc._keep = r, G, None, inner
         rows = trace[r * n // G:(r + 1) * n // G]
         p = ts.prove_sharded(conf, ts.CompiledAir(c, tape), ts.BfChallenger(), np.ascontiguousarray(rows), pis, cc,
-                             min_local_log=3, local_quotient=True)
+                             min_local_log=3, local_quotient=True, column_sharded_inverse=name.endswith("colshard"))
         return p.words
 
     res = _thread_ranks(G, rank)

@@ -1,5 +1,5 @@
 """Soak of the sharded prover on the in-process communicator: G rank threads prove the same trace
-K times (row-sliced and replicated inputs, both inverse-NTT options in turn); every proof of every
+K times (row-sliced and replicated inputs, both inverse-NTT options and both quotient paths in turn); every proof of every
 rank must equal ts_prove's.  Exercises the rendezvous of csrc/comm.cpp (generation counting, buffer
 reuse across collectives) far beyond what the test suite does.
 
@@ -40,7 +40,8 @@ def main():
                 repl = bool(k & 1)
                 m = ts.DeviceMatrix.upload(ctx, trace if repl else rows)
                 p = ts.prove_sharded(config, cair, ts.BfChallenger(), m, [], group.comm(r),
-                                     trace_replicated=repl, column_sharded_inverse=bool(k & 2))
+                                     trace_replicated=repl, column_sharded_inverse=bool(k & 2),
+                                     local_quotient=bool(k & 4))
                 if p.words.tobytes() != ref:
                     bad.append((r, k))
         except BaseException as e:  # noqa: BLE001

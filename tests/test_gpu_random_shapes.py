@@ -70,3 +70,76 @@ def test_random_shape_bit_identical(ctx, orc, name, kind, w, log_n, cfg, seed):
     ts.verify(config, air, ts.BfChallenger(), proof, pis)
     # and the wire format survives the trip
     assert (ts.Proof.from_postcard(proof.to_postcard()).words == proof.words).all()
+
+
+# ------------------------------------------------------------------ the sharded prover, option sweep
+def _sharded_cases():
+    """Seeded sweep of ts_prove_sharded: world size, slab shape and EVERY combination of its options
+    (row-sliced / replicated input, column-sharded inverse, local quotient, min_local_log) -- the
+    combination local_quotient + column_sharded_inverse at n > 4096 was wrong until a soak run met it
+    (profiles/r04_soak.txt).  TS_RANDOM_SHARDED / TS_RANDOM_SEED widen it."""
+    import os
+
+    rng = np.random.default_rng(int(os.environ.get("TS_RANDOM_SEED", "20240607")) + 1)
+    out = []
+    for i in range(int(os.environ.get("TS_RANDOM_SHARDED", "24"))):
+        kind = ["mul", "fib", "ext", "mul"][int(rng.integers(0, 4))]
+        b = int(rng.integers(1, 5))
+        G = 1 << int(rng.integers(0, min(b, 3) + 1))
+        log_n = int(rng.integers(max(3, G.bit_length() - 1), 15))
+        w = int(rng.integers(3, 70)) if kind == "mul" else (int(rng.choice([13, 25, 37])) if kind == "ext" else 2)
+        opts = dict(trace_replicated=bool(rng.integers(0, 2)), column_sharded_inverse=bool(rng.integers(0, 2)),
+                    local_quotient=bool(rng.integers(0, 2)), min_local_log=int(rng.choice([1, 3, 6, 12])))
+        tag = "".join(k[0] for k, v in opts.items() if v is True) or "-"
+        out.append((f"{i}-{kind}{w}-2p{log_n}-b{b}-G{G}-{tag}-m{opts['min_local_log']}", kind, w, log_n,
+                    (b, int(rng.integers(1, 10)), int(rng.choice([0, 4, 8]))), G, opts, int(rng.integers(1, 1 << 30))))
+    return out
+
+
+SHARDED_CASES = _sharded_cases()
+
+
+@pytest.mark.parametrize("name,kind,w,log_n,cfg,G,opts,seed", SHARDED_CASES, ids=[c[0] for c in SHARDED_CASES])
+def test_random_sharded_options_bit_identical(ctx, name, kind, w, log_n, cfg, G, opts, seed):
+    import threading
+
+    from tapstark_amd.comm import LocalCommGroup
+
+    n = 1 << log_n
+    if kind == "mul":
+        air, trace, pis = SynthMulAir(w), generate_synth_mul_trace(n, w, seed), np.zeros(0, dtype=np.uint32)
+    elif kind == "ext":
+        air, trace, pis = SynthExtAir(w), generate_synth_ext_trace(n, w, seed), np.zeros(0, dtype=np.uint32)
+    else:
+        trace = generate_fibonacci_trace(seed % 1000, (seed >> 10) % 1000, n)
+        air, pis = FibonacciAir(), fibonacci_public_values(trace)
+    tape = ts.air_tape(air, len(pis))
+    config = ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(*cfg), ctx))
+    ch = ts.BfChallenger()
+    want = ts.prove(config, ts.CompiledAir(ctx, tape), ch, trace.copy(), pis).words
+    bits = ch.sample_bits(24)
+    group = LocalCommGroup(G)
+    res, errs = [None] * G, [None] * G
+
+    def rank(r):
+        try:
+            c = ts.Context(0)
+            conf = ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(*cfg), c))
+            rows = trace if opts["trace_replicated"] else trace[r * n // G:(r + 1) * n // G]
+            chal = ts.BfChallenger()
+            p = ts.prove_sharded(conf, ts.CompiledAir(c, tape), chal, np.ascontiguousarray(rows), pis, group.comm(r), **opts)
+            res[r] = (p.words, chal.sample_bits(24))
+        except BaseException as e:  # noqa: BLE001
+            errs[r] = e
+
+    th = [threading.Thread(target=rank, args=(r,)) for r in range(G)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in th), "a rank is stuck in a collective"
+    for r in range(G):
+        assert errs[r] is None, f"rank {r}: {errs[r]!r}"
+        words, b2 = res[r]
+        assert len(words) == len(want) and (words == want).all(), f"rank {r}: {int((words != want).sum())} words differ"
+        assert b2 == bits

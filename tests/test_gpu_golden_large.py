@@ -34,18 +34,22 @@ def ctx():
 
 
 def device_trace(ctx, name, n):
-    if name == "config2":
+    if name == "config2" or name.startswith("fib"):
         return ts.DeviceMatrix.fibonacci(ctx, 0, 1, n)
-    if name in ("config3", "config4"):
+    if name in ("config3", "config4") or name.startswith("mul64"):
         return ts.DeviceMatrix.synth_mul(ctx, n, 64)
     return ts.DeviceMatrix.synth_ext(ctx, n, 163)
 
 
 AIRS = {"config2": FibonacciAir, "config3": lambda: SynthMulAir(64), "config4": lambda: SynthMulAir(64),
-        "config5": lambda: SynthExtAir(163)}
+        "config5": lambda: SynthExtAir(163), "fib_2p24_b2": FibonacciAir, "fib_2p26_b1": FibonacciAir,
+        "mul64_2p23_b1": lambda: SynthMulAir(64)}
 
 
-@pytest.mark.parametrize("name", ["config2", "config3", "config5", "config4"])
+# beyond BASELINE: n = 2^23 .. 2^26 (strided NTT passes of 11, 12 and 14 stages: the generic plan), up to the
+# 2^27-row LDE that is the field's limit
+@pytest.mark.parametrize("name", ["config2", "config3", "config5", "config4", "fib_2p24_b2", "mul64_2p23_b1",
+                                  "fib_2p26_b1"])
 def test_full_size_proof_equals_oracle_digests(ctx, orc, name):
     want = load_large(name)
     n = 1 << want["log_n"]

@@ -42,11 +42,16 @@ def bitrev_perm(bits):
                                                 (10, 64, 2), (12, 5, 2), (13, 3, 2), (14, 64, 2),
                                                 (16, 2, 3), (11, 163, 2), (22, 1, 1),
                                                 # 2^21 / 2^22: 8192- / 16384-element chunks (radix-32 rounds)
-                                                (21, 2, 2), (22, 2, 2), (21, 1, 4)])
+                                                (21, 2, 2), (22, 2, 2), (21, 1, 4),
+                                                # 2^23 .. 2^26 rows: strided passes of 11 .. 14 stages (generic plan);
+                                                # (26, 1, 1) is the largest LDE the field allows (2^27 rows)
+                                                (23, 3, 1), (24, 1, 2), (25, 2, 1), (26, 1, 1)])
 def test_commit_lde_and_merkle(ctx, orc, log_n, w, log_blowup):
     pcs = ts.TwoAdicFriPcs(ts.FriConfig(log_blowup, 4, 8), ctx)
     m = rand_mat(17 + log_n, 1 << log_n, w)
-    for shift in (1, 31 * pow(0x1A427A41, 1 << (27 - (log_n + 1)), P) % P if log_n < 26 else 1):
+    # a second, non-trivial domain shift where the field has one and the case is not a big one (the
+    # 2^24+ cases take tens of seconds of oracle hashing each)
+    for shift in ((1, 31 * pow(0x1A427A41, 1 << (27 - (log_n + 1)), P) % P) if log_n < 24 else (1,)):
         root, data = pcs.commit([((log_n, shift), m.copy())])
         want = orc.commit_lde(m, shift, log_blowup)
         got = data.lde(0, w)

@@ -693,6 +693,7 @@ def main():
         # for the input; TS_BENCH_SLICED=1 hands out row slices instead (adds the trace all-gather)
         sliced = bool(os.environ.get("TS_BENCH_SLICED"))
         colshard = bool(os.environ.get("TS_BENCH_COLSHARD"))
+        localq = os.environ.get("TS_BENCH_LOCALQ", "1") != "0"  # every rank on its own cosets: no chunk broadcast
         if sliced:
             full = make_trace(ctx).download()
             rows = np.ascontiguousarray(full[grank * n // gsize:(grank + 1) * n // gsize])
@@ -702,7 +703,8 @@ def main():
 
         def prove_one(i):
             last["proof"] = ts.prove_sharded(config, cair, ts.BfChallenger(), mats[i], pis, comm,
-                                             trace_replicated=not sliced, column_sharded_inverse=colshard)
+                                             trace_replicated=not sliced, column_sharded_inverse=colshard,
+                                             local_quotient=localq)
     else:
         # one resident trace per step (prove() consumes it); beyond 100 GB of them (288 GB of HBM) the
         # trace of a step is generated on the device at the start of the step instead, inside the
@@ -836,7 +838,7 @@ def main():
             "config": {"workload": desc, "rows": n, "width": w, "log_blowup": cfg[0],
                        "num_queries": cfg[1], "proof_of_work_bits": cfg[2], "quotient_degree": qd,
                        "parallelism": (f"{n_groups} group(s) of {gsize} GPU(s), one proof sharded over each group, "
-                                        f"collectives over {comm.backend}" if sharded else
+                                        f"collectives over {comm.backend}, quotient {'local' if localq else 'broadcast'}" if sharded else
                                        ("1 rank per GPU (replicas)" if env.world > 1 else "1 GPU")
                                        + f", {S} proofs in flight per GPU, starts spaced >= {stagger['ms']:.2f} ms"),
                        "quotient_kernel": "hiprtc-specialised" if cair.is_jit else "interpreter",

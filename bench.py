@@ -866,7 +866,17 @@ def main():
 
     # ---- N > 1: BASELINE configs 4 and 5 as one sharded proof each, in the same lease
     wd = None
-    if env.world > 1 and not sharded and not args.no_sharded_block:
+    force_block = bool(os.environ.get("TS_BENCH_FORCE_SHARD_BLOCK")) and env.world == 1 and not sharded
+    if force_block:
+        # Rehearsal of the N > 1 blocks' NATIVE-RCCL branch on a one-GPU box: a process group of one
+        # nccl rank, so that the unique-id exchange, ts_comm_rccl_create, every variant and the gathers of
+        # stage / collective tables run exactly as they will on a node -- everything but a second rank.
+        import torch.distributed as dist
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29513", rank=0, world_size=1,
+                                device_id=torch.device("cuda", dev))
+        env.dist, env.device = dist, f"cuda:{dev}"
+    if (env.world > 1 or force_block) and not sharded and not args.no_sharded_block:
         for c, _, _ in lanes[1:]:
             c.synchronize()
         mats = None

@@ -14,6 +14,7 @@ plan = {
     "bench_config3_k20.json": "bench_config3_k20.json", "bench_config2.json": "bench_config2.json",
     "bench_config4.json": "bench_config4.json", "bench_config5.json": "bench_config5.json",
     "bench_gpus2_shared_gpu_rehearsal.json": "bench_gpus2_shared_gpu_rehearsal.json",
+    "bench_rccl_world1_blocks.json": "bench_rccl_world1_blocks.json",
     "fold_even_odd.json": "fold_even_odd.json", "config4_shard_stages.json": "config4_shard_stages.json",
     "config5_shard_stages.json": "config5_shard_stages.json", "fri_hipgraph_latency.txt": "fri_hipgraph_latency.txt",
     "config3_sq_counters.txt": "config3_sq_counters.txt", "config4_sq_counters.txt": "config4_sq_counters.txt",

@@ -83,17 +83,46 @@ def _sharded_cases():
     rng = np.random.default_rng(int(os.environ.get("TS_RANDOM_SEED", "20240607")) + 1)
     out = []
     for i in range(int(os.environ.get("TS_RANDOM_SHARDED", "24"))):
-        kind = ["mul", "fib", "ext", "mul"][int(rng.integers(0, 4))]
+        kind = ["mul", "fib", "ext", "mul", "pow"][int(rng.integers(0, 5))]
         b = int(rng.integers(1, 5))
+        pow_k = int(rng.choice([3, 5, 9]))  # constraint degree -> quotient degree 2, 4, 8
+        if kind == "pow":
+            b = max(b, (pow_k - 2).bit_length())  # log_quotient_degree <= log_blowup
         G = 1 << int(rng.integers(0, min(b, 3) + 1))
         log_n = int(rng.integers(max(3, G.bit_length() - 1), 15))
         w = int(rng.integers(3, 70)) if kind == "mul" else (int(rng.choice([13, 25, 37])) if kind == "ext" else 2)
+        if kind == "pow":
+            w, log_n = pow_k, min(log_n, 12)  # (the width field carries the degree; the trace is built with Python integers)
         opts = dict(trace_replicated=bool(rng.integers(0, 2)), column_sharded_inverse=bool(rng.integers(0, 2)),
                     local_quotient=bool(rng.integers(0, 2)), min_local_log=int(rng.choice([1, 3, 6, 12])))
         tag = "".join(k[0] for k, v in opts.items() if v is True) or "-"
         out.append((f"{i}-{kind}{w}-2p{log_n}-b{b}-G{G}-{tag}-m{opts['min_local_log']}", kind, w, log_n,
                     (b, int(rng.integers(1, 10)), int(rng.choice([0, 4, 8]))), G, opts, int(rng.integers(1, 1 << 30))))
     return out
+
+
+class PowAir(ts.BaseAir):
+    """columns (a, c): c = a^k (one constraint of degree k: quotient degree 2^ceil(log2(k - 1))), a' = a + 1"""
+
+    def __init__(self, k):
+        self.k = k
+
+    def width(self):
+        return 2
+
+    def eval(self, builder):
+        main = builder.main()
+        local, nxt = main.row_slice(0), main.row_slice(1)
+        acc = local[0]
+        for _ in range(self.k - 1):
+            acc = acc * local[0]
+        builder.assert_zero(acc - local[1])
+        builder.when_transition().assert_eq(local[0] + 1, nxt[0])
+
+
+def pow_trace(n, k, seed):
+    P = 0x78000001
+    return np.array([[(seed + i) % P, pow((seed + i) % P, k, P)] for i in range(n)], dtype=np.uint32)
 
 
 SHARDED_CASES = _sharded_cases()
@@ -110,6 +139,8 @@ def test_random_sharded_options_bit_identical(ctx, name, kind, w, log_n, cfg, G,
         air, trace, pis = SynthMulAir(w), generate_synth_mul_trace(n, w, seed), np.zeros(0, dtype=np.uint32)
     elif kind == "ext":
         air, trace, pis = SynthExtAir(w), generate_synth_ext_trace(n, w, seed), np.zeros(0, dtype=np.uint32)
+    elif kind == "pow":
+        air, trace, pis = PowAir(w), pow_trace(n, w, seed), np.zeros(0, dtype=np.uint32)
     else:
         trace = generate_fibonacci_trace(seed % 1000, (seed >> 10) % 1000, n)
         air, pis = FibonacciAir(), fibonacci_public_values(trace)

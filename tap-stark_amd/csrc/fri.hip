@@ -11,6 +11,7 @@
 #include "chal_dev.hpp"
 #include "kernels.hpp"
 #include "merkle_tree.hpp"
+#include "leaf_tree.hpp"
 
 namespace ts {
 
@@ -153,7 +154,71 @@ k_fri_round(const Ef* __restrict__ prev, const uint32_t* __restrict__ tw, const 
     const mt::Levels lv{tree, 0, (uint64_t)1 << log_leaves};
     FriLeaves<FOLD> prod{prev, tw, ef_zero(), cur, tree};
     if (FOLD) prod.half_beta_mont = ef_mul_base(ef_to_mont(load_ef(beta_prev)), HALF_MONT);
-    mt::tree_body(lds, s_last, prod, lv, log_leaves, ticket, ch, root_out, beta_out);
+    mt::T9::tree_body(lds, s_last, prod, lv, log_leaves, ticket, ch, root_out, beta_out);
+}
+
+// The same round for a TALL vector, through the leaf-tree kernel (leaf_tree.hpp): a lane folds and
+// hashes R leaves, the first log2(R) levels stay in its registers.  Before round 5 a round above
+// 2^17 leaves was a fold launch, one launch per level and the tree launch.
+template <bool FOLD>
+struct FriLeaf {
+    const Ef* prev;
+    const uint32_t* tw;
+    const Ef* beta_prev;
+    Ef* cur;
+    static const char* name(int lr) {
+        static const char* const N[2][4] = {{"k_leaf_tree<0,fri_leaf>", "k_leaf_tree<1,fri_leaf>",
+                                             "k_leaf_tree<2,fri_leaf>", "k_leaf_tree<3,fri_leaf>"},
+                                            {"k_leaf_tree<0,fri_fold>", "k_leaf_tree<1,fri_fold>",
+                                             "k_leaf_tree<2,fri_fold>", "k_leaf_tree<3,fri_fold>"}};
+        return N[FOLD ? 1 : 0][lr];
+    }
+    __device__ __forceinline__ void digest(uint64_t i, uint32_t cv[8]) const {
+        Ef a, b;
+        if (FOLD) {
+            const Ef half_beta_mont = ef_mul_base(ef_to_mont(load_ef(beta_prev)), HALF_MONT);
+            a = fold_one(load_ef(prev + 4 * i), load_ef(prev + 4 * i + 1), tw[2 * i], half_beta_mont, HALF_MONT);
+            b = fold_one(load_ef(prev + 4 * i + 2), load_ef(prev + 4 * i + 3), tw[2 * i + 1], half_beta_mont,
+                         HALF_MONT);
+            store_ef(cur + 2 * i, a);
+            store_ef(cur + 2 * i + 1, b);
+        } else {
+            a = load_ef(cur + 2 * i);
+            b = load_ef(cur + 2 * i + 1);
+        }
+        const uint32_t m[16] = {a.c[0], a.c[1], a.c[2], a.c[3], b.c[0], b.c[1], b.c[2], b.c[3],
+                                0, 0, 0, 0, 0, 0, 0, 0};
+        b3::iv(cv);
+        b3::compress(cv, m, 32, b3::CHUNK_START | b3::CHUNK_END | b3::ROOT);
+    }
+};
+
+bool launch_fri_round_tall(Context& ctx, const Ef* prev, const Ef* d_beta_prev, Ef* cur, uint64_t h,
+                           uint32_t* tree, DevChallenger* ch, uint32_t* root_out, Ef* beta_out,
+                           uint64_t h_global, uint64_t row0) {
+    if (h_global == 0) h_global = h;
+    unsigned log_h = 0, log_hg = 0;
+    while ((1ull << log_h) < h) log_h++;
+    while ((1ull << log_hg) < h_global) log_hg++;
+    TS_REQUIRE((1ull << log_h) == h && (1ull << log_hg) == h_global && row0 + h <= h_global, TS_ERR_INVALID,
+               "fri_round_tall: leaf counts must be powers of two");
+    if (!leaf_tree_enabled(log_h)) {  // the round-4 path: fold (+ leaf digests), levels, tree
+        if (prev != nullptr)
+            launch_fri_fold_dev(ctx, prev, 2 * h, d_beta_prev, cur, tree, 2 * h_global, 2 * row0);
+        else
+            launch_leaf_hash_ef_pairs(ctx, reinterpret_cast<const uint32_t*>(cur), h, tree);
+        return launch_merkle_levels(ctx, tree, log_h, ch, root_out, beta_out);
+    }
+    if (prev != nullptr) {
+        // the fold's output has 2 h_global elements (twiddles of order 4 h_global); this slab's first
+        // output is global element 2 row0
+        ctx.ensure_twiddles(log_hg + 2);
+        launch_leaf_tree(ctx, FriLeaf<true>{prev, ctx.d_twiddle_inv + 2 * h_global + 2 * row0, d_beta_prev, cur},
+                         tree, log_h, ch, root_out, beta_out);
+    } else {
+        launch_leaf_tree(ctx, FriLeaf<false>{nullptr, nullptr, nullptr, cur}, tree, log_h, ch, root_out, beta_out);
+    }
+    return ch != nullptr;
 }
 
 unsigned fri_round_max_log() {

@@ -81,6 +81,15 @@ struct DevChallenger;
 bool launch_merkle_levels(Context& ctx, uint32_t* tree, unsigned log_leaves,
                           DevChallenger* ch = nullptr, uint32_t* root_out = nullptr,
                           Ef* beta_out = nullptr);
+// Leaf digests AND every level in one launch where the shape allows (leaf_tree.hpp; 2^8 leaves and
+// up, rows of at most 256 elements; TS_LEAF_TREE=0 or another shape: launch_leaf_hash +
+// launch_merkle_levels).  Return value as launch_merkle_levels.
+bool leaf_tree_enabled(unsigned log_leaves);
+bool launch_commit_tree(Context& ctx, const LeafMats& mats, unsigned log_leaves, uint32_t* tree,
+                        DevChallenger* ch = nullptr, uint32_t* root_out = nullptr, Ef* beta_out = nullptr);
+bool launch_commit_tree_ef_pairs(Context& ctx, const uint32_t* vec, unsigned log_leaves, uint32_t* tree,
+                                 DevChallenger* ch = nullptr, uint32_t* root_out = nullptr,
+                                 Ef* beta_out = nullptr);
 // mixed-height batches: one level at a time, with the digests of the rows of the matrices whose
 // height equals the level's node count compressed into the nodes (node = Blake3(node || inj))
 // sharded trees: the G sub-tree roots (gathered, rank order) -> the log2(G) top levels.  `top`
@@ -184,6 +193,14 @@ void launch_fri_fold_dev(Context& ctx, const Ef* in, uint64_t h, const Ef* d_bet
 constexpr unsigned FRI_ROUND_MAX_LOG = 22;  // = mt::MAX_LOG_TREE (merkle_tree.hpp)
 void launch_fri_round(Context& ctx, const Ef* prev, const Ef* d_beta_prev, Ef* cur, uint64_t h,
                       uint32_t* tree, DevChallenger* ch, uint32_t* root_out, Ef* beta_out);
+// The same for a round of any height, through the leaf-tree kernel (leaf_tree.hpp: one launch from 2^8
+// to 2^22 leaves; TS_LEAF_TREE=0 or a smaller round: fold launch, level launches, tree launch).  Slab
+// form as launch_fri_fold_dev, in LEAVES: `cur`/`tree` hold leaves [row0, row0 + h) of a round of
+// h_global leaves (the sub-tree of a sharded prover's slab).  Returns whether the challenger step ran
+// (as launch_merkle_levels).
+bool launch_fri_round_tall(Context& ctx, const Ef* prev, const Ef* d_beta_prev, Ef* cur, uint64_t h,
+                           uint32_t* tree, DevChallenger* ch, uint32_t* root_out, Ef* beta_out,
+                           uint64_t h_global = 0, uint64_t row0 = 0);
 unsigned merkle_tree_max_log();  // trees up to this many levels are one launch (TS_TREE_MAX_LOG)
 unsigned fri_round_max_log();    // commit rounds up to this many levels are one launch (TS_FRI_ROUND_LOG)
 // device-resident transcript (chal_dev.hpp): observe the root at `root`, sample beta

@@ -9,6 +9,7 @@
 #include "blake3.hpp"
 #include "blake3_quad.hpp"
 #include "merkle_tree.hpp"
+#include "leaf_tree.hpp"
 #include "chal_dev.hpp"
 #include "kernels.hpp"
 
@@ -275,8 +276,125 @@ k_merkle_tree(uint32_t* __restrict__ tree, unsigned log_leaves, unsigned first_l
     for (unsigned l = 0; l < first_level; l++) off += (uint64_t)1 << (log_leaves - l);
     const unsigned remaining = log_leaves - first_level;
     const mt::Levels lv{tree, off, (uint64_t)1 << remaining};
-    mt::StagedNodes<false> prod{lv.at(0, 0)};
-    mt::tree_body(lds, s_last, prod, lv, remaining, ticket, ch, root_out, beta_out);
+    mt::T9::StagedNodes<false> prod{lv.at(0, 0)};
+    mt::T9::tree_body(lds, s_last, prod, lv, remaining, ticket, ch, root_out, beta_out);
+}
+
+void launch_merkle_tree_from(Context& ctx, uint32_t* tree, unsigned log_leaves, unsigned first_level,
+                             DevChallenger* ch, uint32_t* root_out, Ef* beta_out) {
+    TS_REQUIRE(first_level < log_leaves && log_leaves - first_level <= mt::MAX_LOG_TREE, TS_ERR_INVALID,
+               "merkle_tree_from: between 2 and 2^22 nodes in the first level");
+    const unsigned remaining = log_leaves - first_level;
+    TS_LAUNCH(ctx, k_merkle_tree, dim3(1u << (remaining - mt::block_log(remaining))), dim3(mt::NTH), 0, tree,
+              log_leaves, first_level, ctx.ticket(), ch, root_out, beta_out);
+    TS_HIP(hipGetLastError());
+}
+
+// ---- leaves + tree in one launch (leaf_tree.hpp) ---------------------------------------------------
+// the leaf hashes of k_leaf_hash_strided / k_leaf_hash<1> / k_leaf_hash_ef_pairs as per-row functors
+struct StridedLeaf {
+    const uint32_t* base;
+    uint64_t stride;
+    uint32_t n_full, rem;
+    static const char* name(int lr) {
+        static const char* const N[4] = {"k_leaf_tree<0,strided>", "k_leaf_tree<1,strided>", "k_leaf_tree<2,strided>",
+                                         "k_leaf_tree<3,strided>"};
+        return N[lr];
+    }
+    __device__ __forceinline__ void digest(uint64_t r, uint32_t cv[8]) const {
+        b3::iv(cv);
+        const uint32_t* p = base + r;
+        for (uint32_t blk = 0; blk < n_full; blk++) {
+            uint32_t m[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) m[j] = p[(uint64_t)j * stride];
+            p += 16 * stride;
+            const uint32_t flags = (blk == 0 ? b3::CHUNK_START : 0u) |
+                                   (blk + 1 == n_full && rem == 0 ? (b3::CHUNK_END | b3::ROOT) : 0u);
+            b3::compress(cv, m, 64, flags);
+        }
+        if (rem != 0) {
+            uint32_t m[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) m[j] = (uint32_t)j < rem ? p[(uint64_t)j * stride] : 0u;
+            b3::compress(cv, m, rem * 4, (n_full == 0 ? b3::CHUNK_START : 0u) | b3::CHUNK_END | b3::ROOT);
+        }
+    }
+};
+
+struct TableLeaf {
+    const uint32_t* const* cols;
+    uint32_t total;
+    static const char* name(int lr) {
+        static const char* const N[4] = {"k_leaf_tree<0,table>", "k_leaf_tree<1,table>", "k_leaf_tree<2,table>",
+                                         "k_leaf_tree<3,table>"};
+        return N[lr];
+    }
+    __device__ __forceinline__ void digest(uint64_t r, uint32_t cv[8]) const {
+        b3::iv(cv);
+        const uint32_t n_blocks = total == 0 ? 1 : (total + 15) / 16;
+        for (uint32_t blk = 0; blk < n_blocks; blk++) {
+            uint32_t m[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const uint32_t c = blk * 16 + j;
+                m[j] = c < total ? cols[c][r] : 0u;
+            }
+            const uint32_t words = total - blk * 16 < 16 ? total - blk * 16 : 16;
+            const uint32_t flags = (blk == 0 ? b3::CHUNK_START : 0u) |
+                                   (blk + 1 == n_blocks ? (b3::CHUNK_END | b3::ROOT) : 0u);
+            b3::compress(cv, m, words * 4, flags);
+        }
+    }
+};
+
+struct EfPairLeaf {
+    const uint4* vec;
+    static const char* name(int lr) {
+        static const char* const N[4] = {"k_leaf_tree<0,ef_pairs>", "k_leaf_tree<1,ef_pairs>",
+                                         "k_leaf_tree<2,ef_pairs>", "k_leaf_tree<3,ef_pairs>"};
+        return N[lr];
+    }
+    __device__ __forceinline__ void digest(uint64_t r, uint32_t cv[8]) const {
+        const uint4 a = vec[2 * r], b = vec[2 * r + 1];
+        const uint32_t m[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, 0, 0, 0, 0, 0, 0, 0, 0};
+        b3::iv(cv);
+        b3::compress(cv, m, 32, b3::CHUNK_START | b3::CHUNK_END | b3::ROOT);
+    }
+};
+
+bool leaf_tree_enabled(unsigned log_leaves) {
+    static const int on = [] {
+        const char* e = getenv("TS_LEAF_TREE");  // 0: the round-4 path (leaf launch, level launches, tree launch)
+        return e ? atoi(e) : 1;
+    }();
+    return on != 0 && log_leaves >= mt::LEAF_TREE_MIN_LOG;
+}
+
+bool launch_commit_tree(Context& ctx, const LeafMats& mats, unsigned log_leaves, uint32_t* tree,
+                        DevChallenger* ch, uint32_t* root_out, Ef* beta_out) {
+    const uint64_t height = (uint64_t)1 << log_leaves;
+    if (!leaf_tree_enabled(log_leaves) || mats.total_width > 256) {
+        launch_leaf_hash(ctx, mats, height, tree);
+        return launch_merkle_levels(ctx, tree, log_leaves, ch, root_out, beta_out);
+    }
+    TS_REQUIRE(mats.cols != nullptr, TS_ERR_INVALID, "commit_tree: column pointer table missing");
+    if (mats.n_mats == 1 && mats.d[0] != nullptr && mats.total_width >= 1)
+        launch_leaf_tree(ctx, StridedLeaf{mats.d[0], mats.col_stride[0], mats.total_width / 16, mats.total_width % 16},
+                         tree, log_leaves, ch, root_out, beta_out);
+    else
+        launch_leaf_tree(ctx, TableLeaf{mats.cols, mats.total_width}, tree, log_leaves, ch, root_out, beta_out);
+    return ch != nullptr;
+}
+
+bool launch_commit_tree_ef_pairs(Context& ctx, const uint32_t* vec, unsigned log_leaves, uint32_t* tree,
+                                 DevChallenger* ch, uint32_t* root_out, Ef* beta_out) {
+    if (!leaf_tree_enabled(log_leaves)) {
+        launch_leaf_hash_ef_pairs(ctx, vec, (uint64_t)1 << log_leaves, tree);
+        return launch_merkle_levels(ctx, tree, log_leaves, ch, root_out, beta_out);
+    }
+    launch_leaf_tree(ctx, EfPairLeaf{reinterpret_cast<const uint4*>(vec)}, tree, log_leaves, ch, root_out, beta_out);
+    return ch != nullptr;
 }
 
 // Measured (tools/time_tree.py, us per tree above the leaves, one launch / per-level launches down to

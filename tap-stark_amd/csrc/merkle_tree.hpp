@@ -1,23 +1,35 @@
-// A whole Merkle tree (up to 2^22 nodes in its first level) in ONE launch (device only).
+// A whole Merkle tree in ONE launch (device only).
 //
 // Workgroup g takes a block of B = 2^log_b consecutive nodes of the first level and reduces it to
 // its sub-root; the workgroup that finishes LAST (ticket counter in device memory, sub-roots handed
-// over with sc1 stores / loads behind one acquire in the finisher: see the hand-off note in tree_body) reduces the n_sub
-// sub-roots to the root and, if asked, runs the device challenger step.  Every level is stored in
-// the tree (levels back to back, as the gathers of the query phase expect).
+// over with sc1 stores / loads behind one acquire in the finisher: see the hand-off note in
+// finish_tree) reduces the n_sub sub-roots to the root and, if asked, runs the device challenger
+// step.  Every level is stored in the tree (levels back to back, as the gathers of the query phase
+// expect).
 //
-// A block passes through LDS in chunks of CH = 512 nodes, image layout [word][node] (conflict-free
-// for the coalesced staging and for the compressions).  Four lanes share one compression
-// (blake3_quad.hpp), so a level keeps all 256 lanes busy down to 64 parents; a chunk is therefore
-// reduced 512 -> 32 nodes only (four levels), the 32 are parked in a third image, and the parked
-// nodes of all chunks (<= 256) are reduced together: the latency-bound narrow levels run once per
-// block, not once per chunk.  Level barriers wait on LDS only, a level's digests go to the tree with
-// plain stores that stay in flight.
+// Two block bodies share the finisher:
 //
-// Where the first-level nodes come from is a template parameter (`Producer::fill`): digests already
-// in the tree (leaf kernels wrote them), or computed on the spot -- the FRI commit phase folds the
-// previous round's vector and hashes the pairs right here (fri.hip), which makes a commit round one
-// launch instead of fold + levels + top.
+//  * tree_body (Tree<9>; k_merkle_tree, k_fri_round): up to 2^22 first-level nodes that lie in the
+//    tree already or are produced chunk by chunk (`Producer::fill`).  A block passes through LDS in
+//    chunks of CH = 512 nodes, image layout [word][node] (conflict-free for the coalesced staging
+//    and for the compressions).  Four lanes share one compression (blake3_quad.hpp), so a level
+//    keeps all 256 lanes busy down to 64 parents; a chunk is therefore reduced 512 -> 32 nodes only
+//    (four levels), the 32 are parked in a third image, and the parked nodes of all chunks (<= 256)
+//    are reduced together: the latency-bound narrow levels run once per block, not once per chunk.
+//    Level barriers wait on LDS only, a level's digests go to the tree with plain stores that stay
+//    in flight.
+//
+//  * leaf_tree_body (Tree<8>; k_commit_tree, k_fri_commit): LEAVES AND TREE in one launch, for trees
+//    of 2^8 .. 2^23 leaves (round 5; before it a tall tree was a leaf launch, one launch per level
+//    down to 2^17 nodes -- every one re-reading from HBM what the previous one wrote -- and the
+//    tree launch).  A lane hashes R = 2^LOG_R leaves (rows base + 256 k + lane, k < R: coalesced
+//    columns, adjacent lanes = adjacent rows) and keeps the R digests in registers.  The first
+//    LOG_R levels never leave the registers: in step s the two lanes that differ in bit s hold
+//    sibling nodes for every k, so they swap half of their digests (DPP quad_perm for s = 0, 1,
+//    ds_swizzle for s = 2: no LDS memory, no barrier) and each compresses half of the pairs --
+//    every lane busy with whole compressions at the ALU rate of the leaf hashes themselves.  The
+//    256 nodes a workgroup is left with go through LDS: 128 and 64 parents one compression per
+//    lane, the narrow rest four lanes per compression.  Sub-root hand-off and finisher as above.
 #pragma once
 #include "blake3_quad.hpp"
 #include "chal_dev.hpp"
@@ -26,24 +38,30 @@ namespace ts {
 namespace mt {
 
 constexpr int NTH = 256;
-constexpr uint32_t CH = 512;          // nodes per LDS chunk
-constexpr uint32_t LOG_CH = 9;
-constexpr uint32_t KEEP = 32;         // nodes a chunk is reduced to when its block has several chunks
+constexpr uint32_t KEEP = 32;  // nodes a chunk is reduced to when its block has several chunks
 constexpr uint32_t LOG_KEEP = 5;
+
+// host + device: the constants of the whole-tree kernels (Tree<9>)
+constexpr uint32_t CH = 512;            // nodes per LDS chunk
+constexpr uint32_t LOG_CH = 9;
 constexpr unsigned MAX_LOG_BLOCK = 12;  // 8 chunks -> 256 parked nodes
 constexpr unsigned MAX_LOG_SUB = 10;    // sub-roots the last workgroup reduces (2 chunks)
 constexpr unsigned MAX_LOG_TREE = MAX_LOG_BLOCK + MAX_LOG_SUB;
-
-struct Lds {
-    uint32_t in[8 * CH];    // a chunk as staged / produced
-    uint32_t ab[8 * CH];    // ping (nodes 0..255) and pong (nodes 256..383) of the levels
-    uint32_t keep[8 * CH];  // parked chunk results
-};
 
 // host + device: log2 of the block a workgroup takes, for a tree of 2^remaining first-level nodes
 TS_HD unsigned block_log(unsigned remaining) {
     if (remaining <= 8) return remaining;
     return remaining - 8 > MAX_LOG_SUB ? remaining - MAX_LOG_SUB : 8;
+}
+
+// leaf_tree_body: the smallest tree it takes, the most sub-roots its finisher takes (8 chunks of
+// 256), and the leaves per lane (log2) for a tree of 2^log_leaves leaves
+constexpr unsigned LEAF_TREE_MIN_LOG = 8;
+constexpr unsigned LEAF_TREE_MAX_LOG_SUB = 11;
+TS_HD unsigned leaf_tree_log_r(unsigned log_leaves) {
+    // >= 1024 workgroups where the tree allows it (four resident per CU), then as many in-register
+    // levels as the registers hold
+    return log_leaves >= 21 ? 3 : log_leaves >= 18 ? log_leaves - 18 : 0;
 }
 
 #if defined(__HIPCC__)
@@ -58,165 +76,301 @@ struct Levels {
     }
 };
 
-// Reduces `count` nodes of image `src` (nodes 0..count-1, both powers of two, count <= CH) to `stop`
-// nodes.  src holds nodes [node0, node0 + count) of relative level `level`; every level produced is
-// stored in the tree.  Returns the image holding the result.  With publish, the single node of the
-// last level (stop == 1) is written through for another workgroup to read.
-__device__ __forceinline__ const uint32_t* reduce_levels(Lds& lds, const uint32_t* src, uint32_t count,
-                                                         uint32_t stop, const Levels& lv, unsigned level,
-                                                         uint64_t node0, const uint32_t moff[28],
-                                                         bool publish) {
-    const uint32_t j = threadIdx.x & 3;
-    unsigned l = 0;
-    for (uint32_t n_par = count >> 1; n_par >= stop; n_par >>= 1, l++) {
-        uint32_t* dst = lds.ab + ((l & 1) ? 256 : 0);
-        level++;
-        node0 >>= 1;
-        uint32_t* out = lv.at(level, node0);
-        for (uint32_t t = threadIdx.x; t < 4 * n_par; t += NTH) {
-            const uint32_t i = t >> 2;
-            const uint32_t* base = src + 2 * i;
-            uint32_t lo, hi;
-            b3::compress_quad(j, b3::iv_word(j), b3::iv_word(4 + j),
-                              [&](int k) { return base[moff[k]]; }, 64,
-                              b3::CHUNK_START | b3::CHUNK_END | b3::ROOT, lo, hi);
-            dst[j * CH + i] = lo;
-            dst[(4 + j) * CH + i] = hi;
-            uint32_t* o = out + 8 * i;
-            if (publish && n_par == 1) {
-                __hip_atomic_store(o + j, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(o + 4 + j, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+template <unsigned LC>
+struct Tree {
+    static constexpr uint32_t CH = 1u << LC;
+
+    struct Lds {
+        uint32_t in[8 * CH];    // a chunk as staged / produced
+        uint32_t ab[8 * CH];    // ping (nodes 0..CH/2-1) and pong (nodes CH/2..3CH/4-1) of the levels
+        uint32_t keep[8 * CH];  // parked chunk results
+    };
+
+    // Reduces `count` nodes of image `src` (nodes 0..count-1, both powers of two, count <= CH) to `stop`
+    // nodes.  src holds nodes [node0, node0 + count) of relative level `level`; every level produced is
+    // stored in the tree.  Returns the image holding the result.  With publish, the single node of the
+    // last level (stop == 1) is written through for another workgroup to read.
+    // wide_from: levels with at least this many parents run one compression per LANE (b3::hash64 on
+    // two ds_read_b64 streams) instead of four lanes per compression: 10.5 against 14.4 issued
+    // instructions per compression, at three times the chain length -- right where other workgroups
+    // fill the SIMDs (leaf_tree_body's blocks), wrong for a finisher that runs alone (0 = never).
+    __device__ static __forceinline__ const uint32_t* reduce_levels(Lds& lds, const uint32_t* src, uint32_t count,
+                                                                    uint32_t stop, const Levels& lv, unsigned level,
+                                                                    uint64_t node0, const uint32_t moff[28],
+                                                                    bool publish, uint32_t wide_from = 0) {
+        const uint32_t j = threadIdx.x & 3;
+        unsigned l = 0;
+        for (uint32_t n_par = count >> 1; n_par >= stop; n_par >>= 1, l++) {
+            uint32_t* dst = lds.ab + ((l & 1) ? CH / 2 : 0);
+            level++;
+            node0 >>= 1;
+            uint32_t* out = lv.at(level, node0);
+            if (wide_from != 0 && n_par >= wide_from) {
+                for (uint32_t i = threadIdx.x; i < n_par; i += NTH) {
+                    uint32_t m[16], cv[8];
+#pragma unroll
+                    for (int w = 0; w < 8; w++) {
+                        const uint2 v = *reinterpret_cast<const uint2*>(src + w * CH + 2 * i);
+                        m[w] = v.x;
+                        m[8 + w] = v.y;
+                    }
+                    b3::hash64(m, cv);
+#pragma unroll
+                    for (int w = 0; w < 8; w++) dst[w * CH + i] = cv[w];
+                    uint4* o = reinterpret_cast<uint4*>(out + 8 * i);
+                    o[0] = make_uint4(cv[0], cv[1], cv[2], cv[3]);
+                    o[1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
+                }
             } else {
-                o[j] = lo;
-                o[4 + j] = hi;
+                for (uint32_t t = threadIdx.x; t < 4 * n_par; t += NTH) {
+                    const uint32_t i = t >> 2;
+                    const uint32_t* base = src + 2 * i;
+                    uint32_t lo, hi;
+                    b3::compress_quad(j, b3::iv_word(j), b3::iv_word(4 + j),
+                                      [&](int k) { return base[moff[k]]; }, 64,
+                                      b3::CHUNK_START | b3::CHUNK_END | b3::ROOT, lo, hi);
+                    dst[j * CH + i] = lo;
+                    dst[(4 + j) * CH + i] = hi;
+                    uint32_t* o = out + 8 * i;
+                    if (publish && n_par == 1) {
+                        __hip_atomic_store(o + j, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(o + 4 + j, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else {
+                        o[j] = lo;
+                        o[4 + j] = hi;
+                    }
+                }
+            }
+            b3::lds_barrier();
+            src = dst;
+        }
+        return src;
+    }
+
+    // One block: `count` (a power of two <= 8 * CH) nodes [node0, node0 + count) of relative
+    // level `level`, produced chunk by chunk by prod.fill(lds.in, first node, how many), down to one node.
+    // Returns the image whose node 0 is the block's root.
+    template <class Producer>
+    __device__ static __forceinline__ const uint32_t* reduce_block(Lds& lds, Producer& prod, uint32_t count,
+                                                                   const Levels& lv, unsigned level, uint64_t node0,
+                                                                   const uint32_t moff[28], bool publish) {
+        if (count <= CH) {
+            prod.fill(lds.in, node0, count);
+            if (count == 1) return lds.in;
+            return reduce_levels(lds, lds.in, count, 1, lv, level, node0, moff, publish);
+        }
+        const uint32_t n_chunks = count >> LC;
+        for (uint32_t c = 0; c < n_chunks; c++) {
+            prod.fill(lds.in, node0 + (uint64_t)c * CH, CH);
+            const uint32_t* x = reduce_levels(lds, lds.in, CH, KEEP, lv, level, node0 + (uint64_t)c * CH, moff, false);
+            {
+                const uint32_t w = threadIdx.x >> LOG_KEEP, n = threadIdx.x & (KEEP - 1);  // 8 x 32 = 256 lanes
+                lds.keep[w * CH + c * KEEP + n] = x[w * CH + n];
+            }
+            b3::lds_barrier();
+        }
+        return reduce_levels(lds, lds.keep, n_chunks * KEEP, 1, lv, level + (LC - LOG_KEEP),
+                             node0 >> (LC - LOG_KEEP), moff, publish);
+    }
+
+    // first-level nodes that already lie in the tree; SC1: they were written by other workgroups of
+    // this launch (loads must bypass this CU's L1)
+    template <bool SC1>
+    struct StagedNodes {
+        const uint32_t* nodes;  // the level's node 0
+        __device__ __forceinline__ void fill(uint32_t* in, uint64_t node0, uint32_t count) {
+            const uint32_t* p = nodes + 8 * node0;
+            if (SC1) {
+                for (uint32_t e = threadIdx.x; e < 8 * count; e += NTH)
+                    in[(e & 7) * CH + (e >> 3)] = __hip_atomic_load(p + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                const uint4* p4 = reinterpret_cast<const uint4*>(p);
+                for (uint32_t e = threadIdx.x; e < 2 * count; e += NTH) {  // 16 bytes = half a node per lane
+                    const uint4 v = p4[e];
+                    uint32_t* o = in + (e & 1) * 4 * CH + (e >> 1);
+                    o[0] = v.x;
+                    o[CH] = v.y;
+                    o[2 * CH] = v.z;
+                    o[3 * CH] = v.w;
+                }
+            }
+            __syncthreads();
+        }
+    };
+
+    __device__ static __forceinline__ void quad_offsets(uint32_t moff[28]) {
+        uint32_t idx[28];
+        b3::quad_schedule(threadIdx.x & 3, idx);
+#pragma unroll
+        for (int k = 0; k < 28; k++) moff[k] = (idx[k] & 7) * CH + (idx[k] >> 3);
+    }
+
+    // What every workgroup does once its block is down to its sub-root `top` (node blockIdx.x of
+    // relative level log_b; n_sub = gridDim.x of them): hand-off, the last one reduces the sub-roots
+    // to the root, then the device challenger step.
+    __device__ static __forceinline__ void finish_tree(Lds& lds, uint32_t& s_last, const uint32_t* top,
+                                                       const Levels& lv, unsigned log_b, uint32_t n_sub,
+                                                       const uint32_t moff[28], uint32_t* ticket,
+                                                       DevChallenger* ch, uint32_t* root_out, Ef* beta_out) {
+        bool finisher = n_sub == 1;
+        if (n_sub > 1) {
+            // Hand-off between workgroups.  Per-XCD L2s are not coherent with each other and a CU's L1
+            // is never refreshed by another CU's stores, so (MI355X_MICROARCH.md, "Valid forms" and its
+            // table of measured hand-offs): every handed-off byte -- the 32-byte sub-root -- is stored
+            // sc1 (written through, dropped from the XCD's L2) and loaded sc1 (bypassing L1); the
+            // storing wave drains its stores, the workgroup meets, ONE lane adds to the ticket counter
+            // at agent scope; the workgroup whose add came last loads after a barrier behind that add.
+            // No RELEASE fence on the producing side (sc1 stores are written through; 2-6 us saved per
+            // workgroup).  The consuming side keeps ONE agent-scope acquire in the finishing workgroup:
+            // the guide's fence-free consumer form is measured at one workgroup per CU only, and this
+            // kernel runs two or three per CU with several proofs in flight.  It costs the
+            // finisher ~2.4 us per tree (30.1 against 27.7 us for a 2^16-leaf top) -- once per launch, not
+            // per workgroup -- and the sub-root loads stay sc1 on top of it.  tests/test_build_isa.py
+            // checks the disassembly: sc1 on these stores and loads, buffer_inv sc1, no flat_ access.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const uint32_t tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_last = tk == n_sub - 1 ? 1u : 0u;
+            }
+            __syncthreads();
+            if (s_last) {
+                if (threadIdx.x == 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __syncthreads();
+                StagedNodes<true> sub{lv.at(log_b, 0)};
+                top = reduce_block(lds, sub, n_sub, lv, log_b, 0, moff, false);
+                if (threadIdx.x == 0)  // ready for the next launch on this stream
+                    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                finisher = true;
             }
         }
-        b3::lds_barrier();
-        src = dst;
-    }
-    return src;
-}
-
-// One block: `count` (a power of two <= 2^MAX_LOG_BLOCK) nodes [node0, node0 + count) of relative
-// level `level`, produced chunk by chunk by prod.fill(lds.in, first node, how many), down to one node.
-// Returns the image whose node 0 is the block's root.
-template <class Producer>
-__device__ __forceinline__ const uint32_t* reduce_block(Lds& lds, Producer& prod, uint32_t count,
-                                                        const Levels& lv, unsigned level, uint64_t node0,
-                                                        const uint32_t moff[28], bool publish) {
-    if (count <= CH) {
-        prod.fill(lds.in, node0, count);
-        if (count == 1) return lds.in;
-        return reduce_levels(lds, lds.in, count, 1, lv, level, node0, moff, publish);
-    }
-    const uint32_t n_chunks = count >> LOG_CH;
-    for (uint32_t c = 0; c < n_chunks; c++) {
-        prod.fill(lds.in, node0 + (uint64_t)c * CH, CH);
-        const uint32_t* x = reduce_levels(lds, lds.in, CH, KEEP, lv, level, node0 + (uint64_t)c * CH, moff, false);
-        {
-            const uint32_t w = threadIdx.x >> LOG_KEEP, n = threadIdx.x & (KEEP - 1);  // 8 x 32 = 256 lanes
-            lds.keep[w * CH + c * KEEP + n] = x[w * CH + n];
-        }
-        b3::lds_barrier();
-    }
-    return reduce_levels(lds, lds.keep, n_chunks * KEEP, 1, lv, level + (LOG_CH - LOG_KEEP),
-                         node0 >> (LOG_CH - LOG_KEEP), moff, publish);
-}
-
-// first-level nodes that already lie in the tree; SC1: they were written by other workgroups of
-// this launch (loads must bypass this CU's L1)
-template <bool SC1>
-struct StagedNodes {
-    const uint32_t* nodes;  // the level's node 0
-    __device__ __forceinline__ void fill(uint32_t* in, uint64_t node0, uint32_t count) {
-        const uint32_t* p = nodes + 8 * node0;
-        if (SC1) {
-            for (uint32_t e = threadIdx.x; e < 8 * count; e += NTH)
-                in[(e & 7) * CH + (e >> 3)] = __hip_atomic_load(p + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            const uint4* p4 = reinterpret_cast<const uint4*>(p);
-            for (uint32_t e = threadIdx.x; e < 2 * count; e += NTH) {  // 16 bytes = half a node per lane
-                const uint4 v = p4[e];
-                uint32_t* o = in + (e & 1) * 4 * CH + (e >> 1);
-                o[0] = v.x;
-                o[CH] = v.y;
-                o[2 * CH] = v.z;
-                o[3 * CH] = v.w;
+        // device-resident transcript (fri/src/prover.rs:114-116): the workgroup that produced the root
+        // observes it and samples the next challenge
+        if (finisher && ch != nullptr && threadIdx.x == 0) {
+            uint32_t root[8];
+            for (int k = 0; k < 8; k++) {
+                root[k] = top[k * CH];
+                root_out[k] = root[k];
             }
+            // (the parked-node image is free by now: the sponge runs on a copy there, see chal_dev.hpp)
+            DevChallenger* lc = reinterpret_cast<DevChallenger*>(lds.keep);
+            dc_copy(lc, ch);
+            const Ef beta = dc_observe_root_and_sample(lc, root);
+            dc_copy(ch, lc);
+            *reinterpret_cast<uint4*>(beta_out) = make_uint4(beta.c[0], beta.c[1], beta.c[2], beta.c[3]);
         }
-        __syncthreads();
+    }
+
+    // The body of a whole-tree kernel over staged / chunk-produced first-level nodes.  Grid = n_sub =
+    // 2^(remaining - log_b) workgroups of NTH lanes, remaining = log2(lv.n0) <= MAX_LOG_TREE, log_b =
+    // block_log(remaining).
+    template <class Producer>
+    __device__ static __forceinline__ void tree_body(Lds& lds, uint32_t& s_last, Producer& prod, const Levels& lv,
+                                                     unsigned remaining, uint32_t* ticket, DevChallenger* ch,
+                                                     uint32_t* root_out, Ef* beta_out) {
+        uint32_t moff[28];
+        quad_offsets(moff);
+        const unsigned log_b = block_log(remaining);
+        const uint32_t B = 1u << log_b;
+        const uint32_t n_sub = 1u << (remaining - log_b);
+        const uint32_t* top = reduce_block(lds, prod, B, lv, 0, (uint64_t)blockIdx.x * B, moff, n_sub > 1);
+        finish_tree(lds, s_last, top, lv, log_b, n_sub, moff, ticket, ch, root_out, beta_out);
     }
 };
 
-__device__ __forceinline__ void quad_offsets(uint32_t moff[28]) {
-    uint32_t idx[28];
-    b3::quad_schedule(threadIdx.x & 3, idx);
-#pragma unroll
-    for (int k = 0; k < 28; k++) moff[k] = (idx[k] & 7) * CH + (idx[k] >> 3);
+using T9 = Tree<9>;
+using Lds = T9::Lds;
+
+// ---- leaves and tree in one launch -------------------------------------------------------------
+// the lane whose id differs in bit S (S = 0, 1: DPP quad_perm, a modifier-class move; S = 2: ds_swizzle
+// in bit-mask mode, and = 0x1f, xor = 4 -- the LDS crossbar, no LDS memory)
+template <int S>
+__device__ __forceinline__ uint32_t lane_xor(uint32_t v) {
+    static_assert(S >= 0 && S <= 2, "lane_xor: in-register levels reach three lane bits");
+    if constexpr (S == 0) return b3::quad_perm<0xB1>(v);
+    else if constexpr (S == 1) return b3::quad_perm<0x4E>(v);
+    else return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x101F);
 }
 
-// The body of a tree kernel.  Grid = n_sub = 2^(remaining - log_b) workgroups of NTH lanes,
-// remaining = log2(lv.n0) <= MAX_LOG_TREE, log_b = block_log(remaining).
-template <class Producer>
-__device__ __forceinline__ void tree_body(Lds& lds, uint32_t& s_last, Producer& prod, const Levels& lv,
-                                          unsigned remaining, uint32_t* ticket, DevChallenger* ch,
-                                          uint32_t* root_out, Ef* beta_out) {
+// One in-register level.  Before: D[0..C) with D[m] the digest of node (base + 256 k + lane) >> S of
+// relative level S, k = (m << S) + (lane & (2^S - 1)).  After: D[0..C/2), the same with S + 1.  The
+// partner lane (bit S flipped) holds the sibling of every one of this lane's nodes; the lane with
+// bit S clear takes the even m of each pair of digests, the other the odd m.
+template <int S, int C>
+__device__ __forceinline__ void register_level(uint32_t (*D)[8], const Levels& lv, uint64_t base) {
+    const uint32_t tid = threadIdx.x;
+    const bool hi = (tid >> S) & 1u;
+#pragma unroll
+    for (int m = 0; m < C / 2; m++) {
+        uint32_t msg[16], cv[8];
+#pragma unroll
+        for (int w = 0; w < 8; w++) {
+            const uint32_t send = hi ? D[2 * m][w] : D[2 * m + 1][w];
+            const uint32_t keep = hi ? D[2 * m + 1][w] : D[2 * m][w];
+            const uint32_t recv = lane_xor<S>(send);
+            msg[w] = hi ? recv : keep;      // left child: the lane with bit S clear
+            msg[8 + w] = hi ? keep : recv;  // right child
+        }
+        b3::hash64(msg, cv);
+#pragma unroll
+        for (int w = 0; w < 8; w++) D[m][w] = cv[w];
+        const uint32_t k = ((uint32_t)(2 * m + (hi ? 1 : 0)) << S) + (tid & ((1u << S) - 1));
+        uint4* o = reinterpret_cast<uint4*>(lv.at(S + 1, (base + 256ull * k + tid) >> (S + 1)));
+        o[0] = make_uint4(cv[0], cv[1], cv[2], cv[3]);
+        o[1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
+    }
+}
+
+using T8 = Tree<8>;
+
+// D[k] = digest of leaf row0 + 256 k, k = K .. R-1, stored as level 0.  (A recursion, not a loop: the
+// compiler left `#pragma unroll` over a leaf hash that loops itself partly rolled and put D in scratch.)
+template <int K, int R, class Leaf>
+__device__ __forceinline__ void leaf_rows(Leaf& leaf, uint32_t (*D)[8], const Levels& lv, uint64_t row0) {
+    if constexpr (K < R) {
+        const uint64_t row = row0 + 256u * K;
+        leaf.digest(row, D[K]);
+        uint4* o = reinterpret_cast<uint4*>(lv.at(0, row));
+        o[0] = make_uint4(D[K][0], D[K][1], D[K][2], D[K][3]);
+        o[1] = make_uint4(D[K][4], D[K][5], D[K][6], D[K][7]);
+        leaf_rows<K + 1, R>(leaf, D, lv, row0);
+    }
+}
+
+// Grid = 2^(log_leaves - 8 - LOG_R) workgroups of NTH lanes; leaf.digest(row, cv) hashes leaf `row`
+// (any side effect -- the FRI fold's store -- included).  All lanes of every workgroup are active
+// (the lane exchanges need them).  finish = false (n_sub > 2^LEAF_TREE_MAX_LOG_SUB): the launch ends
+// with the sub-roots in the tree and a whole-tree kernel takes the level over.
+template <int LOG_R, class Leaf>
+__device__ __forceinline__ void leaf_tree_body(T8::Lds& lds, uint32_t& s_last, Leaf& leaf, const Levels& lv,
+                                               unsigned log_leaves, bool finish, uint32_t* ticket,
+                                               DevChallenger* ch, uint32_t* root_out, Ef* beta_out) {
+    constexpr int R = 1 << LOG_R;
+    const uint32_t tid = threadIdx.x;
+    const uint64_t base = (uint64_t)blockIdx.x * (256u * R);
+    uint32_t D[R][8];
+    leaf_rows<0, R>(leaf, D, lv, base + tid);
+    if constexpr (LOG_R >= 1) register_level<0, R>(D, lv, base);
+    if constexpr (LOG_R >= 2) register_level<1, R / 2>(D, lv, base);
+    if constexpr (LOG_R >= 3) register_level<2, R / 4>(D, lv, base);
+    // D[0]: node (base + 256 k + tid) >> LOG_R of level LOG_R, k = tid & (R - 1): slot among the
+    // workgroup's 256 nodes of that level
+    {
+        const uint32_t slot = (256u >> LOG_R) * (tid & (R - 1)) + (tid >> LOG_R);
+#pragma unroll
+        for (int w = 0; w < 8; w++) lds.in[w * T8::CH + slot] = D[0][w];
+    }
+    b3::lds_barrier();
     uint32_t moff[28];
-    quad_offsets(moff);
-    const unsigned log_b = block_log(remaining);
-    const uint32_t B = 1u << log_b;
-    const uint32_t n_sub = 1u << (remaining - log_b);
-    const uint32_t* top = reduce_block(lds, prod, B, lv, 0, (uint64_t)blockIdx.x * B, moff, n_sub > 1);
-    bool finisher = n_sub == 1;
-    if (n_sub > 1) {
-        // Hand-off between workgroups.  Per-XCD L2s are not coherent with each other and a CU's L1
-        // is never refreshed by another CU's stores, so (MI355X_MICROARCH.md, "Valid forms" and its
-        // table of measured hand-offs): every handed-off byte -- the 32-byte sub-root -- is stored
-        // sc1 (written through, dropped from the XCD's L2) and loaded sc1 (bypassing L1); the
-        // storing wave drains its stores, the workgroup meets, ONE lane adds to the ticket counter
-        // at agent scope; the workgroup whose add came last loads after a barrier behind that add.
-        // No RELEASE fence on the producing side (sc1 stores are written through; 2-6 us saved per
-        // workgroup).  The consuming side keeps ONE agent-scope acquire in the finishing workgroup:
-        // the guide's fence-free consumer form is measured at one workgroup per CU only, and this
-        // kernel runs two or three per CU with several proofs in flight.  It costs the
-        // finisher ~2.4 us per tree (30.1 against 27.7 us for a 2^16-leaf top) -- once per launch, not
-        // per workgroup -- and the sub-root loads stay sc1 on top of it.  tests/test_build_isa.py
-        // checks the disassembly: sc1 on these stores and loads, buffer_inv sc1, no flat_ access.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const uint32_t tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_last = tk == n_sub - 1 ? 1u : 0u;
-        }
-        __syncthreads();
-        if (s_last) {
-            if (threadIdx.x == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            __syncthreads();
-            StagedNodes<true> sub{lv.at(log_b, 0)};
-            top = reduce_block(lds, sub, n_sub, lv, log_b, 0, moff, false);
-            if (threadIdx.x == 0)  // ready for the next launch on this stream
-                __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            finisher = true;
-        }
-    }
-    // device-resident transcript (fri/src/prover.rs:114-116): the workgroup that produced the root
-    // observes it and samples the next challenge
-    if (finisher && ch != nullptr && threadIdx.x == 0) {
-        uint32_t root[8];
-        for (int k = 0; k < 8; k++) {
-            root[k] = top[k * CH];
-            root_out[k] = root[k];
-        }
-        // (the parked-node image is free by now: the sponge runs on a copy there, see chal_dev.hpp)
-        DevChallenger* lc = reinterpret_cast<DevChallenger*>(lds.keep);
-        dc_copy(lc, ch);
-        const Ef beta = dc_observe_root_and_sample(lc, root);
-        dc_copy(ch, lc);
-        *reinterpret_cast<uint4*>(beta_out) = make_uint4(beta.c[0], beta.c[1], beta.c[2], beta.c[3]);
-    }
+    T8::quad_offsets(moff);
+    const unsigned log_b = 8 + LOG_R;
+    const uint32_t n_sub = 1u << (log_leaves - log_b);
+    const uint32_t* top = T8::reduce_levels(lds, lds.in, 256, 1, lv, LOG_R, base >> LOG_R, moff,
+                                            finish && n_sub > 1, 64);
+    if (finish) T8::finish_tree(lds, s_last, top, lv, log_b, n_sub, moff, ticket, ch, root_out, beta_out);
 }
 
 #endif

@@ -86,7 +86,7 @@ void mmcs_commit(Context& ctx, PcsData& data) {
         }
         data.col_table = DevBuf<const uint32_t*>(&ctx, cols.size());
         h2d(ctx, data.col_table.p, cols.data(), cols.size() * sizeof(const uint32_t*));
-        auto group_leaves = [&](const Group& g, uint32_t* digests) {
+        auto group_mats = [&](const Group& g) {
             LeafMats lm;
             memset(&lm, 0, sizeof lm);
             lm.cols = data.col_table.p + g.first;
@@ -97,12 +97,15 @@ void mmcs_commit(Context& ctx, PcsData& data) {
                 lm.col_stride[0] = g.only->col_stride;
                 lm.width[0] = g.only->width;
             }
-            launch_leaf_hash(ctx, lm, g.height, digests);
+            return lm;
         };
-        group_leaves(groups[0], data.tree.p);
-        if (uniform) {
-            launch_merkle_levels(ctx, data.tree.p, log_H);
+        auto group_leaves = [&](const Group& g, uint32_t* digests) {
+            launch_leaf_hash(ctx, group_mats(g), g.height, digests);
+        };
+        if (uniform) {  // leaves and every level in one launch (leaf_tree.hpp)
+            launch_commit_tree(ctx, group_mats(groups[0]), log_H, data.tree.p);
         } else {
+            group_leaves(groups[0], data.tree.p);
             DevBuf<uint32_t> inj(&ctx, 8 * (N / 2));
             size_t gi = 1;
             for (unsigned l = 1; l <= log_H; l++) {
@@ -449,12 +452,9 @@ void fri_commit_rounds(Context& ctx, const FriConfig& fri, DevBuf<Ef> folded, ui
         if (fri_round_max_log() != 0 && r.log_leaves <= fri_round_max_log()) {
             launch_fri_round(ctx, prev, prev ? st.d_betas.p + ri - 1 : nullptr, folded.p, h, tree.p, dch,
                              st.d_roots.p + 8 * ri, st.d_betas.p + ri);
-        } else {
-            if (prev)  // the fold hashes its output pairs, i.e. this round's leaves, in the same pass
-                launch_fri_fold_dev(ctx, prev, len, st.d_betas.p + ri - 1, folded.p, tree.p);
-            else
-                launch_leaf_hash_ef_pairs(ctx, reinterpret_cast<const uint32_t*>(folded.p), h, tree.p);
-            if (!launch_merkle_levels(ctx, tree.p, r.log_leaves, dch, st.d_roots.p + 8 * ri, st.d_betas.p + ri))
+        } else {  // tall rounds: fold + leaves + tree in one launch (leaf_tree.hpp)
+            if (!launch_fri_round_tall(ctx, prev, prev ? st.d_betas.p + ri - 1 : nullptr, folded.p, h, tree.p, dch,
+                                       st.d_roots.p + 8 * ri, st.d_betas.p + ri))
                 launch_chal_round(ctx, dch, tree.p + 8 * (merkle_total_digests(r.log_leaves) - 1),
                                   st.d_roots.p + 8 * ri, st.d_betas.p + ri);
         }

@@ -180,8 +180,7 @@ std::unique_ptr<ShardedData> commit_sharded(Shard& sh, std::vector<DeviceMatrix>
             for (uint32_t c = 0; c < cm.width; c++) cols.push_back(cm.d + (uint64_t)c * cm.col_stride);
         loc.col_table = DevBuf<const uint32_t*>(&ctx, cols.size());
         h2d(ctx, loc.col_table.p, cols.data(), cols.size() * sizeof(const uint32_t*));
-        launch_leaf_hash(ctx, loc.leaf_mats(), rows, loc.tree.p);
-        launch_merkle_levels(ctx, loc.tree.p, log_rows);
+        launch_commit_tree(ctx, loc.leaf_mats(), log_rows, loc.tree.p);  // leaves + the slab's sub-tree
         DevBuf<uint32_t> d_top(&ctx, 8 * (size_t)(2 * sh.G - 1));
         gather_top(sh, "commit sub-roots", loc.tree.p + 8 * (merkle_total_digests(log_rows) - 1), d_top.p,
                    nullptr, nullptr, nullptr);
@@ -382,40 +381,37 @@ std::vector<uint32_t> prove_sharded(TwoAdicFriPcs& pcs, const Comm& comm, const 
         auto sharded_round = [&](uint64_t l_glob, uint64_t l_loc) {
             return l_glob > fri.blowup() && l_loc >= min_loc;
         };
-        DevBuf<uint32_t> next_tree;
-        bool leaves_ready = false;
+        // != nullptr: `folded` is not in memory yet -- it is the fold of this slab (the last round's)
+        // with the last round's challenge, and the next round's launch computes it while hashing
+        const Ef* prev = nullptr;
         while (sharded_round(len, loc)) {
             FriRound r;
             const uint64_t h_loc = loc / 2, h_glob = len / 2;
             r.log_leaves = log2_strict(h_loc);
-            DevBuf<uint32_t> tree;
-            if (leaves_ready) {
-                tree = std::move(next_tree);
-            } else {
-                tree = DevBuf<uint32_t>(&ctx, merkle_total_digests(r.log_leaves) * 8);
-                launch_leaf_hash_ef_pairs(ctx, reinterpret_cast<const uint32_t*>(folded.p), h_loc, tree.p);
-            }
             const size_t ri = st.rounds.size();
-            launch_merkle_levels(ctx, tree.p, r.log_leaves);  // the slab's sub-tree
+            DevBuf<uint32_t> tree(&ctx, merkle_total_digests(r.log_leaves) * 8);
+            if (prev) folded = DevBuf<Ef>(&ctx, loc);
+            // the slab's sub-tree: (fold +) leaves + levels in one launch (leaf_tree.hpp)
+            launch_fri_round_tall(ctx, prev, prev ? st.d_betas.p + ri - 1 : nullptr, folded.p, h_loc, tree.p, nullptr,
+                                  nullptr, nullptr, h_glob, (uint64_t)sh.rank * h_loc);
             // exchange 3; the top kernel observes the root and samples beta on every rank alike
             gather_top(sh, "FRI round sub-roots", tree.p + 8 * (merkle_total_digests(r.log_leaves) - 1),
                        d_tops.p + top_words * ri,
                        st.dch(), st.d_roots.p + 8 * ri, st.d_betas.p + ri);
-            DevBuf<Ef> out(&ctx, h_loc);
-            uint32_t* nd = nullptr;
-            leaves_ready = false;
-            if (sharded_round(h_glob, h_loc)) {
-                next_tree = DevBuf<uint32_t>(&ctx, merkle_total_digests(r.log_leaves - 1) * 8);
-                nd = next_tree.p;
-                leaves_ready = true;
-            }
-            launch_fri_fold_dev(ctx, folded.p, h_loc, st.d_betas.p + ri, out.p, nd, h_glob,
-                                (uint64_t)sh.rank * h_loc);
             r.vec = folded.p;
             r.tree = tree.p;
-            st.keep_vecs.push_back(std::move(folded));
+            if (sharded_round(h_glob, h_loc)) {
+                prev = folded.p;  // fri/src/prover.rs:119 happens inside the next round's launch
+                st.keep_vecs.push_back(std::move(folded));
+            } else {
+                DevBuf<Ef> out(&ctx, h_loc);
+                launch_fri_fold_dev(ctx, folded.p, h_loc, st.d_betas.p + ri, out.p, nullptr, h_glob,
+                                    (uint64_t)sh.rank * h_loc);
+                st.keep_vecs.push_back(std::move(folded));
+                folded = std::move(out);
+                prev = nullptr;
+            }
             st.keep_trees.push_back(std::move(tree));
-            folded = std::move(out);
             st.rounds.push_back(r);
             len = h_glob;
             loc = h_loc;

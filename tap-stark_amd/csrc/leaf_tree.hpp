@@ -2,11 +2,16 @@
 // template and its launcher, shared by merkle.hip (committed matrices) and fri.hip (commit-phase
 // rounds, with the fold in the leaf).  Device code; include from .hip files only.
 #pragma once
+#include <stdlib.h>
+
 #include "kernels.hpp"
 #include "merkle_tree.hpp"
 
 namespace ts {
 
+// (Occupancy is not what holds this kernel: built for 5 and 6 waves per SIMD -- 96 / 80 VGPRs with 80 /
+// 192 bytes of scratch -- it measured the same 199 / 482 us on 2^22 rows of 2 / 64 elements as at the 4
+// waves its 116 VGPRs allow.  Its issue fill is 0.95; what is left is the clock.)
 template <int LOG_R, class Leaf>
 __global__ void __launch_bounds__(mt::NTH)
 k_leaf_tree(Leaf leaf, uint32_t* __restrict__ tree, unsigned log_leaves, int finish,
@@ -32,10 +37,15 @@ void launch_leaf_tree(Context& ctx, const Leaf& leaf, uint32_t* tree, unsigned l
                       uint32_t* root_out, Ef* beta_out) {
     TS_REQUIRE(log_leaves >= mt::LEAF_TREE_MIN_LOG && log_leaves <= 27, TS_ERR_INVALID,
                "leaf_tree: between 2^8 and 2^27 leaves");
-    const unsigned log_r = mt::leaf_tree_log_r(log_leaves);
+    // measurement knobs: TS_LEAF_TREE_R = leaves per lane (log2, 0..3) whatever the height;
+    // TS_LEAF_TREE_FINISH=0: the sub-roots always go to a second launch (the whole-tree kernel)
+    static const int knob_r = [] { const char* e = getenv("TS_LEAF_TREE_R"); return e ? atoi(e) : -1; }();
+    static const int knob_finish = [] { const char* e = getenv("TS_LEAF_TREE_FINISH"); return e ? atoi(e) : 1; }();
+    unsigned log_r = mt::leaf_tree_log_r(log_leaves);
+    if (knob_r >= 0 && knob_r <= 3 && log_leaves >= 8u + (unsigned)knob_r) log_r = (unsigned)knob_r;
     const unsigned log_b = 8 + log_r;
     const unsigned log_sub = log_leaves - log_b;
-    const int finish = log_sub <= mt::LEAF_TREE_MAX_LOG_SUB ? 1 : 0;
+    const int finish = (log_sub <= mt::LEAF_TREE_MAX_LOG_SUB && (knob_finish || log_sub == 0)) ? 1 : 0;
     const dim3 grid(1u << log_sub), block(mt::NTH);
     DevChallenger* kch = finish ? ch : nullptr;
     // (kernel timers: one name per leaf kind and R, Leaf::name(log_r))

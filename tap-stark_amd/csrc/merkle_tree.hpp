@@ -54,14 +54,17 @@ TS_HD unsigned block_log(unsigned remaining) {
     return remaining - 8 > MAX_LOG_SUB ? remaining - MAX_LOG_SUB : 8;
 }
 
-// leaf_tree_body: the smallest tree it takes, the most sub-roots its finisher takes (8 chunks of
-// 256), and the leaves per lane (log2) for a tree of 2^log_leaves leaves
+// leaf_tree_body: the smallest tree it takes, the most sub-roots its in-kernel finisher takes, and the
+// leaves per lane (log2) for a tree of 2^log_leaves leaves.  Measured on 2^22 leaves
+// (tools/time_leaf_tree.py, us, rows of 2 / 64 elements): the finisher reduces its sub-roots chunk
+// after chunk, alone on the chip -- 2048 of them cost 55 us against 21 us for a second launch of the
+// whole-tree kernel -- so it takes one chunk at most; four leaves per lane (4096 workgroups) 221 /
+// 505, eight 219 / 528 (issue fill 0.95 against 0.87: eight unrolled copies of the row hash), two 231 /
+// 508, one 265 / 527; the round-4 path (leaf launch, five level launches, tree launch) 250 / 523.
 constexpr unsigned LEAF_TREE_MIN_LOG = 8;
-constexpr unsigned LEAF_TREE_MAX_LOG_SUB = 11;
+constexpr unsigned LEAF_TREE_MAX_LOG_SUB = 8;
 TS_HD unsigned leaf_tree_log_r(unsigned log_leaves) {
-    // >= 1024 workgroups where the tree allows it (four resident per CU), then as many in-register
-    // levels as the registers hold
-    return log_leaves >= 21 ? 3 : log_leaves >= 18 ? log_leaves - 18 : 0;
+    return log_leaves >= 20 ? 2 : log_leaves >= 18 ? log_leaves - 18 : 0;
 }
 
 #if defined(__HIPCC__)

@@ -379,10 +379,10 @@ def sharded_block(name: str, ts, env, ctx, dev, watchdog: Watchdog | None, state
       replicated   every rank generates the trace on its device; FRI rounds stay sharded while a slab
                    holds >= 2^12 values (min_local_log 12)
       mll16/mll20  the same with min_local_log 16 / 20: fewer sub-root all-gathers, more replicated
-                   tail rounds (csrc/sharded.cpp)
+                   tail rounds (csrc/sharded.cpp); not in the default list: on the per-rank solo times
+                   they never paid (profiles/r04_config4_shard_stages.json)
       localq       every rank evaluates the quotient on its own cosets: no chunk broadcast, no rank
                    waiting for the owner of the quotient domain (ts_shard_options.local_quotient)
-      colshard     + column-sharded inverse NTT (one more bulk all-gather)
       sliced       row slices in (adds the trace all-gather)
     Every variant reports ms/step, per-rank stage times and the table of its collectives (kind, bytes,
     count, ms) from one extra proof with the stage timers on."""
@@ -444,16 +444,16 @@ def sharded_block(name: str, ts, env, ctx, dev, watchdog: Watchdog | None, state
     def gen():
         return ts.DeviceMatrix.synth_mul(ctx, n, w) if spec["air"] == "mul64" else ts.DeviceMatrix.synth_ext(ctx, n, w)
 
-    variants = os.environ.get("TS_BENCH_SHARD_VARIANTS", "replicated,localq,mll16,mll20,colshard").split(",")
+    variants = os.environ.get("TS_BENCH_SHARD_VARIANTS", "replicated,localq").split(",")
     out["variants"] = {}
     digests = set()
     for var in variants:
         var = var.strip()
-        if var not in ("replicated", "localq", "mll16", "mll20", "colshard", "sliced"):
+        if var not in ("replicated", "localq", "mll16", "mll20", "sliced"):
             continue
         phase(f"{var}: inputs")
         sliced = var == "sliced"
-        kw = dict(trace_replicated=not sliced, column_sharded_inverse=(var == "colshard"),
+        kw = dict(trace_replicated=not sliced,
                   local_quotient=(var == "localq"), min_local_log={"mll16": 16, "mll20": 20}.get(var, 12))
         if sliced:
             full = gen().download()
@@ -692,7 +692,6 @@ def main():
         # every rank generates the whole trace on its own device (ts_trace_*): nothing to exchange
         # for the input; TS_BENCH_SLICED=1 hands out row slices instead (adds the trace all-gather)
         sliced = bool(os.environ.get("TS_BENCH_SLICED"))
-        colshard = bool(os.environ.get("TS_BENCH_COLSHARD"))
         localq = os.environ.get("TS_BENCH_LOCALQ", "1") != "0"  # every rank on its own cosets: no chunk broadcast
         if sliced:
             full = make_trace(ctx).download()
@@ -703,8 +702,7 @@ def main():
 
         def prove_one(i):
             last["proof"] = ts.prove_sharded(config, cair, ts.BfChallenger(), mats[i], pis, comm,
-                                             trace_replicated=not sliced, column_sharded_inverse=colshard,
-                                             local_quotient=localq)
+                                             trace_replicated=not sliced, local_quotient=localq)
     else:
         # one resident trace per step (prove() consumes it); beyond 100 GB of them (288 GB of HBM) the
         # trace of a step is generated on the device at the start of the step instead, inside the
@@ -844,6 +842,9 @@ def main():
                        "quotient_kernel": "hiprtc-specialised" if cair.is_jit else "interpreter",
                        "proof_words": int(len(proof.words))},
             "proofs_per_sec": res["steps_per_sec"],
+            # --mode sharded: which quotient path was timed.  Both return ts_prove's proof for every trace
+            # (the local path falls back to the broadcast one when FRI's final polynomial is not constant)
+            "local_quotient": bool(localq) if sharded else None,
             "timed_proof_verified": verified,
             "timed_proof_sha256": hashlib.sha256(proof.words.tobytes()).hexdigest(),
             "extra": {"windows_ms_per_step": [round(x, 4) for x in wins],

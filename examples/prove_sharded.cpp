@@ -106,6 +106,13 @@ int main(int argc, char** argv) {
             fprintf(stderr, "librccl is not available\n");
             return 2;
         }
+        // a rank that cannot create its context would leave its peers inside ncclCommInitRank for good:
+        // check what every rank needs BEFORE any of them is started
+        const int n_dev = ts_device_count();
+        if (n_dev < G) {
+            fprintf(stderr, "rccl mode needs one device per rank: %d rank(s), %d device(s)\n", G, n_dev);
+            return 2;
+        }
     } else if (ts_comm_local_group_create(G, &group) != TS_OK) {
         return 1;
     }
@@ -125,11 +132,12 @@ int main(int argc, char** argv) {
                 failed++;
                 if (comm.abort) comm.abort(comm.user);  // the peers must fail, not wait
             };
+            // the in-process communicator first: a rank that fails in any later step can then abort the
+            // group, and its peers fail at their first rendezvous instead of waiting out the timeout
+            if (!use_rccl && ts_comm_local_get(group, r, &comm) != TS_OK) return fail("communicator");
             if (ts_ctx_create(use_rccl ? r : 0, &ctx) != TS_OK) return fail("ts_ctx_create");
             if (ts_air_compile(ctx, tape.data(), tape.size(), &air) != TS_OK) return fail("ts_air_compile");
-            if (use_rccl ? ts_comm_rccl_create(ctx, uid, r, G, &comm, &rc) != TS_OK
-                         : ts_comm_local_get(group, r, &comm) != TS_OK)
-                return fail("communicator");
+            if (use_rccl && ts_comm_rccl_create(ctx, uid, r, G, &comm, &rc) != TS_OK) return fail("communicator");
             ts_shard_options opt;
             memset(&opt, 0, sizeof opt);
             opt.trace_replicated = 1;

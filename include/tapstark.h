@@ -50,6 +50,9 @@ typedef struct {
     uint32_t proof_of_work_bits;
 } ts_fri_config;
 
+/* Number of HIP devices this process sees (0 without a GPU or a driver): lets a multi-rank caller
+ * check "one device per rank" before it starts any rank (examples/prove_sharded.cpp). */
+int ts_device_count(void);
 /* ------------------------------------------------------------------ context */
 ts_status ts_ctx_create(int device, ts_ctx** out);
 void ts_ctx_destroy(ts_ctx* ctx);
@@ -72,6 +75,12 @@ ts_status ts_ctx_take_kernel_timings(ts_ctx* ctx, char* buf, size_t cap);
  * (an allocation the pool could not serve inside the capture), out[2] = shapes whose block sizes
  * are known, out[3] = bytes the context's device pool holds.  Diagnostics only. */
 ts_status ts_ctx_graph_stats(ts_ctx* ctx, uint64_t out[4]);
+/* One diagnostic counter of the context by index: 0-3 as ts_ctx_graph_stats; 4 = graph attempts the
+ * pool could not reserve for (the phase ran eagerly); 5 = ts_prove_sharded calls whose local quotient
+ * (ts_shard_options.local_quotient) was redone through the broadcast path because FRI's final
+ * polynomial was not constant, i.e. the trace was invalid (fri/src/prover.rs:129-134).
+ * TS_ERR_INVALID for an unknown index. */
+ts_status ts_ctx_stat(ts_ctx* ctx, int which, uint64_t* out);
 
 /* ------------------------------------------------------------------ matrices */
 /* RowMajorMatrix<Val>::new(values, width): host row-major canonical values -> device */
@@ -295,18 +304,21 @@ typedef struct {
     uint32_t min_local_log;    /* 0 = default (12) */
     uint32_t trace_replicated; /* 1: `trace_rows` is the WHOLE trace on every rank (e.g. made by
                                   ts_trace_* on each device); the trace all-gather is skipped */
-    uint32_t column_sharded_inverse; /* 1: transposes + the per-column stages of the inverse NTT run
-                                  on w/G columns per rank, followed by an all-gather of the
-                                  half-transformed columns */
+    uint32_t column_sharded_inverse; /* ignored since round 5 (kept for layout): the option -- the
+                                  per-column part of the inverse NTT on w/G columns per rank + an
+                                  all-gather of the half-transformed columns, SURVEY.md section 8(e)
+                                  steps 1-2 -- cost more in bulk all-gathers than it saved; the inverse
+                                  transform is replicated on every rank.  The proof never depended on it. */
     uint32_t local_quotient;   /* 1: every rank evaluates the quotient (uni-stark/src/prover.rs:65-80) on
                                   its OWN cosets and derives its slab of the chunk LDEs from that: no rank
                                   waits for the owner of the quotient domain, no chunk broadcast.  Needs
-                                  2^log_blowup / world >= quotient degree (else ignored).  Same proof for
-                                  every trace that satisfies its constraints; for one that does not
-                                  (ts_prove, like a release build of the reference, still hands out a proof,
-                                  which the verifier rejects) constraints / Z_H is no polynomial, the mixed
-                                  chunks are not low-degree and the call ends with TS_ERR_INVARIANT where the
-                                  reference asserts (fri/src/prover.rs:129-134) */
+                                  2^log_blowup / world >= quotient degree (else ignored).  The same proof as
+                                  ts_prove for EVERY trace: for one that violates its constraints (ts_prove,
+                                  like a release build of the reference, still hands out a proof, which the
+                                  verifier rejects) constraints / Z_H is no polynomial, the mixed chunks are
+                                  not low-degree, FRI's final polynomial is not constant
+                                  (fri/src/prover.rs:129-134) -- on every rank alike -- and all ranks redo the
+                                  quotient through the broadcast path (ts_ctx_stat 5 counts it) */
 } ts_shard_options;
 ts_status ts_prove_sharded(ts_ctx* ctx, const ts_fri_config* cfg, const ts_comm* comm,
                            const ts_air* air, ts_challenger* chal, ts_matrix* trace_rows,
@@ -464,6 +476,15 @@ ts_status ts_verify_tap(const ts_fri_config* cfg, const ts_air* air, ts_challeng
  * SHA-256 compressions (kind 2) with no memory traffic, using the library's own arithmetic -- the integer-ALU ceiling bench.py
  * reports beside the achieved rates. */
 ts_status ts_bench_alu(ts_ctx* ctx, int kind, double* units_per_second);
+
+/* Measurement aid: one stage of the path in a sustained loop on resident, arbitrary data, mean
+ * milliseconds per repetition (HIP events on the context's stream).  stage 0: the coset LDE of a
+ * 2^log_n x width matrix (fri/src/two_adic_pcs.rs:233-241: all NTT passes, every coset); stage 1: the
+ * hashing of BFMmcs::commit (basic/src/mmcs/bf_mmcs.rs:22-35) over a 2^(log_n + log_blowup) x width
+ * matrix.  What tools/power_per_stage.py samples clock and power over, per kernel family and per
+ * working-set size. */
+ts_status ts_bench_stage(ts_ctx* ctx, int stage, unsigned log_n, uint32_t width, unsigned log_blowup,
+                         uint32_t reps, double* ms_per_rep);
 
 /* library/ABI version (bumped on any incompatible change) */
 uint32_t ts_abi_version(void);

@@ -17,9 +17,9 @@ voidpp = C.POINTER(C.c_void_p)
 
 # every symbol include/tapstark.h declares (tests check the built library exports all of them)
 ABI_SYMBOLS = [
-    "ts_abi_version", "ts_ctx_create", "ts_ctx_destroy", "ts_last_error", "ts_ctx_synchronize",
+    "ts_abi_version", "ts_device_count", "ts_ctx_create", "ts_ctx_destroy", "ts_last_error", "ts_ctx_synchronize",
     "ts_ctx_stream", "ts_ctx_set_timing", "ts_ctx_take_timings", "ts_ctx_set_kernel_timing",
-    "ts_ctx_take_kernel_timings", "ts_ctx_graph_stats", "ts_matrix_upload",
+    "ts_ctx_take_kernel_timings", "ts_ctx_graph_stats", "ts_ctx_stat", "ts_matrix_upload",
     "ts_matrix_from_device", "ts_trace_fibonacci", "ts_trace_synth_mul", "ts_trace_synth_ext", "ts_matrix_dims", "ts_matrix_download", "ts_matrix_free",
     "ts_air_compile", "ts_air_info", "ts_air_is_jit", "ts_air_free", "ts_pcs_commit", "ts_mmcs_commit", "ts_pcs_data_lde",
     "ts_pcs_data_info", "ts_pcs_data_matrix_info", "ts_pcs_data_digests", "ts_pcs_open_batch", "ts_pcs_data_free",
@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
     "ts_comm_rccl_info",
     "ts_comm_local_group_create", "ts_comm_local_get", "ts_comm_local_group_destroy",
     "ts_comm_local_group_reset", "ts_comm_local_group_set_timeout",
-    "ts_bench_alu", "ts_host_alloc", "ts_host_free", "ts_matrix_upload_async",
+    "ts_bench_alu", "ts_bench_stage", "ts_host_alloc", "ts_host_free", "ts_matrix_upload_async",
     "ts_tapleaf_hash", "ts_tapbranch_hash", "ts_tap_winternitz_lock_script", "ts_tap_leaf_script",
     "ts_taptree_from_scripts", "ts_taptree_combine", "ts_taptree_info", "ts_taptree_leaf_proof",
     "ts_taptree_verify_inclusion", "ts_taptree_free", "ts_tap_mmcs_commit", "ts_tap_mmcs_info",
@@ -182,7 +182,10 @@ def lib() -> C.CDLL:
         u64p = C.POINTER(C.c_uint64)
         szp = C.POINTER(C.c_size_t)
         l.ts_bench_alu.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
+        l.ts_bench_stage.argtypes = [C.c_void_p, C.c_int, C.c_uint, C.c_uint32, C.c_uint, C.c_uint32,
+                                     C.POINTER(C.c_double)]
         l.ts_ctx_graph_stats.argtypes = [C.c_void_p, u64p]
+        l.ts_ctx_stat.argtypes = [C.c_void_p, C.c_int, u64p]
         l.ts_host_alloc.argtypes = [C.c_size_t, voidpp]
         l.ts_host_free.argtypes = [C.c_void_p]
         l.ts_host_free.restype = None

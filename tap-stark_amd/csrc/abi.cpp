@@ -147,6 +147,15 @@ ts_status ts_proof_from_postcard_v(const uint8_t* bytes, size_t n_bytes, int tsp
 
 uint32_t ts_abi_version(void) { return 4; }  // 4: ts_rccl_info.checked (struct grew), ts_ctx_graph_stats
 
+int ts_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
 ts_status ts_ctx_create(int device, ts_ctx** out) {
     if (!out) return TS_ERR_INVALID;
     *out = nullptr;
@@ -212,9 +221,75 @@ ts_status ts_ctx_graph_stats(ts_ctx* ctx, uint64_t out[4]) {
     return TS_OK;
 }
 
+ts_status ts_ctx_stat(ts_ctx* ctx, int which, uint64_t* out) {
+    if (!ctx || !out) return TS_ERR_INVALID;
+    switch (which) {
+    case 0: *out = ctx->ctx.fri_graph_replays; break;
+    case 1: *out = ctx->ctx.fri_graph_fallbacks; break;
+    case 2: *out = ctx->ctx.fri_graph_sizes.size(); break;
+    case 3: *out = ctx->ctx.bytes_reserved; break;
+    case 4: *out = ctx->ctx.fri_graph_reserve_failures; break;
+    case 5: *out = ctx->ctx.local_quotient_fallbacks; break;
+    default: return TS_ERR_INVALID;
+    }
+    return TS_OK;
+}
+
 ts_status ts_bench_alu(ts_ctx* ctx, int kind, double* units_per_second) {
     if (!ctx || !units_per_second) return TS_ERR_INVALID;
     return guard(ctx, [&] { *units_per_second = ts::alu_ceiling(ctx->ctx, kind); });
+}
+
+// One stage of the path in a sustained loop on resident, arbitrary data (measurement aid; the values
+// are whatever the previous repetition left -- valid lazy-range field elements, never checked):
+//   stage 0: coset_lde of a 2^log_n x width matrix (all three NTT passes, every coset)
+//   stage 1: BFMmcs::commit's hashing of a 2^(log_n + log_blowup) x width matrix (leaves + tree)
+// Returns the mean time of a repetition from HIP events on the context's stream.
+ts_status ts_bench_stage(ts_ctx* ctx, int stage, unsigned log_n, uint32_t width, unsigned log_blowup,
+                         uint32_t reps, double* ms_per_rep) {
+    if (!ctx || !ms_per_rep) return TS_ERR_INVALID;
+    return guard(ctx, [&] {
+        ts::Context& c = ctx->ctx;
+        TS_REQUIRE((stage == 0 || stage == 1) && width >= 1 && width <= 256 && reps >= 1 && log_n >= 1 &&
+                       log_n + log_blowup <= 27,
+                   ts::TS_ERR_INVALID, "bench_stage: stage 0 | 1, width 1..256, log_n + log_blowup <= 27");
+        const uint64_t n = 1ull << log_n, N = n << log_blowup;
+        c.ensure_twiddles(log_n + log_blowup);
+        ts::DevBuf<uint32_t> lde(&c, (size_t)width * N), in(&c, stage == 0 ? (size_t)width * n : 1);
+        TS_HIP(hipMemsetAsync(lde.p, 0x11, (size_t)width * N * 4, c.stream));  // 0x11111111 < p
+        if (stage == 0) TS_HIP(hipMemsetAsync(in.p, 0x11, (size_t)width * n * 4, c.stream));
+        ts::DevBuf<uint32_t> tree(&c, stage == 1 ? ts::merkle_total_digests(log_n + log_blowup) * 8 : 1);
+        std::vector<const uint32_t*> cols(width);
+        for (uint32_t k = 0; k < width; k++) cols[k] = lde.p + (uint64_t)k * N;
+        ts::DevBuf<const uint32_t*> d_cols(&c, width);
+        TS_HIP(hipMemcpyAsync(d_cols.p, cols.data(), width * sizeof(const uint32_t*), hipMemcpyHostToDevice, c.stream));
+        c.sync();
+        ts::LeafMats lm;
+        memset(&lm, 0, sizeof lm);
+        lm.n_mats = 1;
+        lm.d[0] = lde.p;
+        lm.col_stride[0] = N;
+        lm.width[0] = width;
+        lm.total_width = width;
+        lm.cols = d_cols.p;
+        auto once = [&] {
+            if (stage == 0) ts::coset_lde(c, in.p, n, width, log_n, log_blowup, ts::GENERATOR, lde.p, N);
+            else ts::launch_commit_tree(c, lm, log_n + log_blowup, tree.p);
+        };
+        once();  // tables, first-touch
+        hipEvent_t e0, e1;
+        TS_HIP(hipEventCreate(&e0));
+        TS_HIP(hipEventCreate(&e1));
+        TS_HIP(hipEventRecord(e0, c.stream));
+        for (uint32_t r = 0; r < reps; r++) once();
+        TS_HIP(hipEventRecord(e1, c.stream));
+        c.sync();
+        float ms = 0;
+        TS_HIP(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        *ms_per_rep = (double)ms / reps;
+    });
 }
 
 // pinned host memory for traces handed over as host buffers (PCIe at full rate, truly async copies)
@@ -721,7 +796,6 @@ ts_status ts_prove_sharded(ts_ctx* ctx, const ts_fri_config* cfg, const ts_comm*
             opt.min_local_log = options->min_local_log;
         }
         if (options) opt.trace_replicated = options->trace_replicated != 0;
-        if (options) opt.column_sharded_inverse = options->column_sharded_inverse != 0;
         if (options) opt.local_quotient = options->local_quotient != 0;
         ts::StageTimer t(&ctx->ctx, "prove");
         std::vector<uint32_t> proof;

@@ -29,7 +29,8 @@ Context::~Context() {
     if (d_twiddle_fwd) (void)hipFree(d_twiddle_fwd);
     if (d_twiddle_inv) (void)hipFree(d_twiddle_inv);
     for (auto& t : scale_tables) (void)hipFree(t.d);
-    if (d_selectors) (void)hipFree(d_selectors);
+    for (auto& t : sel_tables)
+        if (t.d) (void)hipFree(t.d);
     if (d_ticket) (void)hipFree(d_ticket);
     for (auto& kv : free_blocks) (void)hipFree(kv.second);
     for (auto& kv : live_blocks) (void)hipFree(kv.first);

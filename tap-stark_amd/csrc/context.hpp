@@ -18,6 +18,12 @@ struct Error : std::runtime_error {
     Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
 };
 
+// fri/src/prover.rs:129-134 `assert_eq!(x, final_poly)`: its own type so that a caller that can take
+// another route (prove_sharded's local quotient) can tell it from every other invariant
+struct FinalPolyNotConstant : Error {
+    explicit FinalPolyNotConstant(const std::string& m) : Error(5 /* TS_ERR_INVARIANT */, m) {}
+};
+
 // status codes of the C ABI (include/tapstark.h)
 enum : int {
     TS_OK = 0,
@@ -72,9 +78,17 @@ struct Context {
     uint64_t scale_clock = 0;
     // the last selector table (is_first | is_last | is_transition on the quotient domain,
     // quotient.hip): a function of (log_n, log_qd) only, so repeated proofs of one shape reuse it
-    uint32_t* d_selectors = nullptr;
-    unsigned sel_log_n = ~0u, sel_log_qd = ~0u;
-    uint32_t sel_shift = 0;
+    // selector tables (quotient.hip) by (log_n, log_qd, domain shift): two entries, so that a context
+    // that alternates between the reference shift (prove, the broadcast path) and a rank's own
+    // (local quotient) rebuilds neither -- a rebuild is a stream sync, a hipFree and a hipMalloc
+    struct SelTable {
+        uint32_t* d = nullptr;
+        unsigned log_n = ~0u, log_qd = ~0u;
+        uint32_t shift = 0;
+        uint64_t last_use = 0;
+    };
+    SelTable sel_tables[2];
+    uint64_t sel_clock = 0;
 
     // zero-initialised words (17 lines of 64 bytes) the "last workgroup done" kernels count in
     // (merkle.hip); each kernel leaves them at zero, and launches on the one stream run in order
@@ -122,6 +136,8 @@ struct Context {
     std::vector<size_t>* alloc_log = nullptr;
     std::map<std::vector<uint32_t>, std::vector<size_t>> fri_graph_sizes;  // shape key -> block sizes
     uint64_t fri_graph_replays = 0, fri_graph_fallbacks = 0;
+    uint64_t fri_graph_reserve_failures = 0;  // Context::reserve refused: the phase ran eagerly
+    uint64_t local_quotient_fallbacks = 0;    // prove_sharded: local quotient -> broadcast path (invalid trace)
     bool reserve(const std::vector<size_t>& sizes);
     // ends the deferral: blocks in `revive` stay live (returned: which of them had been parked),
     // every other parked block goes back to the free list

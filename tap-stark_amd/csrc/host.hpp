@@ -172,18 +172,14 @@ struct ShardOptions {
     // true: every rank already holds the WHOLE trace (e.g. generated on each device by
     // ts_trace_*): the one bulk exchange, the all-gather of the trace rows, is skipped
     bool trace_replicated = false;
-    // true: transposes and the contiguous stages of the inverse NTT are done for w/G columns per
-    // rank and the half-transformed columns all-gathered (n w 4 bytes in all), instead of every
-    // rank repeating them for every column.  Trades ~1/4 of a rank's LDE arithmetic for one more
-    // bulk exchange: see DESIGN.md section 6 for when that pays.
-    bool column_sharded_inverse = false;
     // true: every rank evaluates the quotient on its OWN cosets and derives its slab of the chunk
     // LDEs from that (sharded.cpp "local quotient"): no rank waits for the owner of the quotient
     // domain, no chunk broadcast.  Needs 2^log_blowup / G >= quotient degree (else the broadcast
-    // path runs).  Identical proofs for every trace that satisfies its constraints; for a trace that
-    // does not (which a release build of the reference proves without complaint, prover.rs:40-41)
-    // constraints / Z_H is not a polynomial, the mixed chunks are not low-degree and FRI's
-    // final-polynomial assertion (fri/src/prover.rs:129-134) ends the proof with TS_ERR_INVARIANT.
+    // path runs).  The same proof as ts_prove for EVERY trace: for one that violates its constraints
+    // (which a release build of the reference proves without complaint, prover.rs:40-41) constraints /
+    // Z_H is not a polynomial, the mixed chunks are not low-degree, FRI's final polynomial is not
+    // constant (fri/src/prover.rs:129-134) -- and that sends every rank back through the broadcast
+    // path (sharded.cpp; counted in Context::local_quotient_fallbacks).
     bool local_quotient = false;
 };
 // rank g owns the bit-reversed LDE rows [g N/G, (g+1) N/G) (whole cosets,

@@ -45,14 +45,9 @@ void launch_transpose_to_row_major(Context& ctx, const uint32_t* src, uint64_t c
 //   out: out[c][beta*n + t] = p_c(shift * w_N^bitrev(beta*n+t)),  N = n << log_blowup
 // With a coset range (beta0, n_beta > 0) only the row blocks beta0 .. beta0+n_beta-1 are produced,
 // at out[c][(beta - beta0)*n + t]: the slab of a rank that owns those cosets (sharded prover).
-// phase: LDE_ALL, or the two halves a sharded prover runs either side of its all-gather of the
-// half-transformed columns: LDE_INVERSE_CONTIG (the contiguous stages of the inverse, per column,
-// in place in `evals`; a no-op for n <= 4096) and LDE_REST (everything else).
-enum LdePhase { LDE_ALL = 0, LDE_INVERSE_CONTIG = 1, LDE_REST = 2 };
 void coset_lde(Context& ctx, uint32_t* evals, uint64_t in_col_stride, uint32_t ncols, unsigned log_n,
                unsigned log_blowup, uint32_t shift, uint32_t* out, uint64_t out_col_stride,
-               uint32_t beta0 = 0, uint32_t n_beta = 0, LdePhase phase = LDE_ALL,
-               bool first_round_done = false);
+               uint32_t beta0 = 0, uint32_t n_beta = 0, bool first_round_done = false);
 
 // ---- merkle.hip ------------------------------------------------------------------------------
 constexpr int MAX_BATCH_MATS = 64;

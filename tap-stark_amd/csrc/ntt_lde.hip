@@ -656,7 +656,7 @@ bool launch_transpose_bitrev_r16(Context& ctx, const uint32_t* src, uint32_t* ds
 
 void coset_lde(Context& ctx, uint32_t* evals, uint64_t in_col_stride, uint32_t ncols, unsigned log_n,
                unsigned log_blowup, uint32_t shift, uint32_t* out, uint64_t out_col_stride,
-               uint32_t beta0, uint32_t n_beta, LdePhase phase, bool first_round_done) {
+               uint32_t beta0, uint32_t n_beta, bool first_round_done) {
     if (ncols == 0) return;
     TS_REQUIRE(log_n + log_blowup <= 27, TS_ERR_INVALID, "coset_lde: log_n + log_blowup > 27");
     TS_REQUIRE(ncols >= 1 && ncols <= 65535, TS_ERR_INVALID, "coset_lde: bad column count");
@@ -692,9 +692,8 @@ void coset_lde(Context& ctx, uint32_t* evals, uint64_t in_col_stride, uint32_t n
         // the vectorised chunk loads need 16-byte aligned columns
         TS_REQUIRE(in_col_stride % 4 == 0 && out_col_stride % 4 == 0, TS_ERR_INVALID,
                    "coset_lde: column strides must be multiples of 4 elements");
-        if (phase != LDE_REST) {
-            // (stage names: the sharded prover reports where a rank's time goes; this part is per
-            // column, so it can be sharded by columns -- ShardOptions::column_sharded_inverse)
+        {
+            // (stage names: the sharded prover reports where a rank's time goes)
             StageTimer t(&ctx, "lde: inverse NTT, contiguous stages");
             const dim3 g(1u << sA, ncols);
 #define TS_INTT(LMV)                                                                                          \
@@ -709,10 +708,6 @@ void coset_lde(Context& ctx, uint32_t* evals, uint64_t in_col_stride, uint32_t n
             else if (LM == 13) TS_INTT(13);
             else TS_INTT(14);
 #undef TS_INTT
-        }
-        if (phase == LDE_INVERSE_CONTIG) {
-            TS_HIP(hipGetLastError());
-            return;
         }
         StageTimer t_rest(&ctx, "lde: strided pass + forward NTT of the owned cosets");
         const dim3 grid(1u << (LM - log_T), ncols);
@@ -754,7 +749,7 @@ void coset_lde(Context& ctx, uint32_t* evals, uint64_t in_col_stride, uint32_t n
         else
             TS_LAUNCH(ctx, (k_lde_fwd_contig<14, 4>), dim3(gf.x / 4, gf.y, gf.z), dim3(chunk_threads(14)), 0, out,
                       out_col_stride, log_n, W);
-    } else if (phase != LDE_INVERSE_CONTIG) {
+    } else {
         TS_LAUNCH(ctx, k_lde_mid<0>, dim3(1, ncols), dim3(NT_MID), 0, (const uint32_t*)evals,
                   in_col_stride, out, out_col_stride, log_n, log_n, 0u, 0u, beta0, n_beta, W, Winv, scale);
     }

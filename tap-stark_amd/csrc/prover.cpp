@@ -165,7 +165,7 @@ std::unique_ptr<PcsData> TwoAdicFriPcs::commit(std::vector<DeviceMatrix>& evals,
             DevBuf<uint32_t> lde(&ctx_, (size_t)m.width * Ni);
             // two_adic_pcs.rs:235: shift = Val::generator() / domain.shift
             const uint32_t shift = mul(GENERATOR, inv_canon(domain_shifts[i]));
-            coset_lde(ctx_, ev, n, m.width, log_n, fri_.log_blowup, shift, lde.p, Ni, 0, 0, LDE_ALL, r16);
+            coset_lde(ctx_, ev, n, m.width, log_n, fri_.log_blowup, shift, lde.p, Ni, 0, 0, r16);
             ColMat cm;
             cm.d = lde.p;
             cm.height = Ni;
@@ -210,20 +210,25 @@ std::vector<DeviceMatrix> TwoAdicFriPcs::quotient_chunks_slab(const ColMat& lde_
     // whole cosets only: `next` (natural index + qd) stays inside a coset of H_n
     TS_REQUIRE(row_begin % n == 0 && row_end % n == 0, TS_ERR_INVALID, "quotient: slab must hold whole cosets");
 
-    // selectors depend on the shape only: kept in the context between proofs
-    if (ctx_.sel_log_n != log_n || ctx_.sel_log_qd != lqd || ctx_.sel_shift != domain_shift) {
-        ctx_.sync();  // an earlier launch may still read the old table
-        if (ctx_.d_selectors) (void)hipFree(ctx_.d_selectors);
-        ctx_.d_selectors = nullptr;
-        ctx_.sel_log_n = ctx_.sel_log_qd = ~0u;
-        TS_HIP(hipMalloc((void**)&ctx_.d_selectors, 3 * qn * sizeof(uint32_t)));
-        launch_selectors(ctx_, log_n, lqd, ctx_.d_selectors, ctx_.d_selectors + qn, ctx_.d_selectors + 2 * qn,
-                         domain_shift);
-        ctx_.sel_log_n = log_n;
-        ctx_.sel_log_qd = lqd;
-        ctx_.sel_shift = domain_shift;
+    // selectors depend on the shape only: kept in the context between proofs (two tables, LRU)
+    Context::SelTable* st = nullptr;
+    for (auto& t : ctx_.sel_tables)
+        if (t.d && t.log_n == log_n && t.log_qd == lqd && t.shift == domain_shift) st = &t;
+    if (!st) {
+        st = ctx_.sel_tables[0].last_use <= ctx_.sel_tables[1].last_use ? &ctx_.sel_tables[0] : &ctx_.sel_tables[1];
+        if (st->d) {
+            ctx_.sync();  // an earlier launch may still read the old table
+            (void)hipFree(st->d);
+            st->d = nullptr;
+        }
+        TS_HIP(hipMalloc((void**)&st->d, 3 * qn * sizeof(uint32_t)));
+        launch_selectors(ctx_, log_n, lqd, st->d, st->d + qn, st->d + 2 * qn, domain_shift);
+        st->log_n = log_n;
+        st->log_qd = lqd;
+        st->shift = domain_shift;
     }
-    struct { uint32_t* p; } sel{ctx_.d_selectors};
+    st->last_use = ++ctx_.sel_clock;
+    struct { uint32_t* p; } sel{st->d};
 
     // constants / public values in Montgomery form
     std::vector<uint32_t> consts(std::max<size_t>(air.const_canonical.size(), 1), 0);
@@ -530,8 +535,8 @@ Ef fri_commit_finish(Context& ctx, const FriConfig& fri, BfChallenger& challenge
     for (uint32_t r = 0; r < R_total; r++) memcpy(st.rounds[r].root, &roots[8 * (size_t)r], 32);
     const Ef final_poly = fin[0];
     for (auto& x : fin)
-        TS_REQUIRE(ef_eq(x, final_poly), TS_ERR_INVARIANT,
-                   "FRI: final polynomial is not constant (assert_eq!(x, final_poly))");
+        if (!ef_eq(x, final_poly))
+            throw FinalPolyNotConstant("FRI: final polynomial is not constant (assert_eq!(x, final_poly))");
     return final_poly;
 }
 
@@ -576,7 +581,8 @@ void TwoAdicFriPcs::fri_prove(std::vector<DevBuf<Ef>>& inputs, const std::vector
         // before a capture the pool is made to hold all of them at once (Context::reserve); and an
         // allocation that still misses inside the capture (Context::CaptureMiss: no HIP call was made)
         // ends the capture and re-runs the phase eagerly from the untouched inputs.
-        // TS_FRI_GRAPH=2 skips the reservation: the test hook that exercises that fall-back.
+        // TS_FRI_GRAPH=2 skips the reservation: the test hook that exercises that fall-back; =3 treats the
+        // replay as failed after a good capture (instantiate / launch failure: the same fall-back).
         const char* genv = getenv("TS_FRI_GRAPH");
         const int want_graph = (genv && !ctx.timing && !ctx.kernel_timing) ? atoi(genv) : 0;
         const uint64_t len0 = 1ull << log_max_height;
@@ -597,7 +603,9 @@ void TwoAdicFriPcs::fri_prove(std::vector<DevBuf<Ef>>& inputs, const std::vector
                 ctx.alloc_log = nullptr;
                 ctx.fri_graph_sizes[key] = std::move(sizes);
                 done = true;
-            } else if (want_graph == 2 || ctx.reserve(known->second)) {
+            } else if (want_graph != 2 && !ctx.reserve(known->second)) {
+                ctx.fri_graph_reserve_failures++;  // hipMalloc refused the reservation: eager, and on the record
+            } else {
                 hipGraph_t g = nullptr;
                 bool miss = false;
                 TS_HIP(hipStreamBeginCapture(ctx.stream, hipStreamCaptureModeThreadLocal));
@@ -614,12 +622,41 @@ void TwoAdicFriPcs::fri_prove(std::vector<DevBuf<Ef>>& inputs, const std::vector
                     throw;
                 }
                 const hipError_t ec = hipStreamEndCapture(ctx.stream, &g);
-                if (miss || ec != hipSuccess) {
-                    // nothing captured has run.  Drop the half-built round state while frees are still
-                    // parked, take the input vectors back (the rounds had moved some of them into the
-                    // state), return every other parked block to the pool, then run eagerly.
+                // Nothing captured has run yet.  A capture miss, a failed end-of-capture, and a graph
+                // that cannot be instantiated / updated / launched (e.g. out of memory on a new shape)
+                // all take the same way out: drop the graph and the half-built round state while frees
+                // are still parked, take the input vectors back (the rounds had moved some of them into
+                // the state), return every other parked block to the pool, then run eagerly.
+                bool replayed = false;
+                if (!miss && ec == hipSuccess) {
+                    bool ready = false;
+                    if (ctx.fri_graph_exec) {
+                        hipGraphNode_t err_node = nullptr;
+                        hipGraphExecUpdateResult res;
+                        ready = hipGraphExecUpdate(ctx.fri_graph_exec, g, &err_node, &res) == hipSuccess &&
+                                res == hipGraphExecUpdateSuccess;
+                        if (!ready) {
+                            (void)hipGetLastError();
+                            (void)hipGraphExecDestroy(ctx.fri_graph_exec);
+                            ctx.fri_graph_exec = nullptr;
+                        }
+                    }
+                    if (!ready) {
+                        ready = hipGraphInstantiate(&ctx.fri_graph_exec, g, nullptr, nullptr, 0) == hipSuccess;
+                        if (!ready) ctx.fri_graph_exec = nullptr;
+                    }
+                    // TS_FRI_GRAPH=3: the test hook for this branch (pretend the launch failed)
+                    if (ready && want_graph != 3)
+                        replayed = hipGraphLaunch(ctx.fri_graph_exec, ctx.stream) == hipSuccess;
+                }
+                if (g) (void)hipGraphDestroy(g);
+                if (replayed) {
+                    ctx.capturing = false;
+                    ctx.flush_deferred({});
+                    ctx.fri_graph_replays++;
+                    done = true;
+                } else {
                     (void)hipGetLastError();
-                    if (g) (void)hipGraphDestroy(g);
                     st.rounds.clear();
                     st.keep_vecs.clear();
                     st.keep_trees.clear();
@@ -635,26 +672,6 @@ void TwoAdicFriPcs::fri_prove(std::vector<DevBuf<Ef>>& inputs, const std::vector
                                 else inputs[k] = std::move(b);
                             }
                     ctx.fri_graph_fallbacks++;
-                } else {
-                    ctx.capturing = false;
-                    ctx.flush_deferred({});
-                    bool ready = false;
-                    if (ctx.fri_graph_exec) {
-                        hipGraphNode_t err_node = nullptr;
-                        hipGraphExecUpdateResult res;
-                        ready = hipGraphExecUpdate(ctx.fri_graph_exec, g, &err_node, &res) == hipSuccess &&
-                                res == hipGraphExecUpdateSuccess;
-                        if (!ready) {
-                            (void)hipGetLastError();
-                            (void)hipGraphExecDestroy(ctx.fri_graph_exec);
-                            ctx.fri_graph_exec = nullptr;
-                        }
-                    }
-                    if (!ready) TS_HIP(hipGraphInstantiate(&ctx.fri_graph_exec, g, nullptr, nullptr, 0));
-                    TS_HIP(hipGraphLaunch(ctx.fri_graph_exec, ctx.stream));
-                    (void)hipGraphDestroy(g);
-                    ctx.fri_graph_replays++;
-                    done = true;
                 }
             }
         }

@@ -32,7 +32,6 @@ struct Shard {
     const Comm& comm;
     uint32_t G, rank, log_G;
     uint32_t cosets, beta0;  // cosets per rank, first owned coset
-    bool column_sharded_inverse = false;
 };
 
 // what one rank keeps of a committed batch
@@ -101,39 +100,13 @@ std::unique_ptr<ShardedData> commit_sharded(Shard& sh, std::vector<DeviceMatrix>
             uint32_t* ev = m.buf.p;
             DevBuf<uint32_t> lde(&ctx, (size_t)m.width * rows);
             const uint32_t shift = mul(GENERATOR, inv_canon(domain_shifts[i]));  // two_adic_pcs.rs:235
-            // (not for the per-rank matrices of the local quotient: there every rank transforms its OWN
-            // evaluations, there is nothing to share)
-            if (sh.column_sharded_inverse && !mix_local && sh.G > 1 && log_n > 12) {
-                // the per-column part of the inverse transform (the
-                // transpose and the contiguous stages) is done for w/G columns per rank, then the
-                // half-transformed columns are all-gathered; the strided pass and the forward
-                // transforms of the owned cosets follow as usual.  Rank g's columns are
-                // [g cpr, (g+1) cpr) of a matrix padded to G cpr columns, so the gathered buffer IS
-                // the column-major matrix.
-                const uint32_t cpr = (m.width + sh.G - 1) / sh.G;
-                const uint32_t c0 = std::min(m.width, sh.rank * cpr), c1 = std::min(m.width, c0 + cpr);
-                DevBuf<uint32_t> mine(&ctx, (size_t)cpr * n);
-                {
-                    StageTimer t(&ctx, "lde: transpose + inverse contiguous stages of the rank's columns");
-                    bool r16 = false;
-                    if (m.layout == DeviceMatrix::ROW_MAJOR) {
-                        r16 = launch_transpose_bitrev_r16(ctx, m.buf.p + c0, mine.p, log_n, c1 - c0, n, m.width);
-                        if (!r16) launch_transpose_bitrev(ctx, m.buf.p + c0, mine.p, log_n, c1 - c0, n, m.width);
-                    } else if (c1 > c0) {
-                        TS_HIP(hipMemcpyAsync(mine.p, m.buf.p + (size_t)c0 * n, (size_t)(c1 - c0) * n * 4,
-                                              hipMemcpyDeviceToDevice, ctx.stream));
-                    }
-                    coset_lde(ctx, mine.p, n, c1 - c0, log_n, sh.fri.log_blowup, shift, nullptr, rows, sh.beta0,
-                              sh.cosets, LDE_INVERSE_CONTIG, r16);
-                }
-                colmajor = DevBuf<uint32_t>(&ctx, (size_t)cpr * sh.G * n);
-                {
-                    StageTimer t(&ctx, "all-gather half-transformed columns");
-                    coll_all_gather(ctx, sh.comm, "half-transformed columns", mine.p, colmajor.p, (size_t)cpr * n * 4);
-                }
-                coset_lde(ctx, colmajor.p, n, m.width, log_n, sh.fri.log_blowup, shift, lde.p, rows, sh.beta0,
-                          sh.cosets, LDE_REST);
-            } else {
+            // The inverse transform is replicated: every rank transposes and inverts every column, then
+            // runs the forward transforms of its own cosets.  (Rounds 2-4 carried an option that did the
+            // per-column part of the inverse for w/G columns per rank and all-gathered the
+            // half-transformed columns, SURVEY.md section 8(e) steps 1-2: it took 0.5 / 0.35 ms off the
+            // compute path of configs 4 / 5 at G = 8 and added 1.5 / 0.8 ms of bulk all-gathers by the link
+            // model -- removed in round 5, numbers in HISTORY.md.)
+            {
                 bool r16 = false;
                 if (m.layout == DeviceMatrix::ROW_MAJOR) {
                     StageTimer t(&ctx, "lde: transpose (every column on every rank)");
@@ -143,7 +116,7 @@ std::unique_ptr<ShardedData> commit_sharded(Shard& sh, std::vector<DeviceMatrix>
                     ev = colmajor.p;
                 }
                 coset_lde(ctx, ev, n, m.width, log_n, sh.fri.log_blowup, shift, lde.p, rows, sh.beta0, sh.cosets,
-                          LDE_ALL, r16);
+                          r16);
             }
             ColMat cm;
             cm.d = lde.p;
@@ -283,7 +256,7 @@ std::vector<uint32_t> prove_sharded(TwoAdicFriPcs& pcs, const Comm& comm, const 
                "prove_sharded: the number of ranks must be a power of two <= 2^log_blowup (whole "
                "cosets per rank); run independent proofs per GPU otherwise");
     Shard sh{ctx, fri, comm, G, (uint32_t)comm.rank, log2_strict(G), fri.blowup() / G,
-             (uint32_t)comm.rank * (fri.blowup() / G), opt.column_sharded_inverse};
+             (uint32_t)comm.rank * (fri.blowup() / G)};
     TS_REQUIRE(trace_rows.width == air.width, TS_ERR_INVALID, "prove: trace width != AIR width");
     TS_REQUIRE(trace_rows.layout == DeviceMatrix::ROW_MAJOR && trace_rows.buf.p, TS_ERR_INVALID,
                "prove_sharded: the trace slice must be an uploaded row-major matrix");
@@ -326,12 +299,21 @@ std::vector<uint32_t> prove_sharded(TwoAdicFriPcs& pcs, const Comm& comm, const 
     challenger.observe_commitment(trace_data->root);
     const Ef alpha = challenger.sample();
 
+    // Everything after the trace commitment, with the quotient made locally or broadcast.  The local
+    // path is exact whenever constraints / Z_H is a polynomial (every valid trace); for an invalid
+    // trace its mixed chunk LDEs are not low-degree and FRI's final polynomial is not constant -- on
+    // every rank alike, the final vector being replicated -- where ts_prove and the broadcast path
+    // (and a release build of the reference, uni-stark/src/prover.rs:40-41) still hand out a proof
+    // for the verifier to reject.  So that the call stays a drop-in for EVERY trace, that one failure
+    // sends all ranks back to the state after alpha and through the broadcast path.
+    const BfChallenger after_alpha = challenger;
+    auto rest = [&](bool local_quotient) -> std::vector<uint32_t> {
     // :65-80 the quotient domain is the first qd cosets: chunk c = coset bitrev(c), computed by the
     // rank that owns that coset, then broadcast (exchange 2)
     std::vector<uint32_t> qshifts(qd);
     const uint32_t gq = two_adic_generator(log_degree + lqd);
     std::unique_ptr<ShardedData> quotient_data;
-    if (opt.local_quotient && sh.cosets >= qd) {
+    if (local_quotient) {
         // every rank on its own cosets ("local quotient" above); with qd = 1 the values on the rank's
         // first coset determine q itself and the mix is the identity
         const uint32_t s_g =
@@ -561,6 +543,18 @@ std::vector<uint32_t> prove_sharded(TwoAdicFriPcs& pcs, const Comm& comm, const 
     pf.insert(pf.end(), final_poly.c, final_poly.c + 4);
     pf.push_back(pow_witness);
     return pf;
+    };  // rest
+
+    if (opt.local_quotient && sh.cosets >= qd) {
+        try {
+            return rest(true);
+        } catch (const FinalPolyNotConstant&) {
+            ctx.sync();  // the failed attempt's launches are done before its buffers go back to the pool
+            ctx.local_quotient_fallbacks++;
+            challenger = after_alpha;
+        }
+    }
+    return rest(false);
 }
 
 }  // namespace ts

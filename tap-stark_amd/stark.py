@@ -62,6 +62,12 @@ class Context:
         self.check(self._l.ts_bench_alu(self.h, kind, C.byref(r)))
         return float(r.value)
 
+    def bench_stage(self, stage: int, log_n: int, width: int, log_blowup: int, reps: int) -> float:
+        """Mean ms of one repetition of a stage on resident data: 0 = coset LDE, 1 = Merkle hashing."""
+        r = C.c_double()
+        self.check(self._l.ts_bench_stage(self.h, stage, log_n, width, log_blowup, reps, C.byref(r)))
+        return float(r.value)
+
     def set_timing(self, enabled: bool):
         self.check(self._l.ts_ctx_set_timing(self.h, int(enabled)))
 
@@ -95,7 +101,13 @@ class Context:
         out = (C.c_uint64 * 4)()
         self.check(self._l.ts_ctx_graph_stats(self.h, out))
         return {"replays": int(out[0]), "fallbacks": int(out[1]), "shapes": int(out[2]),
-                "pool_bytes": int(out[3])}
+                "pool_bytes": int(out[3]), "reserve_failures": self.stat(4)}
+
+    def stat(self, which: int) -> int:
+        """``ts_ctx_stat``: 0-3 as graph_stats, 4 graph reservations refused, 5 local-quotient fall-backs."""
+        v = C.c_uint64()
+        self.check(self._l.ts_ctx_stat(self.h, which, C.byref(v)))
+        return int(v.value)
 
     def close(self):
         if self.h:
@@ -686,15 +698,16 @@ def prove(config: StarkConfig, air, challenger: BfChallenger, trace, public_valu
 
 def prove_sharded(config: StarkConfig, air, challenger: BfChallenger, trace_rows, public_values,
                   comm, min_local_log: int = 0, trace_replicated: bool = False,
-                  column_sharded_inverse: bool = False, local_quotient: bool = False) -> Proof:
+                  local_quotient: bool = False) -> Proof:
     """One proof over ``comm.world`` GPUs (``ts_prove_sharded``).
 
     Every rank calls this with its own context, a challenger in the same state and its row slice
     ``trace_rows`` = natural rows [g n/G, (g+1) n/G) of the trace; every rank gets the whole proof,
     bit-identical to :func:`prove` on the whole trace.  ``comm`` is a ``dist.TorchComm``.
     ``trace_replicated``: ``trace_rows`` is the whole trace on every rank (no all-gather of it).
-    ``local_quotient``: every rank computes the quotient on its own cosets (no chunk broadcast; valid
-    traces only -- ``ts_shard_options.local_quotient`` in include/tapstark.h).
+    ``local_quotient``: every rank computes the quotient on its own cosets (no chunk broadcast; for a
+    trace that violates its constraints all ranks fall back to the broadcast path, so the proof is
+    :func:`prove`'s for every trace -- ``ts_shard_options.local_quotient`` in include/tapstark.h).
     """
     pcs = config.pcs
     ctx = pcs.ctx
@@ -715,7 +728,7 @@ def prove_sharded(config: StarkConfig, air, challenger: BfChallenger, trace_rows
     n_words = C.c_size_t()
     cfg = pcs.fri._c()
     pis_p = _p(pis) if len(pis) else None
-    opts = _lib.ShardOptionsC(min_local_log, int(trace_replicated), int(column_sharded_inverse),
+    opts = _lib.ShardOptionsC(min_local_log, int(trace_replicated), 0,
                               int(local_quotient))
     rc = ctx._l.ts_prove_sharded(ctx.h, C.byref(cfg), C.byref(comm.c), air.h, challenger.h,
                                  trace_rows.h, pis_p, len(pis), C.byref(opts), _p(out), cap,

@@ -102,8 +102,7 @@ def test_full_size_sharded_proof_equals_oracle_digests(ctx, orc, name, G, localq
             c = ts.Context(0)
             conf = ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(*cfg), c))
             p = ts.prove_sharded(conf, ts.CompiledAir(c, tape), ts.BfChallenger(), device_trace(c, name, n),
-                                 [], group.comm(r), trace_replicated=True,
-                                 column_sharded_inverse=(name == "config5" and not localq), local_quotient=localq)
+                                 [], group.comm(r), trace_replicated=True, local_quotient=localq)
             proofs[r] = p.words
         except BaseException as e:  # noqa: BLE001
             errors[r] = e

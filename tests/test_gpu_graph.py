@@ -19,7 +19,7 @@ def cases(log_n):
             ("fib", FibonacciAir(), fib, fibonacci_public_values(fib))]
 
 
-@pytest.mark.parametrize("knob,log_n", [("1", 16), ("2", 16), ("1", 20)])
+@pytest.mark.parametrize("knob,log_n", [("1", 16), ("2", 16), ("3", 16), ("1", 20)])
 def test_graph_knob_same_context_two_shapes(monkeypatch, knob, log_n):
     from tapstark_amd.build import build
 
@@ -48,8 +48,11 @@ def test_graph_knob_same_context_two_shapes(monkeypatch, knob, log_n):
     assert st["shapes"] == 1
     if knob == "1":
         assert st["replays"] == 8 and st["fallbacks"] == 0, st
-    else:  # no reservation: parked frees starve the capture, the eager fall-back must take over
+    elif knob == "2":  # no reservation: parked frees starve the capture, the eager fall-back must take over
         assert st["replays"] + st["fallbacks"] == 8 and st["fallbacks"] >= 1, st
+    else:  # a good capture whose replay "fails" (instantiate / launch error): the same fall-back, every time
+        assert st["replays"] == 0 and st["fallbacks"] == 8, st
+    assert st["reserve_failures"] == 0
     # another blowup on the same context: a new shape, recorded first, then replayed
     conf3 = ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(3, 9, 8), ctx))
     name, air, trace, pis = cases(10)[0]

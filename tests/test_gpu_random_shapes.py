@@ -75,9 +75,8 @@ def test_random_shape_bit_identical(ctx, orc, name, kind, w, log_n, cfg, seed):
 # ------------------------------------------------------------------ the sharded prover, option sweep
 def _sharded_cases():
     """Seeded sweep of ts_prove_sharded: world size, slab shape and EVERY combination of its options
-    (row-sliced / replicated input, column-sharded inverse, local quotient, min_local_log) -- the
-    combination local_quotient + column_sharded_inverse at n > 4096 was wrong until a soak run met it
-    (profiles/r04_soak.txt).  TS_RANDOM_SHARDED / TS_RANDOM_SEED widen it."""
+    (row-sliced / replicated input, local quotient, min_local_log); a soak run of this kind found
+    round 4's only bug (profiles/r04_soak.txt).  TS_RANDOM_SHARDED / TS_RANDOM_SEED widen it."""
     import os
 
     rng = np.random.default_rng(int(os.environ.get("TS_RANDOM_SEED", "20240607")) + 1)
@@ -93,7 +92,7 @@ def _sharded_cases():
         w = int(rng.integers(3, 70)) if kind == "mul" else (int(rng.choice([13, 25, 37])) if kind == "ext" else 2)
         if kind == "pow":
             w, log_n = pow_k, min(log_n, 12)  # (the width field carries the degree; the trace is built with Python integers)
-        opts = dict(trace_replicated=bool(rng.integers(0, 2)), column_sharded_inverse=bool(rng.integers(0, 2)),
+        opts = dict(trace_replicated=bool(rng.integers(0, 2)), reserved=bool(rng.integers(0, 2)),  # (keeps the seeded stream of round 4)
                     local_quotient=bool(rng.integers(0, 2)), min_local_log=int(rng.choice([1, 3, 6, 12])))
         tag = "".join(k[0] for k, v in opts.items() if v is True) or "-"
         out.append((f"{i}-{kind}{w}-2p{log_n}-b{b}-G{G}-{tag}-m{opts['min_local_log']}", kind, w, log_n,
@@ -158,7 +157,8 @@ def test_random_sharded_options_bit_identical(ctx, name, kind, w, log_n, cfg, G,
             conf = ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(*cfg), c))
             rows = trace if opts["trace_replicated"] else trace[r * n // G:(r + 1) * n // G]
             chal = ts.BfChallenger()
-            p = ts.prove_sharded(conf, ts.CompiledAir(c, tape), chal, np.ascontiguousarray(rows), pis, group.comm(r), **opts)
+            p = ts.prove_sharded(conf, ts.CompiledAir(c, tape), chal, np.ascontiguousarray(rows), pis, group.comm(r),
+                                 **{k: v for k, v in opts.items() if k != "reserved"})
             res[r] = (p.words, chal.sample_bits(24))
         except BaseException as e:  # noqa: BLE001
             errs[r] = e

@@ -178,8 +178,7 @@ def run_local_ranks(spec):
             if spec.get("timing"):
                 ctx.set_timing(True)
             p = ts.prove_sharded(config, air, ch, rows, pis, group.comm(r), spec["min_local_log"],
-                                 trace_replicated=bool(spec.get("replicated")),
-                                 column_sharded_inverse=bool(spec.get("colshard")))
+                                 trace_replicated=bool(spec.get("replicated")))
             proofs[r], bits[r] = p.words, ch.sample_bits(20)
             if spec.get("timing"):
                 spec.setdefault("stages", {})[r] = ctx.take_timings()
@@ -206,29 +205,6 @@ LOCAL_CASES = [
     ("mul7", 22, (2, 7, 8), 4, 12, True),      # 2^22 rows: 16384-element NTT chunks, one coset per rank
     ("mul7", 21, (3, 7, 8), 4, 12, False),     # 2^21 rows: 8192-element chunks, two cosets per rank, row-sliced
 ]
-
-
-@pytest.mark.parametrize("air,log_n,cfg,world,repl", [
-    ("mul64", 13, (4, 16, 8), 8, True),    # config 4's split; 64 columns -> 8 per rank, 8 chunk columns -> 1 per rank
-    ("mul64", 14, (2, 28, 8), 4, False),   # row-sliced input: rows all-gathered, then columns sharded
-    ("mul7", 13, (3, 7, 8), 8, True),      # 7 columns over 8 ranks: one rank owns no trace column
-    ("mul7", 21, (2, 7, 8), 4, True),      # 8192-element chunks: the fused transpose on a column range, then LDE_REST
-], ids=["config4-split", "sliced", "fewer-columns-than-ranks", "2p21-chunks"])
-def test_sharded_column_sharded_inverse(ctx, orc, air, log_n, cfg, world, repl):
-    # transposes and the per-column stages of the inverse NTT on
-    # w/G columns per rank + an all-gather of the half-transformed columns; same proof, and the
-    # stage that every rank used to repeat for all columns is gone from its timings
-    spec = {"air": air, "log_n": log_n, "cfg": list(cfg), "world": world, "min_local_log": 8,
-            "replicated": repl, "colshard": True, "timing": True}
-    want, want_bits, _ = single_gpu_proof(ctx, spec)
-    proofs, bits, errors = run_local_ranks(spec)
-    for r in range(world):
-        assert errors[r] is None, f"rank {r}: {errors[r]!r}"
-        assert (proofs[r] == want.words).all(), f"rank {r}: {int((proofs[r] != want.words).sum())} words differ"
-        assert bits[r] == want_bits
-        names = [k for k, _ in spec["stages"][r]]
-        assert "all-gather half-transformed columns" in names
-        assert "lde: transpose (every column on every rank)" not in names
 
 
 @pytest.mark.parametrize("air,log_n,cfg,world,mll,repl", LOCAL_CASES,
@@ -479,13 +455,12 @@ def _thread_ranks(G, rank_fn):
 
 
 @pytest.mark.parametrize("log_n,mode", [(10, "replicated"), (10, "sliced"), (12, "replicated"), (12, "sliced"),
-                                        (13, "colshard"), (13, "colshard-sliced"), (14, "colshard")])
+                                        (13, "replicated"), (13, "sliced"), (14, "replicated")])
 def test_config5_air_sharded_over_eight_ranks(ctx, orc, log_n, mode):
     """BASELINE config 5 ("... on 8 x MI355X", shape README.md:91,101): SynthExt-163 at log_blowup 4 /
     16 queries as ONE proof over 8 ranks (two cosets each; threads on the box's GPU over the native
-    in-process communicator).  163 columns do not divide by 8: the column-sharded inverse deals 21
-    columns to ranks 0-6 and 16 to rank 7 of a matrix padded to 168, and the strided leaf hash runs on
-    a slab with a ragged last block.  Byte-identical to ts_prove AND to the oracle's proof."""
+    in-process communicator).  163 columns: the strided leaf hash runs on a slab with a ragged last
+    block; 2^13 / 2^14 rows take the two-pass LDE.  Byte-identical to ts_prove AND to the oracle's proof."""
     from tapstark_amd.airs import SynthExtAir, generate_synth_ext_trace
     from tapstark_amd.comm import LocalCommGroup
 
@@ -507,8 +482,7 @@ def test_config5_air_sharded_over_eight_ranks(ctx, orc, log_n, mode):
         rows = trace[r * n // G:(r + 1) * n // G] if sliced else trace
         chal = ts.BfChallenger()
         p = ts.prove_sharded(conf, ts.CompiledAir(c, tape), chal, np.ascontiguousarray(rows), [], group.comm(r),
-                             min_local_log=3, trace_replicated=not sliced,
-                             column_sharded_inverse=mode.startswith("colshard"))
+                             min_local_log=3, trace_replicated=not sliced)
         return p.words, chal.sample_bits(20)
 
     res = _thread_ranks(G, rank)
@@ -555,9 +529,8 @@ LOCALQ_CASES = [
     ("pow9-qd8-b4-G2", lambda n: (PowAir(9), pow_trace(n, 9)), 8, (4, 10, 8), 2, True),
     ("fib-qd1-b2-G4", lambda n: ("fib", None), 11, (2, 9, 8), 4, True),
     ("mul64-qd2-b3-G1", lambda n: (SynthMulAir64(), None), 9, (3, 9, 8), 1, True),
-    # two-pass LDE (n > 4096) together with the column-sharded inverse: the per-rank chunk matrices of
-    # the local quotient must NOT go through the column-sharded path (tools/soak_sharded.py found it)
-    ("mul64-qd2-b3-G4-colshard", lambda n: (SynthMulAir64(), None), 14, (3, 9, 8), 4, True),
+    # two-pass LDE (n > 4096) of the per-rank chunk matrices of the local quotient
+    ("mul64-qd2-b3-G4-2p14", lambda n: (SynthMulAir64(), None), 14, (3, 9, 8), 4, True),
 ]
 
 
@@ -614,7 +587,7 @@ def test_local_quotient_same_proof_no_broadcast(ctx, orc, name, make, log_n, cfg
         cc.rank, cc.world, cc.error, cc._keep = r, G, None, inner
         rows = trace[r * n // G:(r + 1) * n // G]
         p = ts.prove_sharded(conf, ts.CompiledAir(c, tape), ts.BfChallenger(), np.ascontiguousarray(rows), pis, cc,
-                             min_local_log=3, local_quotient=True, column_sharded_inverse=name.endswith("colshard"))
+                             min_local_log=3, local_quotient=True)
         return p.words
 
     res = _thread_ranks(G, rank)
@@ -625,19 +598,20 @@ def test_local_quotient_same_proof_no_broadcast(ctx, orc, name, make, log_n, cfg
     assert n_bcast == [0 if local else qd] * G, n_bcast
 
 
-def test_local_quotient_on_an_invalid_trace_refuses(ctx, orc):
+@pytest.mark.parametrize("G,cfg", [(2, (2, 9, 8)), (8, (4, 9, 8))])
+def test_local_quotient_on_an_invalid_trace_is_still_the_single_gpu_proof(ctx, orc, G, cfg):
     """For a trace that violates its constraints, constraints / Z_H is not a polynomial of degree
     < n qd.  The reference (release build, prover.rs:40-41) and ts_prove commit to the interpolants of
     its values on the quotient domain and hand out a proof the verifier rejects (OodEvaluationMismatch);
-    the default sharded path does exactly the same, word for word.  The local-quotient ranks interpolate
-    the values on their OWN cosets: the mixed chunk LDEs are then not low-degree, FRI's final polynomial
-    is not constant, and the prover stops where the reference asserts (fri/src/prover.rs:129-134):
-    TS_ERR_INVARIANT on every rank, no proof."""
-    from tapstark_amd._lib import TsError
+    the broadcast path does exactly the same, word for word.  The local-quotient ranks interpolate the
+    values on their OWN cosets: the mixed chunk LDEs are then not low-degree and FRI's final polynomial
+    is not constant (fri/src/prover.rs:129-134) -- which every rank sees alike, and which sends all of
+    them back through the broadcast path (csrc/sharded.cpp): the call returns ts_prove's proof for
+    EVERY trace, and the context counts the fall-back."""
     from tapstark_amd.airs import SynthMulAir, generate_synth_mul_trace
     from tapstark_amd.comm import LocalCommGroup
 
-    G, cfg, n = 2, (2, 9, 8), 1 << 9
+    n = 1 << 9
     air = SynthMulAir(64)
     tape = ts.air_tape(air, 0)
     bad = generate_synth_mul_trace(n)
@@ -651,16 +625,15 @@ def test_local_quotient_on_an_invalid_trace_refuses(ctx, orc):
         def rank(r):
             c = ts.Context(0)
             conf = ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(*cfg), c))
-            try:
-                return ts.prove_sharded(conf, ts.CompiledAir(c, tape), ts.BfChallenger(), bad.copy(), [],
-                                        group.comm(r), min_local_log=3, trace_replicated=True,
-                                        local_quotient=localq).words
-            except TsError as e:
-                return e
+            ch = ts.BfChallenger()
+            words = ts.prove_sharded(conf, ts.CompiledAir(c, tape), ch, bad.copy(), [], group.comm(r),
+                                     min_local_log=3, trace_replicated=True, local_quotient=localq).words
+            return words, c.stat(5), ch.state()
 
         res = _thread_ranks(G, rank)
-        if localq:
-            for r in res:
-                assert isinstance(r, TsError) and r.code == 5 and "final polynomial" in str(r), r
-        else:
-            assert len(res[0]) == len(single) and (res[0] == single).all() and (res[1] == single).all()
+        ch1 = ts.BfChallenger()
+        ts.prove(config, ts.CompiledAir(ctx, tape), ch1, bad.copy(), [])
+        for words, fallbacks, state in res:
+            assert len(words) == len(single) and (words == single).all()
+            assert fallbacks == (1 if localq else 0)
+            assert (np.asarray(state) == np.asarray(ch1.state())).all()  # the transcript ends where ts_prove's does

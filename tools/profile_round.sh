@@ -23,7 +23,7 @@ TS_BENCH_FORCE_SHARD_BLOCK=1 TS_BENCH_SHARD_STEPS=2 python3 bench.py --headline-
 python3 bench.py --workload fold > $O/fold_even_odd.json 2>> $O/bench.err
 echo "benches done"
 python3 tools/shard_stages.py config4 8 > $O/config4_shard_stages.json 2>> $O/bench.err
-python3 tools/shard_stages.py config5 8 replicated localq colshard > $O/config5_shard_stages.json 2>> $O/bench.err
+python3 tools/shard_stages.py config5 8 replicated localq > $O/config5_shard_stages.json 2>> $O/bench.err
 echo "shard stages done"
 { python3 tools/latency.py; python3 tools/latency.py; } 2>> $O/bench.err | grep -v amdgpu.ids > $O/fri_hipgraph_latency.txt
 echo "latency done"

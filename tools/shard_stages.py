@@ -15,7 +15,7 @@ What a one-GPU box cannot give is the cost of the collectives themselves over xG
 them with stated assumptions (latency per small collective, link bandwidth for the bulk ones).
 
     python tools/shard_stages.py config4 [G] [variant ...] > profiles/r04_config4_shard_stages.json
-    variants: replicated (min_local_log 12), localq, mll16, mll20, colshard, localq16 (localq + mll16)
+    variants: replicated (min_local_log 12), localq, mll16, mll20, localq16 (localq + mll16)
 """
 import ctypes as C
 import json
@@ -81,7 +81,7 @@ def run(name, G, variant):
     tape = ts.air_tape(air, 0)
     group = LocalCommGroup(G)
     token = threading.Lock()
-    kw = dict(trace_replicated=True, column_sharded_inverse=(variant == "colshard"),
+    kw = dict(trace_replicated=True,
               local_quotient=variant.startswith("localq"),
               min_local_log={"mll16": 16, "mll20": 20, "localq16": 16}.get(variant, 12))
     out, errs = [None] * G, [None] * G
@@ -156,7 +156,7 @@ def model(colls, G):
 def main():
     name = sys.argv[1] if len(sys.argv) > 1 else "config4"
     G = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-    variants = sys.argv[3:] or ["replicated", "localq", "mll16", "localq16", "mll20", "colshard"]
+    variants = sys.argv[3:] or ["replicated", "localq", "mll16", "localq16", "mll20"]
     res = {"_comment": __doc__.split("\n\n")[0] + " " + " ".join(__doc__.split("\n\n")[1].split()),
            "config": name, "ranks": G}
     shas = set()

@@ -40,7 +40,7 @@ def main():
                 repl = bool(k & 1)
                 m = ts.DeviceMatrix.upload(ctx, trace if repl else rows)
                 p = ts.prove_sharded(config, cair, ts.BfChallenger(), m, [], group.comm(r),
-                                     trace_replicated=repl, column_sharded_inverse=bool(k & 2),
+                                     trace_replicated=repl,
                                      local_quotient=bool(k & 4))
                 if p.words.tobytes() != ref:
                     bad.append((r, k))

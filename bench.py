@@ -35,6 +35,33 @@ import sys
 import threading
 import time
 
+# ---- wall budget: the driver gives a run 600 s.  Phases of a rank-0 process, the
+# seconds each is PLANNED to take on an 8-GPU node (from the one-GPU records: driver_run_s 32 for the
+# default run of which 22 are the CPU leg; sharded blocks: 2 variants x (6 proofs of ~10 / ~6 ms + trace
+# generation + one stage-timer proof), bounded by their watchdog), and what they took.
+T_PROCESS_START = time.perf_counter()
+WALL_LIMIT_S = 600.0
+PLANNED_S = {"start-up (imports, rendezvous, context, AIR compile)": 40.0,
+             "replicas: warm-up + timed windows": 10.0,
+             "rank-0 legs (kernel timers, latency, h2d, clocks, cpu_baseline)": 60.0,
+             "sharded_config4": 60.0, "sharded_config5": 60.0}
+_PHASES = []
+
+
+def phase_done(name: str):
+    _PHASES.append((name, time.perf_counter()))
+
+
+def wall_budget() -> dict:
+    el, t = {}, T_PROCESS_START
+    for name, t1 in _PHASES:
+        el[name] = round(t1 - t, 2)
+        t = t1
+    return {"limit_s": WALL_LIMIT_S, "planned_s": PLANNED_S, "planned_total_s": sum(PLANNED_S.values()),
+            "elapsed_s": el, "elapsed_total_s": round(time.perf_counter() - T_PROCESS_START, 2),
+            "note": "sharded blocks: 2 variants each (replicated, localq), under a watchdog of "
+                    "TS_BENCH_SHARD_TIMEOUT_S (default 200 s for both) that prints the record it has"}
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -180,7 +207,39 @@ def algorithmic_bytes_per_proof(n: int, w: int, b: int, qd: int) -> dict:
         "(k_bary_dots<1, 8>)": qd * (16 * n + 16 * n),
         "k_reduce_fused": 4 * N * wall + 16 * N,
         "k_fri_fold_pairs": 16 * big_fri_elems + 8 * big_fri_elems + 8 * big_fri_elems,
+        **_leaf_tree_bytes(N, w, qd, fri_leaves, TREE),
     }
+
+
+def _leaf_tree_log_r(log_leaves: int) -> int:
+    """csrc/merkle_tree.hpp leaf_tree_log_r: leaves per lane (log2) of the leaf-tree kernel."""
+    return 2 if log_leaves >= 20 else (log_leaves - 18 if log_leaves >= 18 else 0)
+
+
+def _leaf_tree_bytes(N: int, w: int, qd: int, fri_leaves, tree_log: int) -> dict:
+    """The round-5 Merkle path (leaf_tree.hpp): leaves + every level in one launch, named
+    k_leaf_tree<log2 leaves per lane, leaf kind>.  A tree of L leaves is 2L - 1 digests of 32 bytes,
+    each written once; the leaf launch also reads what it hashes."""
+    log_N = N.bit_length() - 1
+    out = {}
+
+    def add(name, b):
+        out[name] = out.get(name, 0) + b
+    if log_N >= 8:
+        r = _leaf_tree_log_r(log_N)
+        add(f"k_leaf_tree<{r},strided>", 4 * N * w + 64 * N)       # the trace: one matrix, addressed by stride
+        add(f"k_leaf_tree<{r},table>", 4 * N * 4 * qd + 64 * N)    # the chunk batch: column pointer table
+    first = True
+    for h in fri_leaves:
+        lg = h.bit_length() - 1
+        if h > (1 << tree_log) and lg >= 8:
+            r = _leaf_tree_log_r(lg)
+            if first:
+                add(f"k_leaf_tree<{r},fri_leaf>", 32 * h + 64 * h)            # vector of 2h EF4 in, tree out
+            else:
+                add(f"k_leaf_tree<{r},fri_fold>", 64 * h + 8 * h + 32 * h + 64 * h)  # prev, twiddles, cur, tree
+        first = False
+    return out
 
 
 def _omp_set_threads(n: int):
@@ -581,6 +640,8 @@ def main():
 
     def emit(record: dict):
         sys.stdout.flush()
+        if isinstance(record, dict) and "wall_budget" not in record:
+            record["wall_budget"] = wall_budget()
         os.write(real_stdout, (json.dumps(record) + "\n").encode())
 
     if stub:
@@ -791,10 +852,12 @@ def main():
         if S > 1:
             stagger["ms"] = args.stagger_ms if args.stagger_ms >= 0 else 0.25 * single_ms
 
+    phase_done("start-up (imports, rendezvous, context, AIR compile)")
     # sharded: the ranks of a group share each step's n*w cells
     res = run_timed(env, step, args.steps, warmup, local_sync,
                     units_per_step=float(n * w) / (gsize if sharded else 1), run_steps=run_steps,
                     extra_windows=n_windows - 1)
+    phase_done("replicas: warm-up + timed windows")
     shard_stages = None
     if sharded:
         import torch.distributed as dist
@@ -864,6 +927,7 @@ def main():
         # the two fields VERDICT r3 asked for, at the top level of the line
         out["proof_blake3"] = cb.get("gpu_proof_blake3")
         out["matches_oracle"] = cb.get("matches_oracle")
+    phase_done("rank-0 legs (kernel timers, latency, h2d, clocks, cpu_baseline)")
 
     # ---- N > 1: BASELINE configs 4 and 5 as one sharded proof each, in the same lease
     wd = None
@@ -881,7 +945,7 @@ def main():
         for c, _, _ in lanes[1:]:
             c.synchronize()
         mats = None
-        limit = float(os.environ.get("TS_BENCH_SHARD_TIMEOUT_S", "300"))
+        limit = float(os.environ.get("TS_BENCH_SHARD_TIMEOUT_S", "200"))
         names = [x.strip() for x in os.environ.get("TS_BENCH_SHARD_BLOCKS", "sharded_config4,sharded_config5").split(",")
                  if x.strip() in SHARDED_BLOCKS]
         state = {}
@@ -920,6 +984,7 @@ def main():
                 break
             if out is not None:
                 out[nm] = blk
+            phase_done(nm)
         if state.get("native") and state.get("comm") is not None:
             state["comm"].close()
 
@@ -1050,6 +1115,29 @@ def rank0_legs(ts, args, env, ctx, config, cair, lanes, S, pool, local_sync, mak
                           "frac": round((A1 + C1) / (lde_ms * 1e-3) / HBM_PEAK, 4),
                           "note": "single proof alone on the GPU; the stage is three passes (60 n W bytes "
                                   "moved for 20 n W algorithmic) and VALU-bound, see alu_ceiling"}
+    # every term of SURVEY.md section 8(d) against the stage timers of ONE proof alone on the GPU
+    # (spans named as the reference's tracing spans; leaf hashing is not fused into the forward
+    # pass, so the two Merkle terms carry the re-read of what they hash: + 4 N w and + 16 N qd)
+    A2 = C2 = 32 * (2 * N_ - 1)
+    B_ = 4 * n * qd * w + 16 * n * qd
+    D_ = 4 * N_ * w + 16 * N_ * qd + 16 * N_
+    E_ = 32 * N_ + 16 * N_ + 64 * N_
+    terms = [("A1 + C1: coset_lde (trace + quotient chunks)", A1 + C1, ("coset_lde",), None),
+             ("A2 + C2: merkle_commit (both trees, leaves re-read)", A2 + C2 + 4 * N_ * w + 16 * N_ * qd,
+              ("merkle_commit",), "SURVEY's fused figure: %d" % (A2 + C2)),
+             ("B: compute quotient polynomial", B_, ("compute quotient polynomial",), None),
+             ("D: open (opened values + reduce rows)", D_,
+              ("compute opened values with Lagrange interpolation", "reduce rows"),
+              "the barycentric pass reads the low coset once more: + %d" % (4 * n * wall_)),
+             ("E: FRI commit phase + query phase", E_, ("FRI commit phase", "query phase"), None)]
+    roofline_stages = []
+    for label, nbytes, spans, note in terms:
+        ms_ = sum(stage_sum.get(sp, 0.0) for sp in spans)
+        if ms_ > 0:
+            roofline_stages.append({"stage": label, "alg_bytes": nbytes, "ms": round(ms_, 4),
+                                    "achieved": round(nbytes / (ms_ * 1e-3) / 1e9, 1), "peak": HBM_PEAK / 1e9,
+                                    "unit": "GB/s", "frac": round(nbytes / (ms_ * 1e-3) / HBM_PEAK, 4),
+                                    **({"note": note} if note else {})})
     roofline_whole = {"alg_bytes_per_proof": whole, "ms_per_step": round(res["ms_per_step"], 4),
                       "achieved": round(whole / (res["ms_per_step"] * 1e-3) / 1e9, 1), "peak": HBM_PEAK / 1e9,
                       "unit": "GB/s", "frac": round(whole / (res["ms_per_step"] * 1e-3) / HBM_PEAK, 4)}
@@ -1062,7 +1150,7 @@ def rank0_legs(ts, args, env, ctx, config, cair, lanes, S, pool, local_sync, mak
         return sum(v["ms_per_proof"] for k, v in per_kernel.items() if any(x in k for x in names))
     bf_peak, b3_peak = ctx.alu_ceiling(0), ctx.alu_ceiling(1)
     ntt_ms = ms_of("k_intt_contig", "k_lde_mid", "k_lde_fwd_contig")
-    b3_ms = ms_of("k_leaf_hash", "k_merkle_level", "k_merkle_tree", "k_fri_round")
+    b3_ms = ms_of("k_leaf_hash", "k_merkle_level", "k_merkle_tree", "k_fri_round", "k_leaf_tree")
     alu_ceiling = {
         "butterflies_per_s_peak": round(bf_peak), "butterflies_per_proof": butterflies,
         "ntt_kernels_ms": round(ntt_ms, 4), "ntt_ms_at_peak": round(butterflies / bf_peak * 1e3, 4),
@@ -1071,7 +1159,8 @@ def rank0_legs(ts, args, env, ctx, config, cair, lanes, S, pool, local_sync, mak
         "merkle_kernels_ms": round(b3_ms, 4), "merkle_ms_at_peak": round(compressions / b3_peak * 1e3, 4),
         "merkle_frac_of_alu_peak": round(compressions / b3_peak * 1e3 / b3_ms, 4) if b3_ms else None,
         "note": "peaks from ts_bench_alu (register-resident loops of the same butterfly / compression code, "
-                "no memory traffic); FRI-round leaf hashes fused into the fold kernel are not in merkle_kernels_ms"}
+                "no memory traffic); merkle_kernels_ms also holds the folds that the FRI round launches carry "
+                "(k_fri_round, k_leaf_tree<*,fri_fold>), whose arithmetic is not in the compression count"}
     # ---- the ceiling that actually binds: VALU instruction issue.  A wave64 VALU instruction
     # holds its SIMD for four cycles (tools/pmc_alu.sh: the register-resident loops issue exactly
     # one per 4 cycles per SIMD at 2.30-2.34 GHz); the prover's kernels run at ~2.0 GHz
@@ -1224,7 +1313,8 @@ def rank0_legs(ts, args, env, ctx, config, cair, lanes, S, pool, local_sync, mak
         # several in flight; this is the latency a single caller sees)
         "single_proof_latency_ms": round(single_latency, 4),
         "single_proof_latency_with_stage_timers_ms": stage_sum.get("prove"),
-        "roofline": roofline, "roofline_stage": roofline_stage, "roofline_whole": roofline_whole,
+        "roofline": roofline, "roofline_stage": roofline_stage, "roofline_stages": roofline_stages,
+        "roofline_whole": roofline_whole,
         "alu_ceiling": alu_ceiling, "valu_issue": valu_issue, "clocks": clocks, "h2d_inclusive": h2d,
         "h2d_inclusive_config2": h2d_c2,
         "h2d_inclusive_ms_per_step": (h2d or {}).get("ms_per_step"), "cpu_baseline": cpu,

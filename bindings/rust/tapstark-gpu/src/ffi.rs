@@ -1,7 +1,7 @@
 //! `extern "C"` declarations of include/tapstark.h (ABI version 4).  One line per entry point the
 //! Rust side uses; the header is the authority for argument meaning.
 #![allow(non_camel_case_types)]
-use core::ffi::{c_char, c_int, c_void};
+use core::ffi::{c_char, c_int, c_uint, c_void};
 
 macro_rules! opaque { ($($n:ident),*) => { $( #[repr(C)] pub struct $n { _p: [u8; 0] } )* } }
 opaque!(ts_ctx, ts_matrix, ts_air, ts_pcs_data, ts_challenger, ts_rccl_comm, ts_comm_group, ts_taptree,
@@ -36,7 +36,7 @@ pub struct ts_comm {
 pub struct ts_shard_options {
     pub min_local_log: u32,
     pub trace_replicated: u32,
-    pub column_sharded_inverse: u32,
+    pub column_sharded_inverse: u32, // ignored since round 5 (kept for layout)
     pub local_quotient: u32,
 }
 
@@ -56,6 +56,10 @@ pub struct ts_rccl_info {
 extern "C" {
     pub fn ts_abi_version() -> u32;
     pub fn ts_ctx_graph_stats(ctx: *mut ts_ctx, out: *mut u64) -> ts_status;
+    pub fn ts_ctx_stat(ctx: *mut ts_ctx, which: c_int, out: *mut u64) -> ts_status;
+    pub fn ts_device_count() -> c_int;
+    pub fn ts_bench_stage(ctx: *mut ts_ctx, stage: c_int, log_n: c_uint, width: u32, log_blowup: c_uint,
+                          reps: u32, ms_per_rep: *mut f64) -> ts_status;
     pub fn ts_ctx_create(device: c_int, out: *mut *mut ts_ctx) -> ts_status;
     pub fn ts_ctx_destroy(ctx: *mut ts_ctx);
     pub fn ts_last_error(ctx: *const ts_ctx) -> *const c_char;

@@ -338,7 +338,10 @@ struct TableLeaf {
 #pragma unroll
             for (int j = 0; j < 16; j++) {
                 const uint32_t c = blk * 16 + j;
-                m[j] = c < total ? cols[c][r] : 0u;
+                // a pointer read from memory is a generic one to the compiler (flat_load: an aperture
+                // check per access); these are device allocations: say so
+                typedef const uint32_t __attribute__((address_space(1))) * gptr;
+                m[j] = c < total ? ((gptr)cols[c])[r] : 0u;
             }
             const uint32_t words = total - blk * 16 < 16 ? total - blk * 16 : 16;
             const uint32_t flags = (blk == 0 ? b3::CHUNK_START : 0u) |

@@ -9,7 +9,7 @@ restatement tests/test_oracle.py pins.  Run in the build container (8 cores, 62 
 
     python tests/golden/make_golden_large.py config2 config3 config5     # ~1, ~1, ~5 min
     python tests/golden/make_golden_large.py config4                     # ~10 min, ~40 GiB peak
-    python tests/golden/make_golden_large.py fib_2p24_b2 mul64_2p23_b1 fib_2p26_b1
+    python tests/golden/make_golden_large.py fib_2p24_b2 mul64_2p23_b1 fib_2p25_b1 fib_2p26_b1
 
 Each run merges its configs into the existing JSON.  The buffers themselves are far too large to
 commit (config 4's LDE is 16 GiB); the digests are what travels.
@@ -43,6 +43,7 @@ CONFIGS = {
     # beyond the BASELINE sizes: the LDE plans for n = 2^23 .. 2^26 (strided pass of 11 .. 14 stages) up to
     # the largest LDE the field allows (2^27 rows): ~100 s, ~100 s and ~4 min / 35 GiB of oracle time
     "fib_2p24_b2": (FibonacciAir, lambda n: generate_fibonacci_trace(0, 1, n), fibonacci_public_values, (2, 28, 8), 24),
+    "fib_2p25_b1": (FibonacciAir, lambda n: generate_fibonacci_trace(0, 1, n), fibonacci_public_values, (1, 28, 8), 25),
     "fib_2p26_b1": (FibonacciAir, lambda n: generate_fibonacci_trace(0, 1, n), fibonacci_public_values, (1, 28, 8), 26),
     "mul64_2p23_b1": (lambda: SynthMulAir(64), generate_synth_mul_trace, None, (1, 16, 8), 23),
 }

@@ -53,3 +53,14 @@ def test_merkle_tree_handoff_isa(merkle_isa):
 def test_fri_round_handoff_isa(fri_isa):
     for name, lines in _kernel(fri_isa, "k_fri_round"):
         _check_handoff(name, lines)
+
+
+def test_leaf_tree_handoff_isa(merkle_isa, fri_isa):
+    # leaves + tree in one launch (leaf_tree.hpp): the same finisher, so the same hand-off rules, for
+    # every leaf kind and every leaves-per-lane variant
+    n = 0
+    for isa in (merkle_isa, fri_isa):
+        for name, lines in _kernel(isa, "k_leaf_tree"):
+            _check_handoff(name, lines)
+            n += 1
+    assert n == 20  # (strided, table, ef_pairs, fri_fold, fri_leaf) x (1, 2, 4, 8 leaves per lane)

@@ -42,14 +42,15 @@ def device_trace(ctx, name, n):
 
 
 AIRS = {"config2": FibonacciAir, "config3": lambda: SynthMulAir(64), "config4": lambda: SynthMulAir(64),
-        "config5": lambda: SynthExtAir(163), "fib_2p24_b2": FibonacciAir, "fib_2p26_b1": FibonacciAir,
+        "config5": lambda: SynthExtAir(163), "fib_2p24_b2": FibonacciAir, "fib_2p25_b1": FibonacciAir,
+        "fib_2p26_b1": FibonacciAir,
         "mul64_2p23_b1": lambda: SynthMulAir(64)}
 
 
-# beyond BASELINE: n = 2^23 .. 2^26 (strided NTT passes of 11, 12 and 14 stages: the generic plan), up to the
-# 2^27-row LDE that is the field's limit
+# beyond BASELINE: n = 2^23 .. 2^26 (strided NTT passes of 11, 12, 13 and 14 stages: the generic plan), up
+# to the 2^27-row LDE that is the field's limit
 @pytest.mark.parametrize("name", ["config2", "config3", "config5", "config4", "fib_2p24_b2", "mul64_2p23_b1",
-                                  "fib_2p26_b1"])
+                                  "fib_2p25_b1", "fib_2p26_b1"])
 def test_full_size_proof_equals_oracle_digests(ctx, orc, name):
     want = load_large(name)
     n = 1 << want["log_n"]

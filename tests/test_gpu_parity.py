@@ -49,8 +49,8 @@ def bitrev_perm(bits):
 def test_commit_lde_and_merkle(ctx, orc, log_n, w, log_blowup):
     if log_n >= 24 and not os.environ.get("TS_BIG_TESTS"):
         # 15-30 s of oracle hashing each; run with TS_BIG_TESTS=1 (round 4: all passed).
-        # The same LDE plans are covered end to end by the whole-proof digests of fib_2p24_b2 / fib_2p26_b1
-        # in test_gpu_golden_large.py, which cost a second.
+        # The same LDE plans (2^24, 2^25, 2^26 rows) are covered end to end by the whole-proof digests of
+        # fib_2p24_b2 / fib_2p25_b1 / fib_2p26_b1 in test_gpu_golden_large.py, which cost a second each.
         pytest.skip("2^24+ rows against every oracle digest level: TS_BIG_TESTS=1")
     pcs = ts.TwoAdicFriPcs(ts.FriConfig(log_blowup, 4, 8), ctx)
     m = rand_mat(17 + log_n, 1 << log_n, w)

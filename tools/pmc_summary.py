@@ -22,7 +22,15 @@ from collections import defaultdict
 def short(name):
     name = re.sub(r"^void ", "", name)
     name = re.sub(r"\(.*$", "", name)  # drop the argument list
-    return name.replace("ts::", "")
+    name = name.replace("ts::", "")
+    # k_leaf_tree<2, StridedLeaf> -> k_leaf_tree<2,strided>: the names the library's kernel timers and
+    # bench.py's byte model use (leaf_tree.hpp Leaf::name)
+    m = re.match(r"k_leaf_tree<(\d), (\w+)(<(true|false)> ?)?>", name)
+    if m:
+        kind = {"StridedLeaf": "strided", "TableLeaf": "table", "EfPairLeaf": "ef_pairs",
+                "FriLeaf": "fri_fold" if m.group(4) == "true" else "fri_leaf"}.get(m.group(2), m.group(2))
+        name = f"k_leaf_tree<{m.group(1)},{kind}>"
+    return name
 
 
 def load(path, counter):

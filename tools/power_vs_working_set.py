@@ -55,4 +55,14 @@ for stage in (0, 1):
         r = sustained(stage, width)
         out["rows"].append(r)
         print(r, file=sys.stderr, flush=True)
+# The other way to shrink the working set: fewer ROWS at 64 columns.  Grids keep their width (every
+# column is there), the passes change shape with n (17 .. 20 stages), so the unit is the butterfly.
+out["rows_by_height"] = []
+for log_n in (17, 18, 19, 20):
+    LOG_N = log_n
+    r = sustained(0, 64)
+    bf = 5 * (1 << (log_n - 1)) * log_n * 64  # inverse + 4 cosets forward
+    r.update(log_n=log_n, butterflies=bf, ps_per_butterfly=round(1e9 * r["ms_per_rep"] / bf, 4))
+    out["rows_by_height"].append(r)
+    print(r, file=sys.stderr, flush=True)
 print(json.dumps(out, indent=1))

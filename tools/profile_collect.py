@@ -6,7 +6,7 @@ import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", tag, "final")
 dst = os.path.join(root, "profiles")
@@ -19,6 +19,9 @@ plan = {
     "config5_shard_stages.json": "config5_shard_stages.json", "fri_hipgraph_latency.txt": "fri_hipgraph_latency.txt",
     "config3_sq_counters.txt": "config3_sq_counters.txt", "config4_sq_counters.txt": "config4_sq_counters.txt",
     "config3_pmc_traffic.json": "pmc_traffic.json", "config4_pmc_traffic.json": "config4_pmc_traffic.json",
+    "config2_pmc_traffic.json": "config2_pmc_traffic.json", "config5_pmc_traffic.json": "config5_pmc_traffic.json",
+    "config2_sq_counters.txt": "config2_sq_counters.txt", "config5_sq_counters.txt": "config5_sq_counters.txt",
+    "power_vs_working_set.json": "power_vs_working_set.json", "power_per_stage.json": "power_per_stage.json",
 }
 for cfg in ("config3", "config2", "config4", "config5"):
     plan[f"kt_{cfg}/kt_kernel_stats.csv"] = f"{cfg}_rocprofv3_kernel_stats.csv"

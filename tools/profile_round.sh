@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collects a round's evidence on the GPU box (run from the repo root through gpurun):
-#     bash tools/profile_round.sh r04
+#     bash tools/profile_round.sh r05
 # Everything lands under gpurun_out/<tag>/final/ and is then copied into profiles/<tag>_* by
 # tools/profile_collect.py: bench lines (driver protocol for config 3; configs 2, 4, 5; the 2-rank
 # shared-GPU rehearsal of --gpus 2 with both sharded blocks), rocprofv3 kernel-trace stats for configs
@@ -9,7 +9,7 @@
 # reference's fold benchmark.
 set -e
 set -o pipefail
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG/final
 mkdir -p $O
@@ -27,12 +27,15 @@ python3 tools/shard_stages.py config5 8 replicated localq > $O/config5_shard_sta
 echo "shard stages done"
 { python3 tools/latency.py; python3 tools/latency.py; } 2>> $O/bench.err | grep -v amdgpu.ids > $O/fri_hipgraph_latency.txt
 echo "latency done"
-for cfg in config3 config4; do
+python3 tools/power_vs_working_set.py > $O/power_vs_working_set.json 2>> $O/bench.err
+python3 tools/power_per_stage.py > $O/power_per_stage.json 2>> $O/bench.err
+echo "power done"
+for cfg in config3 config2 config4 config5; do
   bash tools/pmc_sq.sh $cfg > $O/sq_$cfg.log 2>&1 || { tail -20 $O/sq_$cfg.log; exit 1; }
   cp gpurun_out/prof_sq/sq_table.txt $O/${cfg}_sq_counters.txt
 done
 cd /tmp && export TMPDIR=/tmp
-for cfg in config3 config4; do
+for cfg in config3 config2 config4 config5; do
   for c in FETCH_SIZE WRITE_SIZE; do
     timeout -k 10 400 rocprofv3 --pmc $c --output-format csv -d $O/pmc_${cfg}_$c -o pmc -- python3 $R/tools/prof_prove.py 2 $cfg > $O/pmc_${cfg}_$c.log 2>&1 || { echo "pmc $cfg $c failed"; tail -5 $O/pmc_${cfg}_$c.log; exit 1; }
   done
@@ -45,7 +48,7 @@ cd $R
 find $O -name "*.csv" -size +20M -delete
 find $O -name "*.db" -delete
 find $O -name "*kernel_trace.csv" -delete
-for cfg in config3 config4; do
+for cfg in config3 config2 config4 config5; do
   python3 tools/pmc_summary.py $O/pmc_${cfg}_FETCH_SIZE/pmc_counter_collection.csv $O/pmc_${cfg}_WRITE_SIZE/pmc_counter_collection.csv 2 $O/${cfg}_pmc_traffic.json $cfg > $O/${cfg}_traffic.txt
 done
 python3 - <<PY

@@ -43,7 +43,7 @@ T_PROCESS_START = time.perf_counter()
 WALL_LIMIT_S = 600.0
 PLANNED_S = {"start-up (imports, rendezvous, context, AIR compile)": 40.0,
              "replicas: warm-up + timed windows": 10.0,
-             "rank-0 legs (kernel timers, latency, h2d, clocks, cpu_baseline)": 60.0,
+             "rank-0 legs (kernel timers, latency, h2d, clocks, cpu_baseline)": 100.0,
              "sharded_config4": 60.0, "sharded_config5": 60.0}
 _PHASES = []
 
@@ -998,6 +998,64 @@ def main():
         emit(out)
 
 
+def live_pmc_traffic(workload: str, kernel: str, timeout_s: float = 150.0):
+    """HBM-side traffic of `kernel` measured NOW: two child processes, `rocprofv3 --pmc FETCH_SIZE` and
+    `rocprofv3 --pmc WRITE_SIZE` (separate passes, counters only, the program itself after `--`) around
+    tools/prof_prove.py (2 proofs of the workload); KiB units; FETCH_SIZE doubled for gfx950
+    (/opt/skills/guides/MI355X_MICROARCH.md, HBM / rocprofv3 section).  Returns (bytes per launch, note)
+    or (None, reason).  The parent keeps its contexts; the child is an ordinary second process on the GPU."""
+    import csv
+    import glob
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    # the names rocprofv3 reports are the demangled C++ ones; the library's timer names drop "ts::" and
+    # shorten the leaf kinds (tools/pmc_summary.py: short)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    tmp = tempfile.mkdtemp(prefix="ts_pmc_", dir="/tmp")
+    tot, launches = {}, 0
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "pmc", "--",
+                   "/usr/bin/python3", os.path.join(ROOT, "tools", "prof_prove.py"), "2", workload]
+            env = dict(os.environ, TMPDIR="/tmp")
+            env.pop("TS_BENCH_SELF_LAUNCHED", None)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode}): {(r.stderr or r.stdout)[-200:]}"
+            v, c = 0.0, 0
+            for row in csv.DictReader(open(files[0])):
+                if row["Counter_Name"] != counter:
+                    continue
+                name = re.sub(r"\(.*$", "", re.sub(r"^void ", "", row["Kernel_Name"])).replace("ts::", "")
+                m = re.match(r"k_leaf_tree<(\d), (\w+)(<(true|false)> ?)?>", name)
+                if m:
+                    kind = {"StridedLeaf": "strided", "TableLeaf": "table", "EfPairLeaf": "ef_pairs",
+                            "FriLeaf": "fri_fold" if m.group(4) == "true" else "fri_leaf"}.get(m.group(2), m.group(2))
+                    name = f"k_leaf_tree<{m.group(1)},{kind}>"
+                want = kernel.strip("()")
+                if name == want or name.startswith(want.rstrip(">") + ",") or name.startswith(want.rstrip(">") + ">"):
+                    v += float(row["Counter_Value"])
+                    c += 1
+            if c == 0:
+                return None, f"no {counter} rows for {kernel}"
+            tot[counter], launches = v, c
+        per_launch = (2 * 1024 * tot["FETCH_SIZE"] + 1024 * tot["WRITE_SIZE"]) / launches
+        return round(per_launch), (f"live: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (two child processes, "
+                                   f"{launches} launches of {kernel} over 2 proofs; KiB units, FETCH_SIZE x2 for gfx950)")
+    except Exception as e:  # noqa: BLE001 -- the leg is optional
+        return None, repr(e)[:200]
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def latest_profile(pattern: str):
     import glob
     fs = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
@@ -1090,6 +1148,17 @@ def rank0_legs(ts, args, env, ctx, config, cair, lanes, S, pool, local_sync, mak
                             "(tools/prof_prove.py), not collected in this run"}
     except Exception:
         traffic, traffic_source = None, None
+    # ... unless it can be measured right here (default; TS_BENCH_LIVE_PMC=0 keeps the committed figure):
+    # the committed file then stays on the record as the figure it is compared with
+    if os.environ.get("TS_BENCH_LIVE_PMC", "1") != "0" and args.log_n == (22 if args.workload == "config4" else 20):
+        t_live0 = time.perf_counter()
+        live, note = live_pmc_traffic(args.workload, dom)
+        if live is not None:
+            traffic_source = {"note": note, "seconds": round(time.perf_counter() - t_live0, 1),
+                              "committed_figure": {"bytes_per_launch": traffic, **(traffic_source or {})}}
+            traffic = live
+        elif traffic_source is not None:
+            traffic_source["live_attempt"] = note
     lpp = kt[dom][0] / reps
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved / 1e9, 2),
                 "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 4),

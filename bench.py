@@ -1096,7 +1096,13 @@ def rank0_legs(ts, args, env, ctx, config, cair, lanes, S, pool, local_sync, mak
         stage_sum[k] = round(stage_sum.get(k, 0.0) + v, 3)
     alg = algorithmic_bytes_per_proof(n, w, cfg[0], qd)
 
+    leaf_tree_path = any("k_leaf_tree" in k for k in kt)
+
     def alg_bytes(name):  # every instantiation of the strided NTT pass moves the same bytes
+        if leaf_tree_path and name in ("k_fri_fold_pairs", "k_merkle_tree"):
+            # round-5 Merkle path: what is left to these two is the fold into the tail's 1024 elements and
+            # the top of a tree above a few thousand sub-roots (latency, kilobytes): no bandwidth figure
+            return None
         if "k_lde_mid" in name:
             return alg["k_lde_mid<1>"]
         if name == "k_merkle_level<1>" and "k_merkle_level<2>" not in kt:

@@ -22,6 +22,11 @@ def probe():
         root, data = mm.commit([m])
         rows, path = mm.open_batch((1 << lg) // 3, data)
         out[f"tree{lg}"] = [int(x) for x in root] + [int(x) for x in np.asarray(path).ravel()]
+    for lg, widths in ((11, [4, 4]), (19, [64]), (20, [4, 4, 4, 4]), (21, [17])):  # table / strided leaves, ragged block
+        mats = [splitmix64_stream(7 * lg + i, (1 << lg) * w).reshape(1 << lg, w) for i, w in enumerate(widths)]
+        root, data = mm.commit(mats)
+        rows, path = mm.open_batch((1 << lg) - 5, data)
+        out[f"wide{lg}"] = [int(x) for x in root] + [int(x) for x in np.asarray(path).ravel()]
     n = 1 << 19  # FRI rounds with 2^20 .. 2^10 leaves at log_blowup 2
     config = ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(2, 9, 4), ctx))
     last = int(ts.DeviceMatrix.fibonacci(ctx, 0, 1, n).download()[-1, 1])

@@ -128,12 +128,21 @@ def test_alu_ceiling_probe(ctx):
     assert 1e11 < bf < 2e13 and 5e9 < b3 < 5e11 and 2e9 < sha < 2e11
 
 
-@pytest.mark.parametrize("tree_log,round_log", [(16, 0), (22, 22), (19, 20)])
-def test_tree_launch_shapes_agree(ctx, tree_log, round_log):
-    # how many levels one launch takes (whole trees up to 2^22 leaves in one launch, several LDS
-    # chunks per workgroup, 1024 sub-roots; FRI commit rounds with the fold fused in) is a tuning
-    # knob read once per process: every setting must give the same roots, paths and proof bytes as
-    # the default one in this process
+@pytest.mark.parametrize("knobs", [
+    {"TS_TREE_MAX_LOG": "16", "TS_FRI_ROUND_LOG": "0"}, {"TS_TREE_MAX_LOG": "22", "TS_FRI_ROUND_LOG": "22"},
+    {"TS_TREE_MAX_LOG": "19", "TS_FRI_ROUND_LOG": "20"},
+    # round 4's Merkle path (leaf launch, level launches, tree launch), with two of its shapes
+    {"TS_LEAF_TREE": "0"}, {"TS_LEAF_TREE": "0", "TS_TREE_MAX_LOG": "16", "TS_FRI_ROUND_LOG": "0"},
+    # the leaf-tree kernel: every leaves-per-lane variant on every height that takes it, the sub-roots to
+    # a second launch, every FRI round through it
+    {"TS_LEAF_TREE_R": "0"}, {"TS_LEAF_TREE_R": "1"}, {"TS_LEAF_TREE_R": "3"},
+    {"TS_LEAF_TREE_FINISH": "0", "TS_FRI_ROUND_LOG": "0"},
+], ids=lambda k: ",".join(f"{a[3:]}={b}" for a, b in k.items()))
+def test_tree_launch_shapes_agree(ctx, knobs):
+    # how a Merkle commitment is cut into launches (leaves and tree in one launch or apart, leaves per
+    # lane, how many levels a whole-tree launch takes, FRI commit rounds with the fold fused in) is a
+    # set of tuning knobs read once per process: every setting must give the same roots, paths and
+    # proof bytes as the default one in this process
     import subprocess
     import sys
 
@@ -141,7 +150,7 @@ def test_tree_launch_shapes_agree(ctx, tree_log, round_log):
     import _tree_shapes_probe as probe
 
     here = probe.probe()
-    env = dict(os.environ, TS_TREE_MAX_LOG=str(tree_log), TS_FRI_ROUND_LOG=str(round_log))
+    env = dict(os.environ, **knobs)
     r = subprocess.run([sys.executable, probe.__file__], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("PROBE ")][-1]

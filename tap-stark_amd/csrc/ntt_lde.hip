@@ -536,8 +536,10 @@ k_lde_mid(const uint32_t* __restrict__ evals, uint64_t in_col_stride, uint32_t* 
                 for (int q = 0; q < 16; q++) {
                     const uint32_t i = threadIdx.x + (uint32_t)(j + GP * q) * NTM;
                     const uint32_t kk = ((i >> LT) << LM) + (i & ((1u << LT) - 1)) + j2_0;
-                    if constexpr (PREFETCH) v[q] = mont_mul(coef[j + GP * q], scv[q]);
-                    else v[q] = mont_mul(coef[j + GP * q], sc[kk]);
+                    // (lazy product: the butterflies that follow take [0, 2p) -- two instructions fewer
+                    // per coefficient and coset)
+                    if constexpr (PREFETCH) v[q] = mont_mul_lazy(coef[j + GP * q], scv[q]);
+                    else v[q] = mont_mul_lazy(coef[j + GP * q], sc[kk]);
                 }
                 if constexpr (PREFETCH) {
                     if (bl + 1 < n_cosets) {
@@ -579,7 +581,7 @@ k_lde_mid(const uint32_t* __restrict__ evals, uint64_t in_col_stride, uint32_t* 
                 if (i < total) {
                     // coefficient index of this slot
                     const uint32_t kk = ((i >> log_T) << row_shift) + (i & tmask) + j2_0;
-                    s[pad(i)] = mont_mul(coef[k], sc[kk]);
+                    s[pad(i)] = mont_mul_lazy(coef[k], sc[kk]);
                 }
             }
             __syncthreads();

@@ -91,11 +91,23 @@ void mmcs_commit(Context& ctx, PcsData& data) {
             memset(&lm, 0, sizeof lm);
             lm.cols = data.col_table.p + g.first;
             lm.total_width = g.total;
-            if (g.n_mats == 1) {  // lets the leaf kernel address the columns by stride
+            // one matrix -- or several lying back to back with one stride (commit() stores a batch of
+            // equal-height matrices that way) -- lets the leaf kernel address the columns by stride
+            const ColMat* first = nullptr;
+            bool contiguous = true;
+            uint32_t wsum = 0;
+            for (auto& cm : data.ldes)
+                if (cm.height == g.height) {
+                    if (!first) first = &cm;
+                    contiguous = contiguous && cm.col_stride == first->col_stride &&
+                                 cm.d == first->d + (uint64_t)wsum * first->col_stride;
+                    wsum += cm.width;
+                }
+            if (first && contiguous && wsum <= 256) {
                 lm.n_mats = 1;
-                lm.d[0] = g.only->d;
-                lm.col_stride[0] = g.only->col_stride;
-                lm.width[0] = g.only->width;
+                lm.d[0] = first->d;
+                lm.col_stride[0] = first->col_stride;
+                lm.width[0] = wsum;
             }
             return lm;
         };
@@ -147,6 +159,18 @@ std::unique_ptr<PcsData> TwoAdicFriPcs::commit(std::vector<DeviceMatrix>& evals,
     data->log_height = log_N;
     {
         StageTimer t(&ctx_, "coset_lde");
+        // A batch of equal-height matrices (the quotient chunks) gets ONE allocation, matrix after
+        // matrix: to the leaf hash and to the opening's dot products it is then a single matrix of
+        // the summed width (strided addressing, one launch) instead of a pointer table / a launch each.
+        bool same_height = evals.size() > 1;
+        size_t total_w = 0;
+        for (auto& m : evals) {
+            same_height = same_height && m.height == evals[0].height;
+            total_w += m.width;
+        }
+        DevBuf<uint32_t> batch;
+        if (same_height) batch = DevBuf<uint32_t>(&ctx_, total_w * (evals[0].height << fri_.log_blowup));
+        size_t batch_col = 0;
         for (size_t i = 0; i < evals.size(); i++) {
             DeviceMatrix& m = evals[i];
             TS_REQUIRE(domain_shifts[i] != 0 && domain_shifts[i] < P, TS_ERR_INVALID, "bad domain shift");
@@ -162,19 +186,28 @@ std::unique_ptr<PcsData> TwoAdicFriPcs::commit(std::vector<DeviceMatrix>& evals,
                 if (!r16) launch_transpose_bitrev(ctx_, m.buf.p, colmajor.p, log_n, m.width, n);
                 ev = colmajor.p;
             }
-            DevBuf<uint32_t> lde(&ctx_, (size_t)m.width * Ni);
+            DevBuf<uint32_t> lde;
+            uint32_t* lde_p;
+            if (same_height) {
+                lde_p = batch.p + batch_col * Ni;
+                batch_col += m.width;
+            } else {
+                lde = DevBuf<uint32_t>(&ctx_, (size_t)m.width * Ni);
+                lde_p = lde.p;
+            }
             // two_adic_pcs.rs:235: shift = Val::generator() / domain.shift
             const uint32_t shift = mul(GENERATOR, inv_canon(domain_shifts[i]));
-            coset_lde(ctx_, ev, n, m.width, log_n, fri_.log_blowup, shift, lde.p, Ni, 0, 0, r16);
+            coset_lde(ctx_, ev, n, m.width, log_n, fri_.log_blowup, shift, lde_p, Ni, 0, 0, r16);
             ColMat cm;
-            cm.d = lde.p;
+            cm.d = lde_p;
             cm.height = Ni;
             cm.width = m.width;
             cm.col_stride = Ni;
             data->ldes.push_back(cm);
-            data->lde_storage.push_back(std::move(lde));
+            if (!same_height) data->lde_storage.push_back(std::move(lde));
             m.buf.reset();  // consumed
         }
+        if (same_height) data->lde_storage.push_back(std::move(batch));
     }
     if (build_tree) mmcs_commit(ctx_, *data);
     return data;
@@ -312,8 +345,18 @@ DevBuf<Ef> TwoAdicFriPcs::open_reduce_slab(const PcsData& trace_data, const PcsD
         launch_bary_weights(ctx_, log_n, pts_mont, 2, weights.p, coset_gen);
         DevBuf<Ef> sums(&ctx_, raw.size());
         launch_bary_dots(ctx_, tr, log_n, weights.p, 2, sums.p);  // [col][point]
+        bool chunks_contiguous = true;  // commit() lays the chunk LDEs back to back
         for (uint32_t c = 0; c < qd; c++)
-            launch_bary_dots(ctx_, quotient_data.ldes[c], log_n, weights.p, 1, sums.p + 2 * w + 4 * c);
+            chunks_contiguous = chunks_contiguous && quotient_data.ldes[c].col_stride == quotient_data.ldes[0].col_stride &&
+                                quotient_data.ldes[c].d == quotient_data.ldes[0].d + (uint64_t)4 * c * quotient_data.ldes[0].col_stride;
+        if (chunks_contiguous && qd > 1) {
+            ColMat all = quotient_data.ldes[0];
+            all.width = 4 * qd;
+            launch_bary_dots(ctx_, all, log_n, weights.p, 1, sums.p + 2 * w);
+        } else {
+            for (uint32_t c = 0; c < qd; c++)
+                launch_bary_dots(ctx_, quotient_data.ldes[c], log_n, weights.p, 1, sums.p + 2 * w + 4 * c);
+        }
         d2h_sync(ctx_, raw.data(), sums.p, raw.size() * sizeof(Ef));
     }
     // p(z) = ((z/s)^n - 1)/n * sum_i p_i x_i/(z - x_i) on the coset s*H_n (s = 31 unless sharded)

@@ -32,6 +32,19 @@ def test_header_symbols_all_exported(lib):
     assert lib.ts_abi_version() == 4
 
 
+def test_device_count_and_null_context_diagnostics(lib):
+    import ctypes as C
+
+    import torch
+
+    n = lib.ts_device_count()
+    assert n == (torch.cuda.device_count() if torch.cuda.is_available() else 0)
+    # the diagnostics refuse a missing context with a status, like every entry point
+    v, ms = C.c_uint64(), C.c_double()
+    assert lib.ts_ctx_stat(None, 0, C.byref(v)) == 1            # TS_ERR_INVALID
+    assert lib.ts_bench_stage(None, 0, 10, 4, 1, 1, C.byref(ms)) == 1
+
+
 def test_no_cpu_fallback_without_device(lib):
     import torch
 

@@ -155,3 +155,22 @@ def test_tree_launch_shapes_agree(ctx, knobs):
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("PROBE ")][-1]
     assert json.loads(line[6:]) == here
+
+
+def test_stage_bench_and_context_counters(ctx):
+    # ts_bench_stage: sustained loops of one stage on resident data (tools/power_vs_working_set.py);
+    # ts_ctx_stat: the counters by index, refusing an unknown one
+    from tapstark_amd._lib import TsError
+
+    lde = ctx.bench_stage(0, 14, 8, 2, 3)
+    tree = ctx.bench_stage(1, 14, 8, 2, 3)
+    assert 0 < lde < 50 and 0 < tree < 50
+    with pytest.raises(TsError):
+        ctx.bench_stage(2, 14, 8, 2, 3)
+    with pytest.raises(TsError):
+        ctx.bench_stage(0, 26, 8, 2, 1)  # LDE larger than the two-adic subgroup
+    st = ctx.graph_stats()
+    assert [ctx.stat(i) for i in range(4)] == [st["replays"], st["fallbacks"], st["shapes"], st["pool_bytes"]]
+    assert ctx.stat(4) == st["reserve_failures"] and ctx.stat(5) >= 0
+    with pytest.raises(TsError):
+        ctx.stat(6)

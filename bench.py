@@ -1058,6 +1058,47 @@ def live_pmc_traffic(workload: str, kernel: str, timeout_s: float = 150.0):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def live_valu_instructions(workload: str, timeout_s: float = 150.0):
+    """SQ_INSTS_VALU summed over ONE proof of the workload, measured now: a child `rocprofv3 --pmc
+    SQ_INSTS_VALU` around tools/prof_prove.py (counters only).  The table builders, the selector kernel
+    and the synthetic trace generator are not part of a proof.  Returns (wave-instructions, note) or
+    (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    tmp = tempfile.mkdtemp(prefix="ts_sq_", dir="/tmp")
+    try:
+        n_proofs = 2  # the first builds the per-context tables; both are counted and halved
+        cmd = [exe, "--pmc", "SQ_INSTS_VALU", "--output-format", "csv", "-d", tmp, "-o", "sq", "--",
+               "/usr/bin/python3", os.path.join(ROOT, "tools", "prof_prove.py"), str(n_proofs), workload]
+        env = dict(os.environ, TMPDIR="/tmp")
+        r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+        files = glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True)
+        if r.returncode != 0 or not files:
+            return None, f"rocprofv3 --pmc SQ_INSTS_VALU failed (rc {r.returncode}): {(r.stderr or r.stdout)[-200:]}"
+        tot = 0.0
+        for row in csv.DictReader(open(files[0])):
+            if row["Counter_Name"] != "SQ_INSTS_VALU":
+                continue
+            if any(x in row["Kernel_Name"] for x in ("k_build_", "k_trace_", "k_selectors")):
+                continue
+            tot += float(row["Counter_Value"])
+        if tot <= 0:
+            return None, "no SQ_INSTS_VALU rows"
+        return tot / n_proofs, (f"live: rocprofv3 --pmc SQ_INSTS_VALU (a child process, {n_proofs} proofs, per proof; table "
+                                "builders, selectors and the trace generator excluded)")
+    except Exception as e:  # noqa: BLE001 -- the leg is optional
+        return None, repr(e)[:200]
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def latest_profile(pattern: str):
     import glob
     fs = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
@@ -1274,6 +1315,23 @@ def rank0_legs(ts, args, env, ctx, config, cair, lanes, S, pool, local_sync, mak
                                    "in this run; clock = SQ_BUSY_CYCLES / kernel durations of the same pass"}}
     except Exception:
         valu_issue = None
+    # ... measured right here where rocprofv3 can run as a child (TS_BENCH_LIVE_PMC=0: the committed figure)
+    if os.environ.get("TS_BENCH_LIVE_PMC", "1") != "0" and args.log_n == (22 if args.workload == "config4" else 20):
+        t_sq0 = time.perf_counter()
+        insts_live, note = live_valu_instructions(args.workload)
+        if insts_live is not None:
+            simds, clock = 1024, 2.0e9
+            floor_ms = insts_live * 4 / simds / clock * 1e3
+            valu_issue = {
+                "wave_instructions_per_proof": round(insts_live), "simds": simds, "cycles_per_instruction": 4,
+                "clock_hz_under_load": clock, "ms_per_proof_at_ceiling": round(floor_ms, 4),
+                "frac_of_ceiling": round(floor_ms / res["ms_per_step"], 4),
+                "source": {"note": note, "seconds": round(time.perf_counter() - t_sq0, 1),
+                           "committed_figure": None if valu_issue is None else
+                           {"wave_instructions_per_proof": valu_issue["wave_instructions_per_proof"],
+                            **valu_issue["source"]}}}
+        elif valu_issue is not None:
+            valu_issue["source"]["live_attempt"] = note
 
     # ---- the rate a caller sees who hands over HOST traces (never `value`): pinned buffer,
     # asynchronous upload on each lane's stream, the upload of one lane overlapping the proofs of the others

@@ -28,9 +28,10 @@ k_leaf_tree(Leaf leaf, uint32_t* __restrict__ tree, unsigned log_leaves, int fin
 void launch_merkle_tree_from(Context& ctx, uint32_t* tree, unsigned log_leaves, unsigned first_level,
                              DevChallenger* ch, uint32_t* root_out, Ef* beta_out);
 
-// Leaf digests and every level of a tree of 2^log_leaves >= 2^LEAF_TREE_MIN_LOG leaves.  One launch up
-// to 2^22 leaves; above, the leaf launch stops at its sub-roots (<= 2^16 of them) and the whole-tree
-// kernel finishes.  With `ch`, the workgroup that makes the root observes it and samples (as
+// Leaf digests and every level of a tree of 2^log_leaves >= 2^LEAF_TREE_MIN_LOG leaves.  One launch
+// while the workgroups leave at most 2^LEAF_TREE_MAX_LOG_SUB sub-roots (trees up to 2^16 .. 2^18
+// leaves, by leaves per lane); above, the leaf launch stops at its sub-roots and the whole-tree kernel
+// finishes.  With `ch`, the workgroup that makes the root observes it and samples (as
 // launch_merkle_levels).
 template <class Leaf>
 void launch_leaf_tree(Context& ctx, const Leaf& leaf, uint32_t* tree, unsigned log_leaves, DevChallenger* ch,

@@ -18,7 +18,7 @@ python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_config3_k20.json 2> $
 python3 bench.py --workload config2 --streams 8 --steps 48 --warmup 8 --no-cpu-baseline > $O/bench_config2.json 2>> $O/bench.err
 python3 bench.py --workload config4 --streams 1 --steps 6 --warmup 2 --windows 1 --no-cpu-baseline > $O/bench_config4.json 2>> $O/bench.err
 python3 bench.py --workload config5 --streams 2 --steps 8 --warmup 2 --windows 2 --no-cpu-baseline > $O/bench_config5.json 2>> $O/bench.err
-TS_BENCH_SHARE_GPU=1 TS_BENCH_SHARD_STEPS=2 python3 bench.py --gpus 2 --steps 8 --warmup 2 --headline-only > $O/bench_gpus2_shared_gpu_rehearsal.json 2>> $O/bench.err
+TS_BENCH_SHARE_GPU=1 TS_BENCH_SHARD_STEPS=2 python3 bench.py --gpus 2 --steps 8 --warmup 2 > $O/bench_gpus2_shared_gpu_rehearsal.json 2>> $O/bench.err
 TS_BENCH_FORCE_SHARD_BLOCK=1 TS_BENCH_SHARD_STEPS=2 python3 bench.py --headline-only > $O/bench_rccl_world1_blocks.json 2>> $O/bench.err
 python3 bench.py --workload fold > $O/fold_even_odd.json 2>> $O/bench.err
 echo "benches done"

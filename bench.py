@@ -1025,7 +1025,7 @@ def live_pmc_traffic(workload: str, kernel: str, timeout_s: float = 150.0):
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(tmp, counter)
             cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "pmc", "--",
-                   "/usr/bin/python3", os.path.join(ROOT, "tools", "prof_prove.py"), "2", workload]
+                   sys.executable or "/usr/bin/python3", os.path.join(ROOT, "tools", "prof_prove.py"), "2", workload]
             env = dict(os.environ, TMPDIR="/tmp")
             env.pop("TS_BENCH_SELF_LAUNCHED", None)
             r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
@@ -1076,7 +1076,7 @@ def live_valu_instructions(workload: str, timeout_s: float = 150.0):
     try:
         n_proofs = 2  # the first builds the per-context tables; both are counted and halved
         cmd = [exe, "--pmc", "SQ_INSTS_VALU", "--output-format", "csv", "-d", tmp, "-o", "sq", "--",
-               "/usr/bin/python3", os.path.join(ROOT, "tools", "prof_prove.py"), str(n_proofs), workload]
+               sys.executable or "/usr/bin/python3", os.path.join(ROOT, "tools", "prof_prove.py"), str(n_proofs), workload]
         env = dict(os.environ, TMPDIR="/tmp")
         r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
         files = glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True)

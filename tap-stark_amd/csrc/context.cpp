@@ -35,6 +35,7 @@ Context::~Context() {
     for (auto& kv : free_blocks) (void)hipFree(kv.second);
     for (auto& kv : live_blocks) (void)hipFree(kv.first);
     if (h_pinned) (void)hipHostFree(h_pinned);
+    if (h_mailbox) (void)hipHostFree(h_mailbox);
     if (h_arena) (void)hipHostFree(h_arena);
     if (stream) (void)hipStreamDestroy(stream);
 }
@@ -175,6 +176,17 @@ const void* Context::stage(const void* src, size_t bytes) {
     void* p = h_arena + h_arena_off;
     memcpy(p, src, bytes);
     h_arena_off += need;
+    return p;
+}
+
+uint32_t* Context::mailbox(size_t words) {
+    constexpr size_t WORDS = 16384;  // 64 KiB
+    TS_REQUIRE(words <= WORDS / 4, TS_ERR_INVALID, "mailbox: message too large");
+    if (!h_mailbox) TS_HIP(hipHostMalloc((void**)&h_mailbox, WORDS * 4, hipHostMallocDefault));
+    const size_t need = (words + 15) & ~(size_t)15;
+    if (mailbox_off + need > WORDS) mailbox_off = 0;  // every earlier slot has been read: its reader synced
+    uint32_t* p = h_mailbox + mailbox_off;
+    mailbox_off += need;
     return p;
 }
 

@@ -95,6 +95,15 @@ struct Context {
     uint32_t* d_ticket = nullptr;
     uint32_t* ticket();
 
+    // Mailbox: a page of page-locked host memory that kernels write small results into directly (a
+    // Merkle root, the opened-value sums): the host reads them after a stream sync, with no copy
+    // kernel in between (a D2H hipMemcpyAsync of 32 bytes is a launch of its own: ~7 us of a proof's
+    // critical path each time).  Slots are handed out round-robin; a slot is only reused after the
+    // sync that read it.
+    uint32_t* h_mailbox = nullptr;
+    size_t mailbox_off = 0;
+    uint32_t* mailbox(size_t words);
+
     // pinned host staging
     void* h_pinned = nullptr;
     size_t h_pinned_bytes = 0;

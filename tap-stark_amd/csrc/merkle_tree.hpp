@@ -255,18 +255,21 @@ struct Tree {
         }
         // device-resident transcript (fri/src/prover.rs:114-116): the workgroup that produced the root
         // observes it and samples the next challenge
-        if (finisher && ch != nullptr && threadIdx.x == 0) {
+        // (root_out may be page-locked host memory: the commitment goes straight to the caller's mailbox)
+        if (finisher && (ch != nullptr || root_out != nullptr) && threadIdx.x == 0) {
             uint32_t root[8];
             for (int k = 0; k < 8; k++) {
                 root[k] = top[k * CH];
-                root_out[k] = root[k];
+                if (root_out != nullptr) root_out[k] = root[k];
             }
-            // (the parked-node image is free by now: the sponge runs on a copy there, see chal_dev.hpp)
-            DevChallenger* lc = reinterpret_cast<DevChallenger*>(lds.keep);
-            dc_copy(lc, ch);
-            const Ef beta = dc_observe_root_and_sample(lc, root);
-            dc_copy(ch, lc);
-            *reinterpret_cast<uint4*>(beta_out) = make_uint4(beta.c[0], beta.c[1], beta.c[2], beta.c[3]);
+            if (ch != nullptr) {
+                // (the parked-node image is free by now: the sponge runs on a copy there, see chal_dev.hpp)
+                DevChallenger* lc = reinterpret_cast<DevChallenger*>(lds.keep);
+                dc_copy(lc, ch);
+                const Ef beta = dc_observe_root_and_sample(lc, root);
+                dc_copy(ch, lc);
+                *reinterpret_cast<uint4*>(beta_out) = make_uint4(beta.c[0], beta.c[1], beta.c[2], beta.c[3]);
+            }
         }
     }
 

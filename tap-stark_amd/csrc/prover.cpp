@@ -85,7 +85,11 @@ void mmcs_commit(Context& ctx, PcsData& data) {
             if (g.total) groups.push_back(g);
         }
         data.col_table = DevBuf<const uint32_t*>(&ctx, cols.size());
-        h2d(ctx, data.col_table.p, cols.data(), cols.size() * sizeof(const uint32_t*));
+        bool table_uploaded = false;
+        auto upload_table = [&] {  // only the leaf kernels that address columns through the table read it
+            if (!table_uploaded) h2d(ctx, data.col_table.p, cols.data(), cols.size() * sizeof(const uint32_t*));
+            table_uploaded = true;
+        };
         auto group_mats = [&](const Group& g) {
             LeafMats lm;
             memset(&lm, 0, sizeof lm);
@@ -103,19 +107,28 @@ void mmcs_commit(Context& ctx, PcsData& data) {
                                  cm.d == first->d + (uint64_t)wsum * first->col_stride;
                     wsum += cm.width;
                 }
-            if (first && contiguous && wsum <= 256) {
+            static const bool strided_knob = [] { const char* e = getenv("TS_LEAF_STRIDED"); return !e || atoi(e) != 0; }();
+            if (!strided_knob) upload_table();  // TS_LEAF_STRIDED=0 sends even one matrix through the table kernels
+            if (first && contiguous && wsum >= 1 && wsum <= 256) {
                 lm.n_mats = 1;
                 lm.d[0] = first->d;
                 lm.col_stride[0] = first->col_stride;
                 lm.width[0] = wsum;
+            } else {
+                upload_table();  // pointer-table leaf kernels (several scattered matrices, rows wider than 256)
             }
             return lm;
         };
         auto group_leaves = [&](const Group& g, uint32_t* digests) {
             launch_leaf_hash(ctx, group_mats(g), g.height, digests);
         };
+        uint32_t* mail = nullptr;
         if (uniform) {  // leaves and every level in one launch (leaf_tree.hpp)
-            launch_commit_tree(ctx, group_mats(groups[0]), log_H, data.tree.p);
+            // the kernel that makes the root writes it into the context's mailbox (host memory) as well:
+            // no copy kernel between the tree and the host's next transcript step
+            static const bool no_mail = [] { const char* e = getenv("TS_NO_MAILBOX"); return e && atoi(e) != 0; }();
+            if (log_H >= 1 && !no_mail) mail = ctx.mailbox(8);
+            launch_commit_tree(ctx, group_mats(groups[0]), log_H, data.tree.p, nullptr, mail, nullptr);
         } else {
             group_leaves(groups[0], data.tree.p);
             DevBuf<uint32_t> inj(&ctx, 8 * (N / 2));
@@ -132,7 +145,12 @@ void mmcs_commit(Context& ctx, PcsData& data) {
                 }
             }
         }
-        d2h_sync(ctx, data.root, data.tree.p + 8 * (merkle_total_digests(log_H) - 1), 32);
+        if (mail) {
+            ctx.sync();
+            memcpy(data.root, mail, 32);
+        } else {
+            d2h_sync(ctx, data.root, data.tree.p + 8 * (merkle_total_digests(log_H) - 1), 32);
+        }
     }
 }
 
@@ -280,9 +298,13 @@ std::vector<DeviceMatrix> TwoAdicFriPcs::quotient_chunks_slab(const ColMat& lde_
             cur = ef_mul(cur, am);
         }
     }
-    DevBuf<uint32_t> d_consts(&ctx_, consts.size()), d_apow(&ctx_, apow.size());
+    // one upload for both (a small host-to-device copy is a launch of its own on the stream)
+    consts.resize((consts.size() + 3) & ~(size_t)3, 0);  // the powers stay 16-byte aligned
+    const size_t n_consts = consts.size();
+    consts.insert(consts.end(), apow.begin(), apow.end());
+    DevBuf<uint32_t> d_consts(&ctx_, consts.size());
     h2d(ctx_, d_consts.p, consts.data(), consts.size() * 4);
-    h2d(ctx_, d_apow.p, apow.data(), apow.size() * 4);
+    struct { uint32_t* p; } d_apow{d_consts.p + n_consts};
 
     std::vector<DeviceMatrix> chunks(qd);
     QuotOut qo;
@@ -343,7 +365,8 @@ DevBuf<Ef> TwoAdicFriPcs::open_reduce_slab(const PcsData& trace_data, const PcsD
         StageTimer t(&ctx_, "compute opened values with Lagrange interpolation");
         DevBuf<Ef> weights(&ctx_, 2 * n);
         launch_bary_weights(ctx_, log_n, pts_mont, 2, weights.p, coset_gen);
-        DevBuf<Ef> sums(&ctx_, raw.size());
+        // the last kernels of the stage write the sums straight into the context's mailbox (host memory)
+        struct { Ef* p; } sums{reinterpret_cast<Ef*>(ctx_.mailbox(4 * raw.size()))};
         launch_bary_dots(ctx_, tr, log_n, weights.p, 2, sums.p);  // [col][point]
         bool chunks_contiguous = true;  // commit() lays the chunk LDEs back to back
         for (uint32_t c = 0; c < qd; c++)
@@ -357,7 +380,8 @@ DevBuf<Ef> TwoAdicFriPcs::open_reduce_slab(const PcsData& trace_data, const PcsD
             for (uint32_t c = 0; c < qd; c++)
                 launch_bary_dots(ctx_, quotient_data.ldes[c], log_n, weights.p, 1, sums.p + 2 * w + 4 * c);
         }
-        d2h_sync(ctx_, raw.data(), sums.p, raw.size() * sizeof(Ef));
+        ctx_.sync();
+        memcpy(raw.data(), sums.p, raw.size() * sizeof(Ef));
     }
     // p(z) = ((z/s)^n - 1)/n * sum_i p_i x_i/(z - x_i) on the coset s*H_n (s = 31 unless sharded)
     const uint32_t gen_inv = inv_canon(coset_gen);
@@ -388,8 +412,7 @@ DevBuf<Ef> TwoAdicFriPcs::open_reduce_slab(const PcsData& trace_data, const PcsD
             cur = ef_mul(cur, am);
         }
     }
-    DevBuf<uint32_t> d_apow(&ctx_, apow.size());
-    h2d(ctx_, d_apow.p, apow.data(), apow.size() * 4);
+    // (uploaded below, together with the chunk weights: one copy on the stream instead of two)
     auto reduced_ys = [&](const Ef* ys, uint32_t width) {  // dot_product(alpha.powers(), ys), :372
         Ef acc = ef_zero();
         for (uint32_t i = 0; i < width; i++) {
@@ -433,9 +456,11 @@ DevBuf<Ef> TwoAdicFriPcs::open_reduce_slab(const PcsData& trace_data, const PcsD
             }
             num_reduced += 4;
         }
-        DevBuf<uint32_t> d_cw(&ctx_, cw.size());
-        h2d(ctx_, d_cw.p, cw.data(), cw.size() * 4);
-        a.chunk_w = d_cw.p;
+        const size_t n_apow = apow.size();
+        apow.insert(apow.end(), cw.begin(), cw.end());
+        DevBuf<uint32_t> d_apow(&ctx_, apow.size());
+        h2d(ctx_, d_apow.p, apow.data(), apow.size() * 4);
+        a.chunk_w = d_apow.p + n_apow;
         launch_reduce_fused(ctx_, tr, log_N, d_apow.p, a, ro.p);
     }
     return ro;
@@ -736,8 +761,7 @@ void TwoAdicFriPcs::fri_prove(std::vector<DevBuf<Ef>>& inputs, const std::vector
     const uint32_t Q = fri.num_queries;
     std::vector<uint32_t> indices(std::max(Q, 1u));
     for (uint32_t q = 0; q < Q; q++) indices[q] = (uint32_t)challenger.sample_bits(log_max_height);
-    DevBuf<uint32_t> d_idx(&ctx, indices.size());
-    h2d(ctx, d_idx.p, indices.data(), indices.size() * 4);
+    // (uploaded below together with the FRI gather descriptors: one copy on the stream)
 
     // gather everything into one buffer, one D2H
     const size_t n_in_rounds = input_rounds.size();
@@ -758,17 +782,6 @@ void TwoAdicFriPcs::fri_prove(std::vector<DevBuf<Ef>>& inputs, const std::vector
     for (size_t k = 0; k < o_pass.size(); k++) {
         o_pass[k] = off; off += (size_t)Q * 8;
     }
-    DevBuf<uint32_t> d_out(&ctx, std::max<size_t>(off, 1));
-    for (size_t k = 0; k < o_pass.size(); k++)  // the pair holding element index >> shift
-        launch_gather_ef_pairs(ctx, in_ptr[k], d_idx.p, Q, log_max_height - log_lens[k] + 1,
-                               d_out.p + o_pass[k]);
-    for (size_t k = 0; k < n_in_rounds; k++) {
-        // two_adic_pcs.rs:403-409: bits_reduced = log_global_max_height - log_max_height(batch)
-        const unsigned bits_reduced = log_max_height - input_rounds[k]->log_height;
-        launch_gather_rows(ctx, lms[k], d_idx.p, Q, bits_reduced, d_out.p + o_rows[k]);
-        launch_gather_paths(ctx, input_rounds[k]->tree.p, input_rounds[k]->log_height, d_idx.p, Q,
-                            bits_reduced, d_out.p + o_path[k]);
-    }
     // bf_answer_query :69-90: index_i = index >> i >> 1, all rounds in one launch
     std::vector<FriGatherDesc> descs(std::max(R, 1u));
     uint32_t max_ll = 0;
@@ -781,8 +794,25 @@ void TwoAdicFriPcs::fri_prove(std::vector<DevBuf<Ef>>& inputs, const std::vector
         descs[r].out_path = o_fpath[r];
         max_ll = std::max(max_ll, rounds[r].log_leaves);
     }
-    DevBuf<FriGatherDesc> d_descs(&ctx, descs.size());
-    h2d(ctx, d_descs.p, descs.data(), descs.size() * sizeof(FriGatherDesc));
+    // descriptors, then the indices, in ONE upload
+    std::vector<unsigned char> up(descs.size() * sizeof(FriGatherDesc) + indices.size() * 4);
+    memcpy(up.data(), descs.data(), descs.size() * sizeof(FriGatherDesc));
+    memcpy(up.data() + descs.size() * sizeof(FriGatherDesc), indices.data(), indices.size() * 4);
+    DevBuf<unsigned char> d_up(&ctx, up.size());
+    h2d(ctx, d_up.p, up.data(), up.size());
+    struct { FriGatherDesc* p; } d_descs{reinterpret_cast<FriGatherDesc*>(d_up.p)};
+    struct { uint32_t* p; } d_idx{reinterpret_cast<uint32_t*>(d_up.p + descs.size() * sizeof(FriGatherDesc))};
+    DevBuf<uint32_t> d_out(&ctx, std::max<size_t>(off, 1));
+    for (size_t k = 0; k < o_pass.size(); k++)  // the pair holding element index >> shift
+        launch_gather_ef_pairs(ctx, in_ptr[k], d_idx.p, Q, log_max_height - log_lens[k] + 1,
+                               d_out.p + o_pass[k]);
+    for (size_t k = 0; k < n_in_rounds; k++) {
+        // two_adic_pcs.rs:403-409: bits_reduced = log_global_max_height - log_max_height(batch)
+        const unsigned bits_reduced = log_max_height - input_rounds[k]->log_height;
+        launch_gather_rows(ctx, lms[k], d_idx.p, Q, bits_reduced, d_out.p + o_rows[k]);
+        launch_gather_paths(ctx, input_rounds[k]->tree.p, input_rounds[k]->log_height, d_idx.p, Q,
+                            bits_reduced, d_out.p + o_path[k]);
+    }
     launch_gather_fri(ctx, d_descs.p, R, max_ll, d_idx.p, Q, d_out.p);
     std::vector<uint32_t> g(std::max<size_t>(off, 1));
     d2h_sync(ctx, g.data(), d_out.p, off * 4);

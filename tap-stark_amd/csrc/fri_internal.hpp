@@ -18,8 +18,12 @@ struct FriCommit {
     std::vector<FriRound> rounds;
     std::vector<DevBuf<Ef>> keep_vecs;
     std::vector<DevBuf<uint32_t>> keep_trees;
-    DevBuf<uint32_t> d_chal, d_roots;
-    DevBuf<Ef> d_betas, d_final;
+    // challenger | round roots | final values in ONE block: one D2H brings all three back at the end
+    // (three copies were three launches on the stream); the pointers below look into it
+    DevBuf<uint32_t> d_block;
+    struct { uint32_t* p = nullptr; } d_chal, d_roots;
+    struct { Ef* p = nullptr; } d_final;
+    DevBuf<Ef> d_betas;
     uint32_t R_total = 0;
     uint64_t final_len = 0;
     DevChallenger* dch() { return reinterpret_cast<DevChallenger*>(d_chal.p); }

@@ -496,11 +496,14 @@ void fri_commit_begin(Context& ctx, const FriConfig& fri, unsigned log_max_heigh
     st.R_total = log_max_height - fri.log_blowup;
     DevChallenger hc;
     challenger.export_dev(hc);
-    st.d_chal = DevBuf<uint32_t>(&ctx, sizeof(DevChallenger) / 4);
+    static_assert(sizeof(DevChallenger) <= 64 * 4, "the challenger's slot in the block");
+    const size_t n_roots = std::max<size_t>(8 * (size_t)st.R_total, 8);
+    st.d_block = DevBuf<uint32_t>(&ctx, 64 + n_roots + 4 * (size_t)fri.blowup());
+    st.d_chal.p = st.d_block.p;
+    st.d_roots.p = st.d_block.p + 64;
+    st.d_final.p = reinterpret_cast<Ef*>(st.d_block.p + 64 + n_roots);  // 16-byte aligned: 64 + 8 R words
     h2d(ctx, st.d_chal.p, &hc, sizeof hc);
-    st.d_roots = DevBuf<uint32_t>(&ctx, std::max<size_t>(8 * (size_t)st.R_total, 8));
     st.d_betas = DevBuf<Ef>(&ctx, std::max<size_t>(st.R_total, 1));
-    st.d_final = DevBuf<Ef>(&ctx, fri.blowup());
 }
 
 void fri_commit_rounds(Context& ctx, const FriConfig& fri, DevBuf<Ef> folded, uint64_t len,
@@ -593,12 +596,11 @@ Ef fri_commit_finish(Context& ctx, const FriConfig& fri, BfChallenger& challenge
     std::vector<Ef> fin(st.final_len);
     std::vector<uint32_t> roots(std::max<size_t>(8 * (size_t)R_total, 8));
     DevChallenger hc;
-    TS_HIP(hipMemcpyAsync(fin.data(), st.d_final.p, fin.size() * sizeof(Ef), hipMemcpyDeviceToHost,
-                          ctx.stream));
-    if (R_total)
-        TS_HIP(hipMemcpyAsync(roots.data(), st.d_roots.p, 32 * (size_t)R_total, hipMemcpyDeviceToHost,
-                              ctx.stream));
-    d2h_sync(ctx, &hc, st.d_chal.p, sizeof hc);
+    std::vector<uint32_t> block(st.d_block.n);
+    d2h_sync(ctx, block.data(), st.d_block.p, block.size() * 4);
+    memcpy(&hc, block.data(), sizeof hc);
+    memcpy(roots.data(), block.data() + 64, roots.size() * 4);
+    memcpy(fin.data(), block.data() + 64 + roots.size(), fin.size() * sizeof(Ef));
     challenger.import_dev(hc);
     for (uint32_t r = 0; r < R_total; r++) memcpy(st.rounds[r].root, &roots[8 * (size_t)r], 32);
     const Ef final_poly = fin[0];

@@ -1475,6 +1475,15 @@ def rank0_legs(ts, args, env, ctx, config, cair, lanes, S, pool, local_sync, mak
                         "register-resident ALU loops hold the clock in `clocks.alu_loop_butterflies`"}
     except Exception:  # noqa: BLE001
         pass
+    # energy: under the power cap this, not the issue fill, is what a step costs
+    try:
+        ps = clocks["prover_sustained"]
+        idle_w = clocks["idle"]["socket_power_w_median"]
+        clocks["energy_per_proof_j"] = round(ps["socket_power_w_median"] * ps["ms_per_step"] * 1e-3, 3)
+        clocks["energy_per_proof_above_idle_j"] = round((ps["socket_power_w_median"] - idle_w) * ps["ms_per_step"] * 1e-3, 3)
+        clocks["nj_per_trace_cell"] = round(clocks["energy_per_proof_j"] / float(n * w) * 1e9, 2)
+    except Exception:  # noqa: BLE001
+        pass
     # (the contract: timed on rank 0 at N = 1 only)
     same = args.workload == "config3" and args.log_n == 20 and timed_proof is not None
     cpu = None if (args.no_cpu_baseline or env.world > 1) else cpu_baseline(timed_proof.words if same else None)

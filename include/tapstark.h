@@ -473,7 +473,8 @@ ts_status ts_verify_tap(const ts_fri_config* cfg, const ts_air* air, ts_challeng
                         size_t n_scripts, int* verdict);
 
 /* Measurement aid: the whole-chip rate of NTT butterflies (kind 0), Blake3 compressions (kind 1) or
- * SHA-256 compressions (kind 2) with no memory traffic, using the library's own arithmetic -- the integer-ALU ceiling bench.py
+ * SHA-256 compressions (kind 2) with no memory traffic -- kinds 3 / 4: the butterflies with the LDS traffic
+ * of a contiguous NTT pass added (4-byte / 16-byte accesses; measurement of what LDS costs in power) --, using the library's own arithmetic -- the integer-ALU ceiling bench.py
  * reports beside the achieved rates. */
 ts_status ts_bench_alu(ts_ctx* ctx, int kind, double* units_per_second);
 
@@ -481,7 +482,8 @@ ts_status ts_bench_alu(ts_ctx* ctx, int kind, double* units_per_second);
  * milliseconds per repetition (HIP events on the context's stream).  stage 0: the coset LDE of a
  * 2^log_n x width matrix (fri/src/two_adic_pcs.rs:233-241: all NTT passes, every coset); stage 1: the
  * hashing of BFMmcs::commit (basic/src/mmcs/bf_mmcs.rs:22-35) over a 2^(log_n + log_blowup) x width
- * matrix.  What tools/power_per_stage.py samples clock and power over, per kernel family and per
+ * matrix; stages 2, 3, 4: one pass of that LDE alone (inverse contiguous stages / strided middle /
+ * forward contiguous stages; log_n > 12).  What tools/power_per_stage.py samples clock and power over, per kernel family and per
  * working-set size. */
 ts_status ts_bench_stage(ts_ctx* ctx, int stage, unsigned log_n, uint32_t width, unsigned log_blowup,
                          uint32_t reps, double* ms_per_rep);

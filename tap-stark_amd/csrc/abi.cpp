@@ -250,14 +250,25 @@ ts_status ts_bench_stage(ts_ctx* ctx, int stage, unsigned log_n, uint32_t width,
     if (!ctx || !ms_per_rep) return TS_ERR_INVALID;
     return guard(ctx, [&] {
         ts::Context& c = ctx->ctx;
-        TS_REQUIRE((stage == 0 || stage == 1) && width >= 1 && width <= 256 && reps >= 1 && log_n >= 1 &&
+        TS_REQUIRE(stage >= 0 && stage <= 4 && width >= 1 && width <= 256 && reps >= 1 && log_n >= 1 &&
                        log_n + log_blowup <= 27,
-                   ts::TS_ERR_INVALID, "bench_stage: stage 0 | 1, width 1..256, log_n + log_blowup <= 27");
+                   ts::TS_ERR_INVALID, "bench_stage: stage 0 .. 4, width 1..256, log_n + log_blowup <= 27");
+        // stages 2, 3, 4: ONE pass of the LDE alone (inverse contiguous / strided middle / forward
+        // contiguous; two-pass shapes only, log_n > 12), on whatever the buffers hold
+        struct MaskGuard {
+            ts::Context& c;
+            ~MaskGuard() { c.lde_pass_mask = 7; }
+        } guard_mask{c};
+        if (stage >= 2) {
+            TS_REQUIRE(log_n > 12, ts::TS_ERR_INVALID, "bench_stage: single LDE passes exist for log_n > 12 only");
+            c.lde_pass_mask = 1u << (stage - 2);
+        }
+        const bool is_lde = stage != 1;
         const uint64_t n = 1ull << log_n, N = n << log_blowup;
         c.ensure_twiddles(log_n + log_blowup);
-        ts::DevBuf<uint32_t> lde(&c, (size_t)width * N), in(&c, stage == 0 ? (size_t)width * n : 1);
+        ts::DevBuf<uint32_t> lde(&c, (size_t)width * N), in(&c, is_lde ? (size_t)width * n : 1);
         TS_HIP(hipMemsetAsync(lde.p, 0x11, (size_t)width * N * 4, c.stream));  // 0x11111111 < p
-        if (stage == 0) TS_HIP(hipMemsetAsync(in.p, 0x11, (size_t)width * n * 4, c.stream));
+        if (is_lde) TS_HIP(hipMemsetAsync(in.p, 0x11, (size_t)width * n * 4, c.stream));
         ts::DevBuf<uint32_t> tree(&c, stage == 1 ? ts::merkle_total_digests(log_n + log_blowup) * 8 : 1);
         std::vector<const uint32_t*> cols(width);
         for (uint32_t k = 0; k < width; k++) cols[k] = lde.p + (uint64_t)k * N;
@@ -273,7 +284,7 @@ ts_status ts_bench_stage(ts_ctx* ctx, int stage, unsigned log_n, uint32_t width,
         lm.total_width = width;
         lm.cols = d_cols.p;
         auto once = [&] {
-            if (stage == 0) ts::coset_lde(c, in.p, n, width, log_n, log_blowup, ts::GENERATOR, lde.p, N);
+            if (is_lde) ts::coset_lde(c, in.p, n, width, log_n, log_blowup, ts::GENERATOR, lde.p, N);
             else ts::launch_commit_tree(c, lm, log_n + log_blowup, tree.p);
         };
         once();  // tables, first-touch

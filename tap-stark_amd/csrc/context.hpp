@@ -95,6 +95,10 @@ struct Context {
     uint32_t* d_ticket = nullptr;
     uint32_t* ticket();
 
+    // measurement only (ts_bench_stage): which of the three LDE passes coset_lde launches (bit 0 inverse
+    // contiguous, 1 strided middle, 2 forward contiguous); 7 everywhere else
+    unsigned lde_pass_mask = 7;
+
     // Mailbox: a page of page-locked host memory that kernels write small results into directly (a
     // Merkle root, the opened-value sums): the host reads them after a stream sync, with no copy
     // kernel in between (a D2H hipMemcpyAsync of 32 bytes is a launch of its own: ~7 us of a proof's

@@ -694,7 +694,9 @@ void coset_lde(Context& ctx, uint32_t* evals, uint64_t in_col_stride, uint32_t n
         // the vectorised chunk loads need 16-byte aligned columns
         TS_REQUIRE(in_col_stride % 4 == 0 && out_col_stride % 4 == 0, TS_ERR_INVALID,
                    "coset_lde: column strides must be multiples of 4 elements");
-        {
+        // (ctx.lde_pass_mask: measurement only -- ts_bench_stage runs one of the three passes alone, on
+        // whatever the buffers hold, to sample its clock and power; every product path leaves it at 7)
+        if (ctx.lde_pass_mask & 1u) {
             // (stage names: the sharded prover reports where a rank's time goes)
             StageTimer t(&ctx, "lde: inverse NTT, contiguous stages");
             const dim3 g(1u << sA, ncols);
@@ -717,7 +719,8 @@ void coset_lde(Context& ctx, uint32_t* evals, uint64_t in_col_stride, uint32_t n
 #define TS_MID_ARGS                                                                            \
     (const uint32_t*)evals, in_col_stride, out, out_col_stride, log_n, sA, log_T, (unsigned)LM, \
         beta0, n_beta, W, Winv, scale
-        if (sA == 14)
+        if (!(ctx.lde_pass_mask & 2u)) {
+        } else if (sA == 14)
             TS_LAUNCH(ctx, (k_lde_mid<0, 16384>), grid, dim3(NT_MID), 0, TS_MID_ARGS);
         else if (plan2 && plan2_tile == 8192)
             TS_LAUNCH(ctx, (k_lde_mid<2, 8192>), grid1, dim3(NT_MID), 0, TS_MID_ARGS);
@@ -739,7 +742,8 @@ void coset_lde(Context& ctx, uint32_t* evals, uint64_t in_col_stride, uint32_t n
         // chunks per workgroup of the 16384-element forward pass: measured 12.49 (1) / 13.34 (2: spills) /
         // 12.22 ms (4) per proof
         const int fwd_cpw = lde_knobs().fwd_cpw;
-        if (LM == 12)
+        if (!(ctx.lde_pass_mask & 4u)) {
+        } else if (LM == 12)
             TS_LAUNCH(ctx, k_lde_fwd_contig<12>, gf, dim3(chunk_threads(12)), 0, out, out_col_stride, log_n, W);
         else if (LM == 13)
             TS_LAUNCH(ctx, k_lde_fwd_contig<13>, gf, dim3(chunk_threads(13)), 0, out, out_col_stride, log_n, W);

@@ -165,8 +165,14 @@ def test_stage_bench_and_context_counters(ctx):
     lde = ctx.bench_stage(0, 14, 8, 2, 3)
     tree = ctx.bench_stage(1, 14, 8, 2, 3)
     assert 0 < lde < 50 and 0 < tree < 50
+    for single_pass in (2, 3, 4):  # one LDE pass alone (log_n > 12 only)
+        assert 0 < ctx.bench_stage(single_pass, 14, 8, 2, 3) < lde + 1
     with pytest.raises(TsError):
-        ctx.bench_stage(2, 14, 8, 2, 3)
+        ctx.bench_stage(5, 14, 8, 2, 3)
+    with pytest.raises(TsError):
+        ctx.bench_stage(3, 10, 8, 2, 3)
+    lde2 = ctx.bench_stage(0, 14, 8, 2, 3)  # the pass mask is back at "all three"
+    assert 0.3 * lde < lde2 < 3 * lde
     with pytest.raises(TsError):
         ctx.bench_stage(0, 26, 8, 2, 1)  # LDE larger than the two-adic subgroup
     st = ctx.graph_stats()

@@ -65,4 +65,18 @@ for log_n in (17, 18, 19, 20):
     r.update(log_n=log_n, butterflies=bf, ps_per_butterfly=round(1e9 * r["ms_per_rep"] / bf, 4))
     out["rows_by_height"].append(r)
     print(r, file=sys.stderr, flush=True)
+# Which of the three LDE passes sits at the cap?  Each pass alone (ts_bench_stage 2 / 3 / 4), 2^20 x 64.
+LOG_N = 20
+out["rows_by_pass"] = []
+for st, nm in ((2, "k_intt_contig (inverse, contiguous stages)"), (3, "k_lde_mid (strided inverse + scale + strided forward, 4 cosets)"),
+               (4, "k_lde_fwd_contig (forward, contiguous stages, 4 cosets)")):
+    one = ctx.bench_stage(st, LOG_N, 64, B, 2)
+    reps = max(2, int(800 / one))
+    with smp:
+        ms = ctx.bench_stage(st, LOG_N, 64, B, reps)
+    s = smp.summary()
+    r = dict(stage=nm, reps=reps, ms_per_rep=round(ms, 4), gfxclk_mhz_median=s.get("gfxclk_mhz_median"),
+             socket_power_w_median=s.get("socket_power_w_median"), socket_power_w_max=s.get("socket_power_w_max"))
+    out["rows_by_pass"].append(r)
+    print(r, file=sys.stderr, flush=True)
 print(json.dumps(out, indent=1))

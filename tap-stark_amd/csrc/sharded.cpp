@@ -92,13 +92,28 @@ std::unique_ptr<ShardedData> commit_sharded(Shard& sh, std::vector<DeviceMatrix>
     loc.log_height = log_rows;
     {
         StageTimer t(&ctx, "coset_lde");
+        // a batch (the quotient chunks) in one allocation, matrix after matrix, as TwoAdicFriPcs::commit
+        // does: the slab's leaf hash then takes it as one strided matrix
+        size_t total_w = 0;
+        for (auto& m : evals) total_w += m.width;
+        DevBuf<uint32_t> batch;
+        if (evals.size() > 1) batch = DevBuf<uint32_t>(&ctx, total_w * rows);
+        size_t batch_col = 0;
         for (size_t i = 0; i < evals.size(); i++) {
             DeviceMatrix& m = evals[i];
             TS_REQUIRE(m.height == n && m.width >= 1 && m.buf.p, TS_ERR_INVALID,
                        "sharded commit: matrices of one height expected");
             DevBuf<uint32_t> colmajor;
             uint32_t* ev = m.buf.p;
-            DevBuf<uint32_t> lde(&ctx, (size_t)m.width * rows);
+            struct { uint32_t* p; } lde{nullptr};
+            DevBuf<uint32_t> own;
+            if (batch.p) {
+                lde.p = batch.p + batch_col * rows;
+                batch_col += m.width;
+            } else {
+                own = DevBuf<uint32_t>(&ctx, (size_t)m.width * rows);
+                lde.p = own.p;
+            }
             const uint32_t shift = mul(GENERATOR, inv_canon(domain_shifts[i]));  // two_adic_pcs.rs:235
             // The inverse transform is replicated: every rank transposes and inverts every column, then
             // runs the forward transforms of its own cosets.  (Rounds 2-4 carried an option that did the
@@ -124,9 +139,10 @@ std::unique_ptr<ShardedData> commit_sharded(Shard& sh, std::vector<DeviceMatrix>
             cm.width = m.width;
             cm.col_stride = rows;
             loc.ldes.push_back(cm);
-            loc.lde_storage.push_back(std::move(lde));
+            if (own.p) loc.lde_storage.push_back(std::move(own));
             m.buf.reset();  // consumed
         }
+        if (batch.p) loc.lde_storage.push_back(std::move(batch));
     }
     if (mix) {
         StageTimer t(&ctx, "mix chunk LDEs (local quotient)");
@@ -153,7 +169,20 @@ std::unique_ptr<ShardedData> commit_sharded(Shard& sh, std::vector<DeviceMatrix>
             for (uint32_t c = 0; c < cm.width; c++) cols.push_back(cm.d + (uint64_t)c * cm.col_stride);
         loc.col_table = DevBuf<const uint32_t*>(&ctx, cols.size());
         h2d(ctx, loc.col_table.p, cols.data(), cols.size() * sizeof(const uint32_t*));
-        launch_commit_tree(ctx, loc.leaf_mats(), log_rows, loc.tree.p);  // leaves + the slab's sub-tree
+        LeafMats lm = loc.leaf_mats();
+        if (loc.ldes.size() > 1) {  // laid back to back above: one matrix of the summed width for the leaf hash
+            bool contiguous = true;
+            uint32_t wsum = 0;
+            for (auto& cm : loc.ldes) {
+                contiguous = contiguous && cm.col_stride == rows && cm.d == loc.ldes[0].d + (uint64_t)wsum * rows;
+                wsum += cm.width;
+            }
+            if (contiguous && wsum <= 256) {
+                lm.n_mats = 1;
+                lm.width[0] = wsum;
+            }
+        }
+        launch_commit_tree(ctx, lm, log_rows, loc.tree.p);  // leaves + the slab's sub-tree
         DevBuf<uint32_t> d_top(&ctx, 8 * (size_t)(2 * sh.G - 1));
         gather_top(sh, "commit sub-roots", loc.tree.p + 8 * (merkle_total_digests(log_rows) - 1), d_top.p,
                    nullptr, nullptr, nullptr);

@@ -38,22 +38,25 @@ def _headers_mtime() -> float:
     return max(os.path.getmtime(h) for h in hs)
 
 
-def build(force: bool = False, verbose: bool = False, asan: bool = False) -> str:
-    """asan=True: the HOST sources (.cpp: C ABI, wire formats, verifier, challenger, host prover) are
+def build(force: bool = False, verbose: bool = False, asan: bool = False, defines: tuple = ()) -> str:
+    """defines: diagnostic builds (-D...; e.g. ("TS_TAIL_STAMPS",) = in-kernel time stamps in k_fri_tail,
+    tools/tail_stamps.py) go to lib_diag/ and are used through TS_LIB_PATH; the product build has none.
+
+    asan=True: the HOST sources (.cpp: C ABI, wire formats, verifier, challenger, host prover) are
     built with AddressSanitizer + UBSan into lib_asan/ (device code is not instrumented: GPU
     sanitizers are not available on the pool).  Run the CPU suite on it with
 
         TS_LIB_PATH=tap-stark_amd/lib_asan/libtapstark_hip.so ASAN_OPTIONS=detect_leaks=0 \
         LD_PRELOAD="$(python -m tapstark_amd.build --asan-runtime)" python -m pytest tests -m "not gpu"
     """
-    obj_dir = OBJ + ("_asan" if asan else "")
-    lib_dir = LIBDIR + ("_asan" if asan else "")
+    obj_dir = OBJ + ("_asan" if asan else "_diag" if defines else "")
+    lib_dir = LIBDIR + ("_asan" if asan else "_diag" if defines else "")
     lib = os.path.join(lib_dir, "libtapstark_hip.so")
     os.makedirs(obj_dir, exist_ok=True)
     os.makedirs(lib_dir, exist_ok=True)
     hipcc = _hipcc()
     hdr_m = _headers_mtime()
-    common = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-I", CSRC]
+    common = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-I", CSRC, *("-D" + d for d in defines)]
     san = ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer",
            "-shared-libsan"]
     jobs = []
@@ -144,4 +147,5 @@ if __name__ == "__main__":
     if "--asan-runtime" in sys.argv:
         print(asan_runtime())
     else:
-        print(build(force="--force" in sys.argv, verbose=True, asan="--asan" in sys.argv))
+        print(build(force="--force" in sys.argv, verbose=True, asan="--asan" in sys.argv,
+                    defines=tuple(a[2:] for a in sys.argv if a.startswith("-D"))))

@@ -8,9 +8,12 @@
 // lanes inside the quad (DPP quad_perm: a modifier on the consuming instruction, no LDS) and back.
 // That is 14 G per lane instead of 56: the chain is ~3.5x shorter.
 //
-// Message words are not kept in registers: each lane fetches the two words its G needs from where
-// the block already lies (LDS), through 28 offsets it derives once from the message schedule
-// (7 rounds x {column x, column y, diagonal x, diagonal y}).
+// Message words: each lane fetches the words its G functions need from where the block already lies
+// (LDS), through 28 offsets it derives once from the message schedule (7 rounds x {column x, column y,
+// diagonal x, diagonal y}).  Callers on a latency chain fetch all 28 in ONE batch before the rounds and
+// pass the registers (one LDS latency per compression; fetched round by round it was four) -- with a
+// single wave on a SIMD every instruction costs its four cycles, on the dependent chain or not, so such
+// callers also keep every address a per-lane constant (merkle_tree.hpp: reduce_levels, fri.hip: tail).
 #pragma once
 #include "blake3.hpp"
 
@@ -68,16 +71,19 @@ __device__ __forceinline__ uint32_t quad_perm(uint32_t v) {
     c = c + d;                 \
     b = rotr(b ^ c, 7);
 
-// Lane j (0..3 inside its quad; all four lanes must be active) passes cv[j] and cv[4+j] of the
-// input chaining value and gets back word j and word 4+j of the output.  msg(k) returns the
-// message word for schedule slot k (0..27, the slot order of quad_schedule).
+// Column j of the initial state: (cv[j], cv[4+j], IV[j], {counter lo, counter hi, block_len, flags}[j]).
+// It depends on the lane only: a kernel that compresses level after level derives it once (as a
+// chain of selects inside every call it cost ~ 20 instructions and two branches).
+struct QuadIv {
+    uint32_t a, b, c, d;
+};
+
+// Lane j (0..3 inside its quad; all four lanes must be active) passes column j of the initial state
+// and gets back word j and word 4+j of the output.  msg(k) returns the message word for schedule slot
+// k (0..27, the slot order of quad_schedule).
 template <class Msg>
-__device__ __forceinline__ void compress_quad(uint32_t j, uint32_t cv_lo, uint32_t cv_hi, Msg msg,
-                                              uint32_t block_len, uint32_t flags, uint32_t& out_lo,
-                                              uint32_t& out_hi) {
-    uint32_t a = cv_lo, b = cv_hi;
-    uint32_t c = j == 0 ? TS_B3_IV0 : j == 1 ? TS_B3_IV1 : j == 2 ? TS_B3_IV2 : TS_B3_IV3;
-    uint32_t d = j == 2 ? block_len : j == 3 ? flags : 0u;  // counter = 0
+__device__ __forceinline__ void compress_quad(const QuadIv& s0, Msg msg, uint32_t& out_lo, uint32_t& out_hi) {
+    uint32_t a = s0.a, b = s0.b, c = s0.c, d = s0.d;
 #pragma unroll
     for (int r = 0; r < 7; r++) {
         const uint32_t m0 = msg(4 * r + 0), m1 = msg(4 * r + 1), m2 = msg(4 * r + 2), m3 = msg(4 * r + 3);
@@ -102,6 +108,18 @@ __device__ __forceinline__ uint32_t iv_word(uint32_t k) {
 #pragma unroll
     for (int i = 1; i < 8; i++) v = k == (uint32_t)i ? IVW[i] : v;
     return v;
+}
+
+// the initial state of a one-block hash (chaining value = IV, counter = 0)
+__device__ __forceinline__ QuadIv quad_iv(uint32_t j, uint32_t block_len, uint32_t flags) {
+    return QuadIv{iv_word(j), iv_word(4 + j), iv_word(j), j == 2 ? block_len : j == 3 ? flags : 0u};
+}
+
+template <class Msg>
+__device__ __forceinline__ void compress_quad(uint32_t j, uint32_t cv_lo, uint32_t cv_hi, Msg msg,
+                                              uint32_t block_len, uint32_t flags, uint32_t& out_lo,
+                                              uint32_t& out_hi) {
+    compress_quad(QuadIv{cv_lo, cv_hi, iv_word(j), j == 2 ? block_len : j == 3 ? flags : 0u}, msg, out_lo, out_hi);
 }
 
 #endif

@@ -4,6 +4,7 @@
 // basic/src/challenger/mod.rs:151-174 (duplexing), :183-194 (observe), :261-313 (sample).
 #pragma once
 #include "blake3.hpp"
+#include "blake3_quad.hpp"
 
 namespace ts {
 
@@ -73,6 +74,66 @@ __device__ inline Ef dc_observe_root_and_sample(DevChallenger* c, const uint32_t
         r.c[0] = dc_pop(c);
     }
     return r;
+}
+
+// The same step on FOUR lanes, for the kernels whose last workgroup holds the root in an LDS digest
+// image (word w of node n at img[w * STRIDE + n]; node 0 = the root).  With an empty input buffer and
+// Blake3's permutation, observing the 8 words of a root fills the buffer exactly: the 8th observe
+// duplexes, state = root || capacity, ONE hash64 -- the compression of a tree node whose children are
+// (root, capacity half) --, state' = 0 || digest, and the samples are the digest's last words popped
+// from the end.  So the capacity half is parked as node 1 of the image and the sponge runs as one more
+// tree level on lanes 0..3 (blake3_quad.hpp: a quarter of the dependent chain), every index static.
+// Measured in k_fri_tail: 3.5 us -> 0.8 us per round.  Anything else (pending input, the reverse test
+// permutation) takes the one-lane form above.
+//   lc: the challenger's working copy in LDS; node_iv: quad_iv(lane, 64, one-block flags); pm[k]: byte offsets into the image of this lane's 28 message
+//   words for the node pair (0, 1) (quad_schedule; only lanes 0..3 use them); root_out / beta_out: global
+//   (or page-locked host) destinations, may be null; beta_lds: where the workgroup reads beta afterwards.
+// Call with the whole of wave 0 (threadIdx.x < 64 at least), uniformly; the caller's barrier follows.
+template <uint32_t STRIDE>
+__device__ __forceinline__ void dc_round_quad(DevChallenger* lc, uint32_t* img, const uint32_t pm[28],
+                                              const b3::QuadIv& node_iv, uint32_t* root_out, Ef* beta_lds,
+                                              Ef* beta_out) {
+    const uint32_t tid = threadIdx.x;
+    const bool fast = lc->n_in == 0 && lc->permutation == 0;
+    if (!fast) {
+        if (tid == 0) {
+            uint32_t root[8];
+            for (int k = 0; k < 8; k++) {
+                root[k] = img[k * STRIDE];
+                if (root_out != nullptr) root_out[k] = root[k];
+            }
+            const Ef beta = dc_observe_root_and_sample(lc, root);
+            if (beta_lds != nullptr) *beta_lds = beta;
+            if (beta_out != nullptr) *reinterpret_cast<uint4*>(beta_out) = make_uint4(beta.c[0], beta.c[1], beta.c[2], beta.c[3]);
+        }
+        return;
+    }
+    if (tid < 8) {
+        const uint32_t r = img[tid * STRIDE];
+        if (root_out != nullptr) root_out[tid] = r;
+        lc->in_buf[tid] = r;                       // what the eight observes leave behind
+        img[tid * STRIDE + 1] = lc->state[8 + tid];  // the capacity half: node 1
+        lc->state[tid] = 0;
+    }
+    if (tid < 4) {
+        uint32_t m[28];
+#pragma unroll
+        for (int k = 0; k < 28; k++)
+            m[k] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(img) + pm[k]);
+        uint32_t lo, hi;
+        b3::compress_quad(node_iv, [&](int k) { return m[k]; }, lo, hi);
+        lc->state[8 + tid] = lo;
+        lc->state[12 + tid] = hi;
+        lc->out_buf[tid] = lo;
+        lc->out_buf[4 + tid] = hi;
+        // pops take out_buf[7], [6], ...: challenge coefficient i is word 7 - i of the digest, lane 3 - i's `hi`
+        const uint32_t n_pop = lc->sample_ext ? 4u : 1u;
+        const uint32_t i = 3 - tid;
+        const uint32_t c = i < n_pop ? hi % P : 0u;
+        if (tid == 0) lc->n_out = 8 - n_pop;
+        if (beta_lds != nullptr) beta_lds->c[i] = c;
+        if (beta_out != nullptr) beta_out->c[i] = c;
+    }
 }
 #endif
 

@@ -360,7 +360,53 @@ constexpr int TAIL_MAX = 1 << FRI_TAIL_LOG;
 constexpr int TAIL_STRIDE = TAIL_MAX / 2;  // digest images: [word][node], one stride for both
 
 // Every compression here is shared by four lanes (blake3_quad.hpp): the kernel is one long chain of
-// dependent compressions (leaf, log2(h) levels, the sponge, per round), i.e. pure latency.
+// dependent compressions (leaf, log2(h) levels, the sponge, per round), i.e. pure latency -- and with one
+// wave per SIMD every instruction costs its four cycles whether it is on the chain or not.  So (round 5,
+// in-kernel time stamps: 0.95 -> 0.6 us per level, 3.5 -> 0.8 us per sponge step):
+//  * a lane's 28 message words are fetched in ONE batch (one LDS latency per compression instead of four),
+//    at byte offsets it derives once per kernel: its parent index is folded in, and the ping / pong image is
+//    a compile-time constant that goes into the instruction's offset field (the levels are unrolled in
+//    pairs), so a level issues no address arithmetic at all;
+//  * the sponge step is one more tree level on four lanes (dc_round_quad, chal_dev.hpp).
+#ifdef TS_TAIL_STAMPS
+__device__ unsigned long long g_stamps[512];
+#define STAMP(i) do { if (threadIdx.x == 0) { g_stamps[2*(i)] = __builtin_amdgcn_s_memrealtime(); g_stamps[2*(i)+1] = __builtin_amdgcn_s_memtime(); } } while (0)
+extern "C" __attribute__((visibility("default"))) void ts_debug_stamps(unsigned long long* out) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 512);
+}
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
+// One tree level of the tail: n_par parents from image PAR to image PAR ^ 1 (and to the tree arena at `out`).
+template <int PAR>
+__device__ __forceinline__ void tail_level(uint32_t (*dig)[8 * TAIL_STRIDE], const uint32_t pm[28],
+                                           const b3::QuadIv& node_iv, uint32_t n_par, uint32_t* __restrict__ out) {
+    const uint32_t j = threadIdx.x & 3;
+    const char* src = reinterpret_cast<const char*>(dig[PAR]);
+    uint32_t* dst = dig[PAR ^ 1];
+    // pass p takes parents 128 p + (lane >> 2): 1 KiB further on in every image row
+    for (uint32_t q = threadIdx.x, off = 0; q < 4 * n_par; q += TAIL_NT, off += 4 * 2 * (TAIL_NT / 4)) {
+        const uint32_t i = q >> 2;
+        uint32_t m[28];
+        if (off == 0) {
+#pragma unroll
+            for (int k = 0; k < 28; k++) m[k] = *reinterpret_cast<const uint32_t*>(src + pm[k]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 28; k++) m[k] = *reinterpret_cast<const uint32_t*>(src + pm[k] + off);
+        }
+        uint32_t lo, hi;
+        b3::compress_quad(node_iv, [&](int k) { return m[k]; }, lo, hi);
+        uint32_t* o = out + 8 * (uint64_t)i;
+        o[j] = lo;
+        o[4 + j] = hi;
+        dst[j * TAIL_STRIDE + i] = lo;
+        dst[(4 + j) * TAIL_STRIDE + i] = hi;
+    }
+    b3::lds_barrier();
+}
+
 __global__ void __launch_bounds__(TAIL_NT)
 k_fri_tail(const Ef* __restrict__ in, uint32_t L0, uint32_t blowup, DevChallenger* __restrict__ ch,
            const uint32_t* __restrict__ Winv, Ef* __restrict__ tail_vecs,
@@ -368,85 +414,76 @@ k_fri_tail(const Ef* __restrict__ in, uint32_t L0, uint32_t blowup, DevChallenge
            Ef* __restrict__ betas_out, Ef* __restrict__ final_out) {
     __shared__ Ef bufA[TAIL_MAX];
     __shared__ Ef bufB[TAIL_MAX / 2];
-    __shared__ uint32_t digA[8 * TAIL_STRIDE];
-    __shared__ uint32_t digB[8 * TAIL_STRIDE];
+    __shared__ uint32_t dig[2][8 * TAIL_STRIDE];  // digest images [word][node], used in turn
     __shared__ Ef s_beta;
-    __shared__ DevChallenger s_ch;  // the sponge's working copy (chal_dev.hpp); lane 0 only
+    __shared__ DevChallenger s_ch;  // the sponge's working copy (chal_dev.hpp); wave 0 only
     if (threadIdx.x == 0) dc_copy(&s_ch, ch);
     const uint32_t j = threadIdx.x & 3;
-    uint32_t moff[28], lidx[28], lmask = 0;  // tree-node offsets; leaf word indices and their validity
+    // pm: byte offsets in an image of the 28 message words of parent lane >> 2 (children 2i, 2i + 1);
+    // lidx / lmask: leaf word indices and their validity (a leaf is 8 words, the rest of the block zero)
+    uint32_t pm[28], lidx[28], lmask = 0;
     {
         uint32_t idx[28];
         b3::quad_schedule(j, idx);
 #pragma unroll
         for (int k = 0; k < 28; k++) {
-            moff[k] = (idx[k] & 7) * TAIL_STRIDE + (idx[k] >> 3);
+            pm[k] = 4 * ((idx[k] & 7) * TAIL_STRIDE + (idx[k] >> 3) + 2 * (threadIdx.x >> 2));
             lidx[k] = idx[k] & 7;
             lmask |= (idx[k] < 8 ? 1u : 0u) << k;
         }
     }
+    const b3::QuadIv node_iv = b3::quad_iv(j, 64, b3::CHUNK_START | b3::CHUNK_END | b3::ROOT);
+    const b3::QuadIv leaf_iv = b3::quad_iv(j, 32, b3::CHUNK_START | b3::CHUNK_END | b3::ROOT);
     Ef* cur = bufA;
     Ef* nxt = bufB;
+    STAMP(0);
     for (uint32_t i = threadIdx.x; i < L0; i += TAIL_NT) cur[i] = load_ef(in + i);
     __syncthreads();
+    STAMP(1);
     uint32_t L = L0, voff = 0, toff = 0, t = 0;
     while (L > blowup) {
         const uint32_t h = L >> 1;
+        STAMP(2 + 5 * t);
         for (uint32_t i = threadIdx.x; i < L; i += TAIL_NT) store_ef(tail_vecs + voff + i, cur[i]);
         // leaves: rows (cur[2i], cur[2i+1]) = 8 words, one short block
         for (uint32_t q = threadIdx.x; q < 4 * h; q += TAIL_NT) {
             const uint32_t i = q >> 2;
             const uint32_t* row = reinterpret_cast<const uint32_t*>(cur + 2 * i);
             uint32_t lo, hi;
-            b3::compress_quad(j, b3::iv_word(j), b3::iv_word(4 + j),
-                              [&](int k) { return ((lmask >> k) & 1u) ? row[lidx[k]] : 0u; }, 32,
-                              b3::CHUNK_START | b3::CHUNK_END | b3::ROOT, lo, hi);
+            uint32_t m[28];
+#pragma unroll
+            for (int k = 0; k < 28; k++) m[k] = ((lmask >> k) & 1u) ? row[lidx[k]] : 0u;
+            b3::compress_quad(leaf_iv, [&](int k) { return m[k]; }, lo, hi);
             uint32_t* o = tail_trees + 8 * (uint64_t)(toff + i);
             o[j] = lo;
             o[4 + j] = hi;
-            digA[j * TAIL_STRIDE + i] = lo;
-            digA[(4 + j) * TAIL_STRIDE + i] = hi;
+            dig[0][j * TAIL_STRIDE + i] = lo;
+            dig[0][(4 + j) * TAIL_STRIDE + i] = hi;
         }
         b3::lds_barrier();
-        uint32_t* src = digA;
-        uint32_t n = h, lvl_off = toff, lvl = 0;
+        STAMP(3 + 5 * t);
+        uint32_t n = h, lvl_off = toff, par = 0;
         while (n > 1) {
-            const uint32_t n_par = n >> 1;
-            uint32_t* dst = (lvl & 1) ? digA : digB;
-            for (uint32_t q = threadIdx.x; q < 4 * n_par; q += TAIL_NT) {
-                const uint32_t i = q >> 2;
-                const uint32_t* base = src + 2 * i;
-                uint32_t lo, hi;
-                b3::compress_quad(j, b3::iv_word(j), b3::iv_word(4 + j),
-                                  [&](int k) { return base[moff[k]]; }, 64,
-                                  b3::CHUNK_START | b3::CHUNK_END | b3::ROOT, lo, hi);
-                uint32_t* o = tail_trees + 8 * (uint64_t)(lvl_off + n + i);
-                o[j] = lo;
-                o[4 + j] = hi;
-                dst[j * TAIL_STRIDE + i] = lo;
-                dst[(4 + j) * TAIL_STRIDE + i] = hi;
-            }
-            b3::lds_barrier();
-            src = dst;
+            tail_level<0>(dig, pm, node_iv, n >> 1, tail_trees + 8 * (uint64_t)(lvl_off + n));
             lvl_off += n;
-            n = n_par;
-            lvl++;
+            n >>= 1;
+            par = 1;
+            if (n <= 1) break;
+            tail_level<1>(dig, pm, node_iv, n >> 1, tail_trees + 8 * (uint64_t)(lvl_off + n));
+            lvl_off += n;
+            n >>= 1;
+            par = 0;
         }
-        if (threadIdx.x == 0) {
-            uint32_t root[8];
-            for (int k = 0; k < 8; k++) {
-                root[k] = src[k * TAIL_STRIDE];
-                roots_out[8 * t + k] = root[k];
-            }
-            const Ef beta = dc_observe_root_and_sample(&s_ch, root);
-            s_beta = beta;
-            store_ef(betas_out + t, beta);
-        }
+        STAMP(4 + 5 * t);
+        // the root is node 0 of image `par`: observe it, sample beta (fri/src/prover.rs:113-116)
+        if (threadIdx.x < 64) dc_round_quad<TAIL_STRIDE>(&s_ch, dig[par], pm, node_iv, roots_out + 8 * t, &s_beta, betas_out + t);
         b3::lds_barrier();
+        STAMP(5 + 5 * t);
         const Ef half_beta_mont = ef_mul_base(ef_to_mont(s_beta), HALF_MONT);
         for (uint32_t i = threadIdx.x; i < h; i += TAIL_NT)
             nxt[i] = fold_one(cur[2 * i], cur[2 * i + 1], Winv[h + i], half_beta_mont, HALF_MONT);
         b3::lds_barrier();
+        STAMP(6 + 5 * t);
         Ef* tmp = cur;
         cur = nxt;
         nxt = tmp;
@@ -456,7 +493,9 @@ k_fri_tail(const Ef* __restrict__ in, uint32_t L0, uint32_t blowup, DevChallenge
         t++;
     }
     for (uint32_t i = threadIdx.x; i < L; i += TAIL_NT) store_ef(final_out + i, cur[i]);
-    if (threadIdx.x == 0) dc_copy(ch, &s_ch);  // only lane 0 ever touched the copy
+    STAMP(100);
+    if (threadIdx.x == 0) dc_copy(ch, &s_ch);  // wave 0 made every change to the copy
+    STAMP(101);
 }
 
 void launch_fri_tail(Context& ctx, const Ef* in, uint32_t L0, uint32_t blowup, DevChallenger* ch,

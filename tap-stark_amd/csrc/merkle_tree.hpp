@@ -90,67 +90,145 @@ struct Tree {
         uint32_t in[8 * CH];    // a chunk as staged / produced
         uint32_t ab[8 * CH];    // ping (nodes 0..CH/2-1) and pong (nodes CH/2..3CH/4-1) of the levels
         uint32_t keep[8 * CH];  // parked chunk results
+        DevChallenger chal;     // the transcript's working copy (prefetch_challenger, finish_tree)
     };
 
-    // Reduces `count` nodes of image `src` (nodes 0..count-1, both powers of two, count <= CH) to `stop`
-    // nodes.  src holds nodes [node0, node0 + count) of relative level `level`; every level produced is
-    // stored in the tree.  Returns the image holding the result.  With publish, the single node of the
-    // last level (stop == 1) is written through for another workgroup to read.
-    // wide_from: levels with at least this many parents run one compression per LANE (b3::hash64 on
-    // two ds_read_b64 streams) instead of four lanes per compression: 10.5 against 14.4 issued
-    // instructions per compression, at three times the chain length -- right where other workgroups
-    // fill the SIMDs (leaf_tree_body's blocks), wrong for a finisher that runs alone (0 = never).
-    __device__ static __forceinline__ const uint32_t* reduce_levels(Lds& lds, const uint32_t* src, uint32_t count,
-                                                                    uint32_t stop, const Levels& lv, unsigned level,
-                                                                    uint64_t node0, const uint32_t moff[28],
-                                                                    bool publish, uint32_t wide_from = 0) {
-        const uint32_t j = threadIdx.x & 3;
-        unsigned l = 0;
-        for (uint32_t n_par = count >> 1; n_par >= stop; n_par >>= 1, l++) {
-            uint32_t* dst = lds.ab + ((l & 1) ? CH / 2 : 0);
-            level++;
-            node0 >>= 1;
-            uint32_t* out = lv.at(level, node0);
-            if (wide_from != 0 && n_par >= wide_from) {
-                for (uint32_t i = threadIdx.x; i < n_par; i += NTH) {
-                    uint32_t m[16], cv[8];
+    // The images a level reads and writes, as compile-time ids: the LDS address of an image is then a
+    // constant that the compiler folds into the per-lane message offsets (no address arithmetic in a
+    // level; see blake3_quad.hpp on why that matters on the latency chain).
+    enum { IMG_IN = 0, IMG_KEEP = 1, IMG_PING = 2, IMG_PONG = 3 };
+    template <int IMG>
+    __device__ static __forceinline__ uint32_t* image(Lds& lds) {
+        if constexpr (IMG == IMG_IN) return lds.in;
+        else if constexpr (IMG == IMG_KEEP) return lds.keep;
+        else if constexpr (IMG == IMG_PING) return lds.ab;
+        else return lds.ab + CH / 2;
+    }
+
+    // per-lane constants of the levels that run four lanes per compression
+    struct Quad {
+        uint32_t pm[28];  // byte offsets inside an image of the 28 message words of parent (lane >> 2)
+        b3::QuadIv iv;    // initial state column of a node = hash64(left || right)
+    };
+    __device__ static __forceinline__ void quad_setup(Quad& q) {
+        uint32_t idx[28];
+        b3::quad_schedule(threadIdx.x & 3, idx);
 #pragma unroll
-                    for (int w = 0; w < 8; w++) {
-                        const uint2 v = *reinterpret_cast<const uint2*>(src + w * CH + 2 * i);
-                        m[w] = v.x;
-                        m[8 + w] = v.y;
-                    }
-                    b3::hash64(m, cv);
+        for (int k = 0; k < 28; k++) q.pm[k] = 4 * ((idx[k] & 7) * CH + (idx[k] >> 3) + 2 * (threadIdx.x >> 2));
+        q.iv = b3::quad_iv(threadIdx.x & 3, 64, b3::CHUNK_START | b3::CHUNK_END | b3::ROOT);
+    }
+
+    // One level: n_par parents of the nodes in image SRC go to image DST and to the tree at `out`.
+    // wide: one compression per LANE (b3::hash64 on two ds_read_b64 streams) instead of four lanes per
+    // compression: 10.5 against 14.4 issued instructions per compression, at three times the chain
+    // length -- right where other workgroups fill the SIMDs (leaf_tree_body's blocks), wrong for a
+    // finisher that runs alone.  publish_one: the level's single node is written through for another
+    // workgroup to read.
+    // (SRC = DST = -1: the images are the run-time pointers src_rt / dst_rt.)
+    template <int SRC, int DST>
+    __device__ static __forceinline__ void level_step(Lds& lds, const Quad& q, const uint32_t* src_rt, uint32_t* dst_rt,
+                                                      uint32_t n_par, uint32_t* out, bool publish_one, bool wide) {
+        const uint32_t* src;
+        uint32_t* dst;
+        if constexpr (SRC >= 0) {
+            src = image<SRC>(lds);
+            dst = image<DST>(lds);
+        } else {
+            src = src_rt;
+            dst = dst_rt;
+        }
+        if (wide) {
+            for (uint32_t i = threadIdx.x; i < n_par; i += NTH) {
+                uint32_t m[16], cv[8];
 #pragma unroll
-                    for (int w = 0; w < 8; w++) dst[w * CH + i] = cv[w];
-                    uint4* o = reinterpret_cast<uint4*>(out + 8 * i);
-                    o[0] = make_uint4(cv[0], cv[1], cv[2], cv[3]);
-                    o[1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
+                for (int w = 0; w < 8; w++) {
+                    const uint2 v = *reinterpret_cast<const uint2*>(src + w * CH + 2 * i);
+                    m[w] = v.x;
+                    m[8 + w] = v.y;
                 }
-            } else {
-                for (uint32_t t = threadIdx.x; t < 4 * n_par; t += NTH) {
-                    const uint32_t i = t >> 2;
-                    const uint32_t* base = src + 2 * i;
-                    uint32_t lo, hi;
-                    b3::compress_quad(j, b3::iv_word(j), b3::iv_word(4 + j),
-                                      [&](int k) { return base[moff[k]]; }, 64,
-                                      b3::CHUNK_START | b3::CHUNK_END | b3::ROOT, lo, hi);
-                    dst[j * CH + i] = lo;
-                    dst[(4 + j) * CH + i] = hi;
-                    uint32_t* o = out + 8 * i;
-                    if (publish && n_par == 1) {
-                        __hip_atomic_store(o + j, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(o + 4 + j, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    } else {
-                        o[j] = lo;
-                        o[4 + j] = hi;
-                    }
+                b3::hash64(m, cv);
+#pragma unroll
+                for (int w = 0; w < 8; w++) dst[w * CH + i] = cv[w];
+                uint4* o = reinterpret_cast<uint4*>(out + 8 * i);
+                o[0] = make_uint4(cv[0], cv[1], cv[2], cv[3]);
+                o[1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
+            }
+        } else {
+            const uint32_t j = threadIdx.x & 3;
+            const char* sb = reinterpret_cast<const char*>(src);
+            // pass p takes parents (NTH / 4) p + (lane >> 2): 2 NTH bytes further on in every image row
+            for (uint32_t t = threadIdx.x, off = 0; t < 4 * n_par; t += NTH, off += 2 * NTH) {
+                const uint32_t i = t >> 2;
+                uint32_t m[28];  // all 28 words in flight at once
+                if (off == 0) {
+#pragma unroll
+                    for (int k = 0; k < 28; k++) m[k] = *reinterpret_cast<const uint32_t*>(sb + q.pm[k]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 28; k++) m[k] = *reinterpret_cast<const uint32_t*>(sb + q.pm[k] + off);
+                }
+                uint32_t lo, hi;
+                b3::compress_quad(q.iv, [&](int k) { return m[k]; }, lo, hi);
+                dst[j * CH + i] = lo;
+                dst[(4 + j) * CH + i] = hi;
+                uint32_t* o = out + 8 * i;
+                if (publish_one) {
+                    __hip_atomic_store(o + j, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(o + 4 + j, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    o[j] = lo;
+                    o[4 + j] = hi;
                 }
             }
-            b3::lds_barrier();
-            src = dst;
         }
-        return src;
+        b3::lds_barrier();
+    }
+
+    // Reduces `count` nodes of image SRC0 (nodes 0..count-1, both powers of two, count <= CH) to `stop`
+    // nodes.  The image holds nodes [node0, node0 + count) of relative level `level`; every level
+    // produced is stored in the tree.  Returns the image holding the result.  With publish, the single
+    // node of the last level (stop == 1) is written through for another workgroup to read.
+    // wide_from: levels with at least this many parents run one compression per lane (0 = never).
+    // STATIC_IMAGES (the whole-tree kernels, Tree<9>: latency chains): the levels are unrolled over the
+    // three (source, destination) image pairs, every LDS address a per-lane constant -- 84 VGPRs of
+    // addresses, which a kernel that runs alone can afford.  The leaf-tree kernel (Tree<8>) is bound by
+    // throughput and by its 128-VGPR budget: one copy of the level, image pointers at run time (one add
+    // per message word), as in rounds 3-4.
+    static constexpr bool STATIC_IMAGES = LC == 9;
+    template <int SRC0>
+    __device__ static __forceinline__ const uint32_t* reduce_levels(Lds& lds, uint32_t count, uint32_t stop,
+                                                                    const Levels& lv, unsigned level, uint64_t node0,
+                                                                    const Quad& q, bool publish,
+                                                                    uint32_t wide_from = 0) {
+        uint32_t n_par = count >> 1;
+        if (n_par < stop) return image<SRC0>(lds);
+        auto out = [&]() {
+            level++;
+            node0 >>= 1;
+            return lv.at(level, node0);
+        };
+        if constexpr (STATIC_IMAGES) {
+            level_step<SRC0, IMG_PING>(lds, q, nullptr, nullptr, n_par, out(), publish && n_par == 1,
+                                       wide_from != 0 && n_par >= wide_from);
+            for (n_par >>= 1;; n_par >>= 1) {
+                if (n_par < stop) return image<IMG_PING>(lds);
+                level_step<IMG_PING, IMG_PONG>(lds, q, nullptr, nullptr, n_par, out(), publish && n_par == 1,
+                                               wide_from != 0 && n_par >= wide_from);
+                n_par >>= 1;
+                if (n_par < stop) return image<IMG_PONG>(lds);
+                level_step<IMG_PONG, IMG_PING>(lds, q, nullptr, nullptr, n_par, out(), publish && n_par == 1,
+                                               wide_from != 0 && n_par >= wide_from);
+            }
+        } else {
+            const uint32_t* src = image<SRC0>(lds);
+            for (unsigned l = 0; n_par >= stop; n_par >>= 1, l++) {
+                uint32_t* dst = lds.ab + ((l & 1) ? CH / 2 : 0);
+                level_step<-1, -1>(lds, q, src, dst, n_par, out(), publish && n_par == 1,
+                                   wide_from != 0 && n_par >= wide_from);
+                src = dst;
+            }
+            return src;
+        }
     }
 
     // One block: `count` (a power of two <= 8 * CH) nodes [node0, node0 + count) of relative
@@ -159,24 +237,24 @@ struct Tree {
     template <class Producer>
     __device__ static __forceinline__ const uint32_t* reduce_block(Lds& lds, Producer& prod, uint32_t count,
                                                                    const Levels& lv, unsigned level, uint64_t node0,
-                                                                   const uint32_t moff[28], bool publish) {
+                                                                   const Quad& q, bool publish) {
         if (count <= CH) {
             prod.fill(lds.in, node0, count);
             if (count == 1) return lds.in;
-            return reduce_levels(lds, lds.in, count, 1, lv, level, node0, moff, publish);
+            return reduce_levels<IMG_IN>(lds, count, 1, lv, level, node0, q, publish);
         }
         const uint32_t n_chunks = count >> LC;
         for (uint32_t c = 0; c < n_chunks; c++) {
             prod.fill(lds.in, node0 + (uint64_t)c * CH, CH);
-            const uint32_t* x = reduce_levels(lds, lds.in, CH, KEEP, lv, level, node0 + (uint64_t)c * CH, moff, false);
+            const uint32_t* x = reduce_levels<IMG_IN>(lds, CH, KEEP, lv, level, node0 + (uint64_t)c * CH, q, false);
             {
                 const uint32_t w = threadIdx.x >> LOG_KEEP, n = threadIdx.x & (KEEP - 1);  // 8 x 32 = 256 lanes
                 lds.keep[w * CH + c * KEEP + n] = x[w * CH + n];
             }
             b3::lds_barrier();
         }
-        return reduce_levels(lds, lds.keep, n_chunks * KEEP, 1, lv, level + (LC - LOG_KEEP),
-                             node0 >> (LC - LOG_KEEP), moff, publish);
+        return reduce_levels<IMG_KEEP>(lds, n_chunks * KEEP, 1, lv, level + (LC - LOG_KEEP), node0 >> (LC - LOG_KEEP), q,
+                                       publish);
     }
 
     // first-level nodes that already lie in the tree; SC1: they were written by other workgroups of
@@ -204,19 +282,21 @@ struct Tree {
         }
     };
 
-    __device__ static __forceinline__ void quad_offsets(uint32_t moff[28]) {
-        uint32_t idx[28];
-        b3::quad_schedule(threadIdx.x & 3, idx);
-#pragma unroll
-        for (int k = 0; k < 28; k++) moff[k] = (idx[k] & 7) * CH + (idx[k] >> 3);
+    // Every workgroup fetches the transcript's 36 words at its start (one coalesced load that nobody
+    // waits for): the workgroup that turns out to be the finisher has them in LDS when it gets there
+    // instead of paying a global round trip at the very end of the dependency chain.  The previous
+    // launch on the stream wrote them; nothing in this launch does before the finisher.
+    __device__ static __forceinline__ void prefetch_challenger(Lds& lds, const DevChallenger* ch) {
+        if (ch != nullptr && threadIdx.x < DC_WORDS)
+            reinterpret_cast<uint32_t*>(&lds.chal)[threadIdx.x] = reinterpret_cast<const uint32_t*>(ch)[threadIdx.x];
     }
 
     // What every workgroup does once its block is down to its sub-root `top` (node blockIdx.x of
     // relative level log_b; n_sub = gridDim.x of them): hand-off, the last one reduces the sub-roots
-    // to the root, then the device challenger step.
+    // to the root, then the device challenger step.  (prefetch_challenger ran at the workgroup's start.)
     __device__ static __forceinline__ void finish_tree(Lds& lds, uint32_t& s_last, const uint32_t* top,
                                                        const Levels& lv, unsigned log_b, uint32_t n_sub,
-                                                       const uint32_t moff[28], uint32_t* ticket,
+                                                       const Quad& q, uint32_t* ticket,
                                                        DevChallenger* ch, uint32_t* root_out, Ef* beta_out) {
         bool finisher = n_sub == 1;
         if (n_sub > 1) {
@@ -247,28 +327,24 @@ struct Tree {
                 }
                 __syncthreads();
                 StagedNodes<true> sub{lv.at(log_b, 0)};
-                top = reduce_block(lds, sub, n_sub, lv, log_b, 0, moff, false);
+                top = reduce_block(lds, sub, n_sub, lv, log_b, 0, q, false);
                 if (threadIdx.x == 0)  // ready for the next launch on this stream
                     __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 finisher = true;
             }
         }
         // device-resident transcript (fri/src/prover.rs:114-116): the workgroup that produced the root
-        // observes it and samples the next challenge
-        // (root_out may be page-locked host memory: the commitment goes straight to the caller's mailbox)
-        if (finisher && (ch != nullptr || root_out != nullptr) && threadIdx.x == 0) {
-            uint32_t root[8];
-            for (int k = 0; k < 8; k++) {
-                root[k] = top[k * CH];
-                if (root_out != nullptr) root_out[k] = root[k];
-            }
+        // observes it and samples the next challenge -- as one more tree level on four lanes
+        // (dc_round_quad, chal_dev.hpp).  root_out may be page-locked host memory: the commitment goes
+        // straight to the caller's mailbox.
+        if (finisher && threadIdx.x < 64) {
+            uint32_t* img = const_cast<uint32_t*>(top);  // node 1 of the final image is free
             if (ch != nullptr) {
-                // (the parked-node image is free by now: the sponge runs on a copy there, see chal_dev.hpp)
-                DevChallenger* lc = reinterpret_cast<DevChallenger*>(lds.keep);
-                dc_copy(lc, ch);
-                const Ef beta = dc_observe_root_and_sample(lc, root);
-                dc_copy(ch, lc);
-                *reinterpret_cast<uint4*>(beta_out) = make_uint4(beta.c[0], beta.c[1], beta.c[2], beta.c[3]);
+                dc_round_quad<CH>(&lds.chal, img, q.pm, q.iv, root_out, nullptr, beta_out);
+                if (threadIdx.x < DC_WORDS)
+                    reinterpret_cast<uint32_t*>(ch)[threadIdx.x] = reinterpret_cast<const uint32_t*>(&lds.chal)[threadIdx.x];
+            } else if (root_out != nullptr && threadIdx.x < 8) {
+                root_out[threadIdx.x] = img[threadIdx.x * CH];
             }
         }
     }
@@ -280,13 +356,14 @@ struct Tree {
     __device__ static __forceinline__ void tree_body(Lds& lds, uint32_t& s_last, Producer& prod, const Levels& lv,
                                                      unsigned remaining, uint32_t* ticket, DevChallenger* ch,
                                                      uint32_t* root_out, Ef* beta_out) {
-        uint32_t moff[28];
-        quad_offsets(moff);
+        prefetch_challenger(lds, ch);
+        Quad q;
+        quad_setup(q);
         const unsigned log_b = block_log(remaining);
         const uint32_t B = 1u << log_b;
         const uint32_t n_sub = 1u << (remaining - log_b);
-        const uint32_t* top = reduce_block(lds, prod, B, lv, 0, (uint64_t)blockIdx.x * B, moff, n_sub > 1);
-        finish_tree(lds, s_last, top, lv, log_b, n_sub, moff, ticket, ch, root_out, beta_out);
+        const uint32_t* top = reduce_block(lds, prod, B, lv, 0, (uint64_t)blockIdx.x * B, q, n_sub > 1);
+        finish_tree(lds, s_last, top, lv, log_b, n_sub, q, ticket, ch, root_out, beta_out);
     }
 };
 
@@ -360,6 +437,7 @@ __device__ __forceinline__ void leaf_tree_body(T8::Lds& lds, uint32_t& s_last, L
     constexpr int R = 1 << LOG_R;
     const uint32_t tid = threadIdx.x;
     const uint64_t base = (uint64_t)blockIdx.x * (256u * R);
+    if (finish) T8::prefetch_challenger(lds, ch);
     uint32_t D[R][8];
     leaf_rows<0, R>(leaf, D, lv, base + tid);
     if constexpr (LOG_R >= 1) register_level<0, R>(D, lv, base);
@@ -373,13 +451,13 @@ __device__ __forceinline__ void leaf_tree_body(T8::Lds& lds, uint32_t& s_last, L
         for (int w = 0; w < 8; w++) lds.in[w * T8::CH + slot] = D[0][w];
     }
     b3::lds_barrier();
-    uint32_t moff[28];
-    T8::quad_offsets(moff);
+    T8::Quad q;
+    T8::quad_setup(q);
     const unsigned log_b = 8 + LOG_R;
     const uint32_t n_sub = 1u << (log_leaves - log_b);
-    const uint32_t* top = T8::reduce_levels(lds, lds.in, 256, 1, lv, LOG_R, base >> LOG_R, moff,
-                                            finish && n_sub > 1, 64);
-    if (finish) T8::finish_tree(lds, s_last, top, lv, log_b, n_sub, moff, ticket, ch, root_out, beta_out);
+    const uint32_t* top = T8::reduce_levels<T8::IMG_IN>(lds, 256, 1, lv, LOG_R, base >> LOG_R, q,
+                                                        finish && n_sub > 1, 64);
+    if (finish) T8::finish_tree(lds, s_last, top, lv, log_b, n_sub, q, ticket, ch, root_out, beta_out);
 }
 
 #endif

@@ -374,6 +374,10 @@ __device__ unsigned long long g_stamps[512];
 extern "C" __attribute__((visibility("default"))) void ts_debug_stamps(unsigned long long* out) {
     (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 512);
 }
+// the last k_fri_round launch (merkle_tree.hpp: TS_TREE_STAMP)
+extern "C" __attribute__((visibility("default"))) void ts_debug_tree_stamps(unsigned long long* out) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(mt::g_tree_stamps), sizeof(unsigned long long) * 64);
+}
 #else
 #define STAMP(i) do { } while (0)
 #endif

@@ -72,6 +72,15 @@ TS_HD unsigned leaf_tree_log_r(unsigned log_leaves) {
 
 #if defined(__HIPCC__)
 
+// diagnostic build only (python -m tapstark_amd.build -DTS_TAIL_STAMPS, tools/tail_stamps.py): time stamps of the
+// last whole-tree launch of a translation unit -- workgroup 0 for its block, the finisher for the rest
+#ifdef TS_TAIL_STAMPS
+__device__ static unsigned long long g_tree_stamps[64];
+#define TS_TREE_STAMP(i, who) do { if (threadIdx.x == 0 && (who)) { g_tree_stamps[i] = __builtin_amdgcn_s_memrealtime(); g_tree_stamps[32 + (i)] = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define TS_TREE_STAMP(i, who) do { } while (0)
+#endif
+
 // where the tree keeps its levels, relative to the first level this launch works on
 struct Levels {
     uint32_t* tree;    // base of the whole tree
@@ -93,18 +102,6 @@ struct Tree {
         DevChallenger chal;     // the transcript's working copy (prefetch_challenger, finish_tree)
     };
 
-    // The images a level reads and writes, as compile-time ids: the LDS address of an image is then a
-    // constant that the compiler folds into the per-lane message offsets (no address arithmetic in a
-    // level; see blake3_quad.hpp on why that matters on the latency chain).
-    enum { IMG_IN = 0, IMG_KEEP = 1, IMG_PING = 2, IMG_PONG = 3 };
-    template <int IMG>
-    __device__ static __forceinline__ uint32_t* image(Lds& lds) {
-        if constexpr (IMG == IMG_IN) return lds.in;
-        else if constexpr (IMG == IMG_KEEP) return lds.keep;
-        else if constexpr (IMG == IMG_PING) return lds.ab;
-        else return lds.ab + CH / 2;
-    }
-
     // per-lane constants of the levels that run four lanes per compression
     struct Quad {
         uint32_t pm[28];  // byte offsets inside an image of the 28 message words of parent (lane >> 2)
@@ -118,25 +115,18 @@ struct Tree {
         q.iv = b3::quad_iv(threadIdx.x & 3, 64, b3::CHUNK_START | b3::CHUNK_END | b3::ROOT);
     }
 
-    // One level: n_par parents of the nodes in image SRC go to image DST and to the tree at `out`.
+    // One level: n_par parents of the nodes in image `src` go to image `dst` and to the tree at `out`.
     // wide: one compression per LANE (b3::hash64 on two ds_read_b64 streams) instead of four lanes per
     // compression: 10.5 against 14.4 issued instructions per compression, at three times the chain
     // length -- right where other workgroups fill the SIMDs (leaf_tree_body's blocks), wrong for a
     // finisher that runs alone.  publish_one: the level's single node is written through for another
     // workgroup to read.
-    // (SRC = DST = -1: the images are the run-time pointers src_rt / dst_rt.)
-    template <int SRC, int DST>
-    __device__ static __forceinline__ void level_step(Lds& lds, const Quad& q, const uint32_t* src_rt, uint32_t* dst_rt,
-                                                      uint32_t n_par, uint32_t* out, bool publish_one, bool wide) {
-        const uint32_t* src;
-        uint32_t* dst;
-        if constexpr (SRC >= 0) {
-            src = image<SRC>(lds);
-            dst = image<DST>(lds);
-        } else {
-            src = src_rt;
-            dst = dst_rt;
-        }
+    // (Image addresses as compile-time constants -- the levels unrolled over the three (source,
+    // destination) pairs, no address arithmetic left in a level -- were built and measured in round 5:
+    // 84 more VGPRs, three copies of the code, and the eight levels of a 256-node block took 8.8 us
+    // against 8.5 with the run-time pointers below.  One add per message word is 0.05 us of a 0.85 us level.)
+    __device__ static __forceinline__ void level_step(const Quad& q, const uint32_t* src, uint32_t* dst, uint32_t n_par,
+                                                      uint32_t* out, bool publish_one, bool wide) {
         if (wide) {
             for (uint32_t i = threadIdx.x; i < n_par; i += NTH) {
                 uint32_t m[16], cv[8];
@@ -159,14 +149,9 @@ struct Tree {
             // pass p takes parents (NTH / 4) p + (lane >> 2): 2 NTH bytes further on in every image row
             for (uint32_t t = threadIdx.x, off = 0; t < 4 * n_par; t += NTH, off += 2 * NTH) {
                 const uint32_t i = t >> 2;
-                uint32_t m[28];  // all 28 words in flight at once
-                if (off == 0) {
+                uint32_t m[28];  // all 28 words requested before the first round needs one
 #pragma unroll
-                    for (int k = 0; k < 28; k++) m[k] = *reinterpret_cast<const uint32_t*>(sb + q.pm[k]);
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 28; k++) m[k] = *reinterpret_cast<const uint32_t*>(sb + q.pm[k] + off);
-                }
+                for (int k = 0; k < 28; k++) m[k] = *reinterpret_cast<const uint32_t*>(sb + q.pm[k] + off);
                 uint32_t lo, hi;
                 b3::compress_quad(q.iv, [&](int k) { return m[k]; }, lo, hi);
                 dst[j * CH + i] = lo;
@@ -184,51 +169,26 @@ struct Tree {
         b3::lds_barrier();
     }
 
-    // Reduces `count` nodes of image SRC0 (nodes 0..count-1, both powers of two, count <= CH) to `stop`
-    // nodes.  The image holds nodes [node0, node0 + count) of relative level `level`; every level
-    // produced is stored in the tree.  Returns the image holding the result.  With publish, the single
-    // node of the last level (stop == 1) is written through for another workgroup to read.
+    // Reduces `count` nodes of image `src` (nodes 0..count-1, both powers of two, count <= CH) to `stop`
+    // nodes.  src holds nodes [node0, node0 + count) of relative level `level`; every level produced is
+    // stored in the tree.  Returns the image holding the result.  With publish, the single node of the
+    // last level (stop == 1) is written through for another workgroup to read.
     // wide_from: levels with at least this many parents run one compression per lane (0 = never).
-    // STATIC_IMAGES (the whole-tree kernels, Tree<9>: latency chains): the levels are unrolled over the
-    // three (source, destination) image pairs, every LDS address a per-lane constant -- 84 VGPRs of
-    // addresses, which a kernel that runs alone can afford.  The leaf-tree kernel (Tree<8>) is bound by
-    // throughput and by its 128-VGPR budget: one copy of the level, image pointers at run time (one add
-    // per message word), as in rounds 3-4.
-    static constexpr bool STATIC_IMAGES = LC == 9;
-    template <int SRC0>
-    __device__ static __forceinline__ const uint32_t* reduce_levels(Lds& lds, uint32_t count, uint32_t stop,
-                                                                    const Levels& lv, unsigned level, uint64_t node0,
-                                                                    const Quad& q, bool publish,
+    __device__ static __forceinline__ const uint32_t* reduce_levels(Lds& lds, const uint32_t* src, uint32_t count,
+                                                                    uint32_t stop, const Levels& lv, unsigned level,
+                                                                    uint64_t node0, const Quad& q, bool publish,
                                                                     uint32_t wide_from = 0) {
-        uint32_t n_par = count >> 1;
-        if (n_par < stop) return image<SRC0>(lds);
-        auto out = [&]() {
+        unsigned l = 0;
+        for (uint32_t n_par = count >> 1; n_par >= stop; n_par >>= 1, l++) {
+            uint32_t* dst = lds.ab + ((l & 1) ? CH / 2 : 0);
             level++;
             node0 >>= 1;
-            return lv.at(level, node0);
-        };
-        if constexpr (STATIC_IMAGES) {
-            level_step<SRC0, IMG_PING>(lds, q, nullptr, nullptr, n_par, out(), publish && n_par == 1,
-                                       wide_from != 0 && n_par >= wide_from);
-            for (n_par >>= 1;; n_par >>= 1) {
-                if (n_par < stop) return image<IMG_PING>(lds);
-                level_step<IMG_PING, IMG_PONG>(lds, q, nullptr, nullptr, n_par, out(), publish && n_par == 1,
-                                               wide_from != 0 && n_par >= wide_from);
-                n_par >>= 1;
-                if (n_par < stop) return image<IMG_PONG>(lds);
-                level_step<IMG_PONG, IMG_PING>(lds, q, nullptr, nullptr, n_par, out(), publish && n_par == 1,
-                                               wide_from != 0 && n_par >= wide_from);
-            }
-        } else {
-            const uint32_t* src = image<SRC0>(lds);
-            for (unsigned l = 0; n_par >= stop; n_par >>= 1, l++) {
-                uint32_t* dst = lds.ab + ((l & 1) ? CH / 2 : 0);
-                level_step<-1, -1>(lds, q, src, dst, n_par, out(), publish && n_par == 1,
-                                   wide_from != 0 && n_par >= wide_from);
-                src = dst;
-            }
-            return src;
+            level_step(q, src, dst, n_par, lv.at(level, node0), publish && n_par == 1,
+                       wide_from != 0 && n_par >= wide_from);
+            src = dst;
+            TS_TREE_STAMP(10 + l, blockIdx.x == 0 && publish);
         }
+        return src;
     }
 
     // One block: `count` (a power of two <= 8 * CH) nodes [node0, node0 + count) of relative
@@ -240,21 +200,22 @@ struct Tree {
                                                                    const Quad& q, bool publish) {
         if (count <= CH) {
             prod.fill(lds.in, node0, count);
+            TS_TREE_STAMP(1, blockIdx.x == 0 && level == 0);
             if (count == 1) return lds.in;
-            return reduce_levels<IMG_IN>(lds, count, 1, lv, level, node0, q, publish);
+            return reduce_levels(lds, lds.in, count, 1, lv, level, node0, q, publish);
         }
         const uint32_t n_chunks = count >> LC;
         for (uint32_t c = 0; c < n_chunks; c++) {
             prod.fill(lds.in, node0 + (uint64_t)c * CH, CH);
-            const uint32_t* x = reduce_levels<IMG_IN>(lds, CH, KEEP, lv, level, node0 + (uint64_t)c * CH, q, false);
+            const uint32_t* x = reduce_levels(lds, lds.in, CH, KEEP, lv, level, node0 + (uint64_t)c * CH, q, false);
             {
                 const uint32_t w = threadIdx.x >> LOG_KEEP, n = threadIdx.x & (KEEP - 1);  // 8 x 32 = 256 lanes
                 lds.keep[w * CH + c * KEEP + n] = x[w * CH + n];
             }
             b3::lds_barrier();
         }
-        return reduce_levels<IMG_KEEP>(lds, n_chunks * KEEP, 1, lv, level + (LC - LOG_KEEP), node0 >> (LC - LOG_KEEP), q,
-                                       publish);
+        return reduce_levels(lds, lds.keep, n_chunks * KEEP, 1, lv, level + (LC - LOG_KEEP), node0 >> (LC - LOG_KEEP), q,
+                             publish);
     }
 
     // first-level nodes that already lie in the tree; SC1: they were written by other workgroups of
@@ -315,19 +276,24 @@ struct Tree {
             // checks the disassembly: sc1 on these stores and loads, buffer_inv sc1, no flat_ access.
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+            TS_TREE_STAMP(3, blockIdx.x == 0);
             if (threadIdx.x == 0) {
                 const uint32_t tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 s_last = tk == n_sub - 1 ? 1u : 0u;
             }
             __syncthreads();
+            TS_TREE_STAMP(4, blockIdx.x == 0);
             if (s_last) {
+                TS_TREE_STAMP(5, true);
                 if (threadIdx.x == 0) {
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
                 __syncthreads();
+                TS_TREE_STAMP(6, true);
                 StagedNodes<true> sub{lv.at(log_b, 0)};
                 top = reduce_block(lds, sub, n_sub, lv, log_b, 0, q, false);
+                TS_TREE_STAMP(7, true);
                 if (threadIdx.x == 0)  // ready for the next launch on this stream
                     __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 finisher = true;
@@ -338,6 +304,7 @@ struct Tree {
         // (dc_round_quad, chal_dev.hpp).  root_out may be page-locked host memory: the commitment goes
         // straight to the caller's mailbox.
         if (finisher && threadIdx.x < 64) {
+            TS_TREE_STAMP(8, true);
             uint32_t* img = const_cast<uint32_t*>(top);  // node 1 of the final image is free
             if (ch != nullptr) {
                 dc_round_quad<CH>(&lds.chal, img, q.pm, q.iv, root_out, nullptr, beta_out);
@@ -346,6 +313,7 @@ struct Tree {
             } else if (root_out != nullptr && threadIdx.x < 8) {
                 root_out[threadIdx.x] = img[threadIdx.x * CH];
             }
+            TS_TREE_STAMP(9, true);
         }
     }
 
@@ -356,6 +324,7 @@ struct Tree {
     __device__ static __forceinline__ void tree_body(Lds& lds, uint32_t& s_last, Producer& prod, const Levels& lv,
                                                      unsigned remaining, uint32_t* ticket, DevChallenger* ch,
                                                      uint32_t* root_out, Ef* beta_out) {
+        TS_TREE_STAMP(0, blockIdx.x == 0);
         prefetch_challenger(lds, ch);
         Quad q;
         quad_setup(q);
@@ -363,6 +332,7 @@ struct Tree {
         const uint32_t B = 1u << log_b;
         const uint32_t n_sub = 1u << (remaining - log_b);
         const uint32_t* top = reduce_block(lds, prod, B, lv, 0, (uint64_t)blockIdx.x * B, q, n_sub > 1);
+        TS_TREE_STAMP(2, blockIdx.x == 0);
         finish_tree(lds, s_last, top, lv, log_b, n_sub, q, ticket, ch, root_out, beta_out);
     }
 };
@@ -455,8 +425,7 @@ __device__ __forceinline__ void leaf_tree_body(T8::Lds& lds, uint32_t& s_last, L
     T8::quad_setup(q);
     const unsigned log_b = 8 + LOG_R;
     const uint32_t n_sub = 1u << (log_leaves - log_b);
-    const uint32_t* top = T8::reduce_levels<T8::IMG_IN>(lds, 256, 1, lv, LOG_R, base >> LOG_R, q,
-                                                        finish && n_sub > 1, 64);
+    const uint32_t* top = T8::reduce_levels(lds, lds.in, 256, 1, lv, LOG_R, base >> LOG_R, q, finish && n_sub > 1, 64);
     if (finish) T8::finish_tree(lds, s_last, top, lv, log_b, n_sub, q, ticket, ch, root_out, beta_out);
 }
 

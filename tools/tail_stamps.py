@@ -29,3 +29,11 @@ for name in ("config3",):
         t += 1
         if t > 15: break
     print("end", us(100), us(101))
+    tb = (C.c_ulonglong * 64)()
+    lib.ts_debug_tree_stamps(tb)
+    names = ["start", "fill done (block 0)", "block levels done", "stores drained + barrier", "ticket taken", "finisher: is last",
+             "acquire done", "sub-roots staged + reduced", "sponge start", "end"]
+    print("last k_fri_round launch (us from workgroup 0's start):")
+    for i, nm in enumerate(names):
+        print(f"  {nm:32s} {(tb[i] - tb[0]) / 100.0:8.2f}   shader clock since the previous stamp {((tb[32 + i] - tb[32 + i - 1]) / max(1, (tb[i] - tb[i - 1]) * 10)) if i else 0:5.2f} GHz")
+    print("  block 0's levels (us each):", [round((tb[10 + l] - (tb[10 + l - 1] if l else tb[1])) / 100.0, 2) for l in range(9) if tb[10 + l]])

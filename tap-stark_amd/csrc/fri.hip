@@ -415,7 +415,8 @@ __global__ void __launch_bounds__(TAIL_NT)
 k_fri_tail(const Ef* __restrict__ in, uint32_t L0, uint32_t blowup, DevChallenger* __restrict__ ch,
            const uint32_t* __restrict__ Winv, Ef* __restrict__ tail_vecs,
            uint32_t* __restrict__ tail_trees, uint32_t* __restrict__ roots_out,
-           Ef* __restrict__ betas_out, Ef* __restrict__ final_out) {
+           Ef* __restrict__ betas_out, Ef* __restrict__ final_out, uint32_t pow_bits,
+           uint32_t* __restrict__ pow_out) {
     __shared__ Ef bufA[TAIL_MAX];
     __shared__ Ef bufB[TAIL_MAX / 2];
     __shared__ uint32_t dig[2][8 * TAIL_STRIDE];  // digest images [word][node], used in turn
@@ -499,19 +500,53 @@ k_fri_tail(const Ef* __restrict__ in, uint32_t L0, uint32_t blowup, DevChallenge
     for (uint32_t i = threadIdx.x; i < L; i += TAIL_NT) store_ef(final_out + i, cur[i]);
     STAMP(100);
     if (threadIdx.x == 0) dc_copy(ch, &s_ch);  // wave 0 made every change to the copy
+    // The proof-of-work witness (fri/src/prover.rs:43, basic/src/challenger/mod.rs:95-114): the smallest w
+    // < 4096 for which a CLONE of the transcript, after observing (w, 0 x 7), samples `pow_bits` zero bits.
+    // With an empty input buffer those eight words fill it exactly: one permutation of (w, 0 x 7, capacity
+    // half), and the sample is the digest's last word mod p.  On the host that is ~256 sponge steps one
+    // after another (30-40 us of every proof); here every lane tries one candidate.  The transcript itself
+    // does not move: the host checks the hint with one step of its own and grinds itself if it must.
+    if (pow_out != nullptr) {
+        __shared__ uint32_t s_pow;
+        const bool can = s_ch.n_in == 0 && s_ch.permutation == 0;  // uniform
+        if (threadIdx.x == 0) s_pow = FRI_POW_NONE;
+        b3::lds_barrier();
+        if (can) {
+            uint32_t m[16], d[8];
+#pragma unroll
+            for (int i = 1; i < 8; i++) m[i] = 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) m[8 + i] = s_ch.state[8 + i];
+            // 256 candidates a pass -- one wave per SIMD, 1.4 us; a pass finds one 19 times in 20 at 8 bits
+            constexpr uint32_t PER_PASS = 256;
+            for (uint32_t w0 = 0; w0 < (1u << 12); w0 += PER_PASS) {
+                if (threadIdx.x < PER_PASS) {
+                    m[0] = w0 + threadIdx.x;
+                    b3::hash64(m, d);
+                    if (pow_bits == 0 || ((d[7] % P) >> (32 - pow_bits)) == 0) atomicMin(&s_pow, w0 + threadIdx.x);
+                }
+                b3::lds_barrier();
+                const bool found = s_pow != FRI_POW_NONE;  // uniform: every add is behind the barrier
+                b3::lds_barrier();                          // ... and nobody adds again before all have read
+                if (found) break;
+            }
+        }
+        if (threadIdx.x == 0) *pow_out = s_pow;
+    }
     STAMP(101);
 }
 
 void launch_fri_tail(Context& ctx, const Ef* in, uint32_t L0, uint32_t blowup, DevChallenger* ch,
                      Ef* tail_vecs, uint32_t* tail_trees, uint32_t* roots_out, Ef* betas_out,
-                     Ef* final_out) {
+                     Ef* final_out, uint32_t pow_bits, uint32_t* pow_out) {
+    TS_REQUIRE(pow_bits <= 31, TS_ERR_INVALID, "fri_tail: proof-of-work bits > 31");
     TS_REQUIRE(L0 <= (uint32_t)TAIL_MAX && L0 >= 1, TS_ERR_INVALID, "fri_tail: vector too long");
     unsigned log_l = 0;
     while ((1u << log_l) < L0) log_l++;
     ctx.ensure_twiddles(log_l == 0 ? 1 : log_l);
     TS_LAUNCH(ctx, k_fri_tail, dim3(1), dim3(TAIL_NT), 0, in, L0, blowup, ch,
               (const uint32_t*)ctx.d_twiddle_inv, tail_vecs, tail_trees, roots_out, betas_out,
-              final_out);
+              final_out, pow_bits, pow_out);
     TS_HIP(hipGetLastError());
 }
 

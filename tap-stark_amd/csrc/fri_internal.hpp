@@ -26,8 +26,12 @@ struct FriCommit {
     DevBuf<Ef> d_betas;
     uint32_t R_total = 0;
     uint64_t final_len = 0;
+    // the tail kernel's proof-of-work hint (word FRI_POW_WORD of the challenger's 64-word slot): the
+    // witness it found, or FRI_POW_NONE
+    uint32_t pow_hint = 0xffffffffu;
     DevChallenger* dch() { return reinterpret_cast<DevChallenger*>(d_chal.p); }
 };
+constexpr size_t FRI_POW_WORD = 40;
 
 // moves the transcript to the device and sizes the per-round buffers
 void fri_commit_begin(Context& ctx, const FriConfig& fri, unsigned log_max_height,
@@ -39,6 +43,9 @@ void fri_commit_rounds(Context& ctx, const FriConfig& fri, DevBuf<Ef> folded, ui
                        size_t next_in, FriCommit& st);
 // brings roots, final values and the transcript back; checks prover.rs:129-134; returns final_poly
 Ef fri_commit_finish(Context& ctx, const FriConfig& fri, BfChallenger& challenger, FriCommit& st);
+// prover.rs:43 challenger.grind(bits): takes the device's hint if one step of the host transcript
+// confirms it, grinds on the host otherwise
+uint32_t fri_pow_witness(BfChallenger& challenger, unsigned bits, const FriCommit& st);
 
 // small host helpers
 void h2d(Context& ctx, void* dst, const void* src, size_t bytes);

@@ -204,9 +204,13 @@ void launch_chal_round(Context& ctx, DevChallenger* ch, const uint32_t* root, ui
                        Ef* beta_out);
 // all remaining commit-phase rounds once the vector has <= 2^FRI_TAIL_LOG elements, one workgroup
 constexpr int FRI_TAIL_LOG = 10;
+// pow_out != nullptr: the kernel also grinds (fri/src/prover.rs:43) -- *pow_out = the smallest witness
+// below 4096 that passes pow_bits on the transcript as the last round leaves it, FRI_POW_NONE if it
+// cannot tell (pending transcript input, the test permutation) or none passes
+constexpr uint32_t FRI_POW_NONE = 0xffffffffu;
 void launch_fri_tail(Context& ctx, const Ef* in, uint32_t L0, uint32_t blowup, DevChallenger* ch,
                      Ef* tail_vecs, uint32_t* tail_trees, uint32_t* roots_out, Ef* betas_out,
-                     Ef* final_out);
+                     Ef* final_out, uint32_t pow_bits = 0, uint32_t* pow_out = nullptr);
 void launch_vec_add(Context& ctx, Ef* acc, const Ef* other, uint64_t n);
 // gathers: rows of column-major matrices and Merkle paths at given indices
 void launch_gather_rows(Context& ctx, const LeafMats& mats, const uint32_t* d_indices,

@@ -502,7 +502,11 @@ void fri_commit_begin(Context& ctx, const FriConfig& fri, unsigned log_max_heigh
     st.d_chal.p = st.d_block.p;
     st.d_roots.p = st.d_block.p + 64;
     st.d_final.p = reinterpret_cast<Ef*>(st.d_block.p + 64 + n_roots);  // 16-byte aligned: 64 + 8 R words
-    h2d(ctx, st.d_chal.p, &hc, sizeof hc);
+    uint32_t slot[64] = {0};
+    static_assert(sizeof(DevChallenger) <= FRI_POW_WORD * 4, "the hint word lies behind the challenger");
+    memcpy(slot, &hc, sizeof hc);
+    slot[FRI_POW_WORD] = FRI_POW_NONE;
+    h2d(ctx, st.d_chal.p, slot, sizeof slot);
     st.d_betas = DevBuf<Ef>(&ctx, std::max<size_t>(st.R_total, 1));
 }
 
@@ -563,8 +567,10 @@ void fri_commit_rounds(Context& ctx, const FriConfig& fri, DevBuf<Ef> folded, ui
         DevBuf<Ef> tail_vecs(&ctx, 2 * (size_t)L0);
         DevBuf<uint32_t> tail_trees(&ctx, 8 * 2 * (size_t)L0);
         const size_t ri = st.rounds.size();
+        static const bool host_grind = [] { const char* e = getenv("TS_HOST_GRIND"); return e && atoi(e) != 0; }();
         launch_fri_tail(ctx, folded.p, L0, fri.blowup(), dch, tail_vecs.p, tail_trees.p,
-                        st.d_roots.p + 8 * ri, st.d_betas.p + ri, st.d_final.p);
+                        st.d_roots.p + 8 * ri, st.d_betas.p + ri, st.d_final.p, fri.proof_of_work_bits,
+                        host_grind ? nullptr : st.d_chal.p + FRI_POW_WORD);
         uint32_t L = L0;
         size_t voff = 0, toff = 0;
         while (L > fri.blowup()) {
@@ -599,6 +605,7 @@ Ef fri_commit_finish(Context& ctx, const FriConfig& fri, BfChallenger& challenge
     std::vector<uint32_t> block(st.d_block.n);
     d2h_sync(ctx, block.data(), st.d_block.p, block.size() * 4);
     memcpy(&hc, block.data(), sizeof hc);
+    st.pow_hint = block[FRI_POW_WORD];
     memcpy(roots.data(), block.data() + 64, roots.size() * 4);
     memcpy(fin.data(), block.data() + 64 + roots.size(), fin.size() * sizeof(Ef));
     challenger.import_dev(hc);
@@ -608,6 +615,17 @@ Ef fri_commit_finish(Context& ctx, const FriConfig& fri, BfChallenger& challenge
         if (!ef_eq(x, final_poly))
             throw FinalPolyNotConstant("FRI: final polynomial is not constant (assert_eq!(x, final_poly))");
     return final_poly;
+}
+
+uint32_t fri_pow_witness(BfChallenger& challenger, unsigned bits, const FriCommit& st) {
+    if (st.pow_hint < (1u << 12)) {
+        BfChallenger clone = challenger;
+        if (clone.check_witness(bits, st.pow_hint)) {
+            challenger = clone;
+            return st.pow_hint;
+        }
+    }
+    return challenger.grind(bits);
 }
 
 // ------------------------------------------------------------------ bf_prove
@@ -755,7 +773,7 @@ void TwoAdicFriPcs::fri_prove(std::vector<DevBuf<Ef>>& inputs, const std::vector
     uint32_t pow_witness;
     {
         StageTimer t(&ctx, "grind for proof-of-work witness");
-        pow_witness = challenger.grind(fri.proof_of_work_bits);
+        pow_witness = fri_pow_witness(challenger, fri.proof_of_work_bits, st);
     }
 
     // ---- query phase :45-59

@@ -445,7 +445,7 @@ std::vector<uint32_t> prove_sharded(TwoAdicFriPcs& pcs, const Comm& comm, const 
     uint32_t pow_witness;
     {
         StageTimer t(&ctx, "grind for proof-of-work witness");
-        pow_witness = challenger.grind(fri.proof_of_work_bits);  // prover.rs:43
+        pow_witness = fri_pow_witness(challenger, fri.proof_of_work_bits, st);  // prover.rs:43
     }
 
     // ---- query phase (prover.rs:45-59): a rank answers the queries that fall into its slab

@@ -700,6 +700,36 @@ def test_edge_shapes_bit_identical(ctx, orc, name, make, has_pis, cfg):
     ts.verify(config, air, ts.BfChallenger(), proof, pis)
 
 
+@pytest.mark.parametrize("bits", [0, 1, 5, 8, 10, 11])
+def test_proof_of_work_witness_found_on_the_device(ctx, orc, bits):
+    # fri/src/prover.rs:43 `challenger.grind`: the last commit-phase kernel tries 256 candidates a pass and
+    # hands the host the smallest witness that passes (csrc/fri.hip: k_fri_tail); the host confirms it with
+    # one sponge step.  Same witness, same proof as the oracle's serial search -- over several transcripts,
+    # for bit counts whose witnesses lie in the first pass (<= 8 bits, mostly) and beyond it (10, 11 bits:
+    # one candidate in ~340 / ~680 passes)
+    seen = []
+    for a0 in range(4):
+        trace = generate_fibonacci_trace(a0, 1, 1 << 6)
+        pis = fibonacci_public_values(trace)
+        tape = ts.air_tape(FibonacciAir(), len(pis))
+        cfg = (2, 3, bits)
+        want = None
+        try:
+            want = orc.prove(orc.FriConfig(*cfg), tape, trace, pis)
+        except Exception:  # no witness below 4096: the product must refuse too
+            with pytest.raises(ts._lib.TsError):
+                ts.prove(ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(*cfg), ctx)), FibonacciAir(), ts.BfChallenger(), trace, pis)
+            continue
+        proof = ts.prove(ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(*cfg), ctx)), FibonacciAir(), ts.BfChallenger(), trace, pis)
+        assert len(proof.words) == len(want) and (proof.words == want).all()
+        seen.append(proof.pow_witness)
+    assert seen, "no transcript had a witness"
+    if bits == 0:
+        assert seen == [0] * len(seen)
+    if bits >= 10:
+        assert max(seen) >= 256, f"no witness beyond the first pass was exercised: {seen}"
+
+
 def test_zero_queries_refused(ctx):
     with pytest.raises(ts._lib.TsError):
         ts.prove(ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(2, 0, 8), ctx)), SynthMulAir(64),

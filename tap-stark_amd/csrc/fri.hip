@@ -550,18 +550,17 @@ void launch_fri_tail(Context& ctx, const Ef* in, uint32_t L0, uint32_t blowup, D
     TS_HIP(hipGetLastError());
 }
 
-// every commit-phase opening of every query in one launch (bf_answer_query, fri/src/prover.rs:69-90):
-// blockIdx.y = round; per query 8 value words (the row of two EF4) then 8*log_leaves path words
-__global__ void k_gather_fri(const FriGatherDesc* __restrict__ descs, const uint32_t* __restrict__ indices,
-                             uint32_t n_idx, uint32_t* __restrict__ out) {
-    const FriGatherDesc d = descs[blockIdx.y];
+// one descriptor's share: per query 8 value words (the row of two EF4; skipped when vec == nullptr) then
+// 8*log_leaves path words
+__device__ __forceinline__ void gather_desc(const FriGatherDesc d, const uint32_t* __restrict__ indices,
+                                            uint32_t n_idx, uint32_t* __restrict__ out) {
     const uint32_t per_q = 8 + 8 * d.log_leaves;
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_idx * per_q) return;
     const uint32_t q = t / per_q, e = t % per_q;
     const uint64_t row = indices[q] >> d.shift;
     if (e < 8) {
-        out[d.out_vals + (uint64_t)q * 8 + e] = d.vec[8 * row + e];
+        if (d.vec != nullptr) out[d.out_vals + (uint64_t)q * 8 + e] = d.vec[8 * row + e];
     } else {
         const uint32_t l = (e - 8) >> 3, word = (e - 8) & 7;
         uint64_t off = 0;
@@ -570,6 +569,48 @@ __global__ void k_gather_fri(const FriGatherDesc* __restrict__ descs, const uint
         out[d.out_path + ((uint64_t)q * d.log_leaves + l) * 8 + word] = d.tree[8 * node + word];
     }
 }
+// every commit-phase opening of every query in one launch (bf_answer_query, fri/src/prover.rs:69-90):
+// blockIdx.y = round
+__global__ void k_gather_fri(const FriGatherDesc* __restrict__ descs, const uint32_t* __restrict__ indices,
+                             uint32_t n_idx, uint32_t* __restrict__ out) {
+    gather_desc(descs[blockIdx.y], indices, n_idx, out);
+}
+
+// The query phase of one proof in one launch (kernels.hpp): blockIdx.y < n_rows: the opened rows of
+// committed batch blockIdx.y (k_gather_rows' work, the matrix table read from device memory); then one
+// descriptor each.
+__global__ void k_gather_queries(const RowGatherJob* __restrict__ rows, uint32_t n_rows,
+                                 const FriGatherDesc* __restrict__ descs, const uint32_t* __restrict__ indices,
+                                 uint32_t n_idx, uint32_t* __restrict__ out) {
+    if (blockIdx.y >= n_rows) {
+        gather_desc(descs[blockIdx.y - n_rows], indices, n_idx, out);
+        return;
+    }
+    const RowGatherJob& jb = rows[blockIdx.y];
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t total = jb.mats.total_width;
+    if (t >= n_idx * total) return;
+    const uint32_t q = t / total;
+    uint32_t c = t % total;
+    uint32_t mi = 0;
+    while (c >= jb.mats.width[mi]) {
+        c -= jb.mats.width[mi];
+        mi++;
+    }
+    const uint64_t row = ((uint64_t)indices[q] >> jb.shift) >> jb.mats.row_shift[mi];
+    out[jb.out + t] = jb.mats.d[mi][(uint64_t)c * jb.mats.col_stride[mi] + row];
+}
+void launch_gather_queries(Context& ctx, const RowGatherJob* d_rows, uint32_t n_rows, uint32_t max_row_width,
+                           const FriGatherDesc* d_descs, uint32_t n_descs, uint32_t max_log_leaves,
+                           const uint32_t* d_indices, uint32_t n_idx, uint32_t* out) {
+    if (!n_idx || n_rows + n_descs == 0) return;
+    const uint32_t per_q = std::max(n_descs ? 8 + 8 * max_log_leaves : 0u, n_rows ? max_row_width : 0u);
+    if (!per_q) return;
+    TS_LAUNCH(ctx, k_gather_queries, dim3((n_idx * per_q + 255) / 256, n_rows + n_descs), dim3(256), 0, d_rows,
+              n_rows, d_descs, d_indices, n_idx, out);
+    TS_HIP(hipGetLastError());
+}
+
 void launch_gather_fri(Context& ctx, const FriGatherDesc* d_descs, uint32_t n_rounds,
                        uint32_t max_log_leaves, const uint32_t* d_indices, uint32_t n_idx,
                        uint32_t* out) {

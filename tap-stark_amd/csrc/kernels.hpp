@@ -232,6 +232,20 @@ struct FriGatherDesc {
 void launch_gather_fri(Context& ctx, const FriGatherDesc* d_descs, uint32_t n_rounds,
                        uint32_t max_log_leaves, const uint32_t* d_indices, uint32_t n_idx,
                        uint32_t* out);
+// The whole query phase of one proof in ONE launch (after the host's sync the stream is empty, and
+// every launch on an empty stream costs the ~4 us it takes to reach the GPU: five launches were 16 us
+// of a 3.4 ms proof).  Row jobs: the opened rows of a committed batch (k_gather_rows' work); descriptor
+// jobs as above, where vec == nullptr means "path only" (the batch's Merkle path) and log_leaves == 0
+// "values only" (a pass-through input).  Both tables are device arrays.
+struct RowGatherJob {
+    LeafMats mats;
+    uint32_t shift;  // row = index >> shift (>> row_shift[i] per matrix)
+    uint32_t pad;
+    uint64_t out;    // word offset of [query][total_width] in `out`
+};
+void launch_gather_queries(Context& ctx, const RowGatherJob* d_rows, uint32_t n_rows, uint32_t max_row_width,
+                           const FriGatherDesc* d_descs, uint32_t n_descs, uint32_t max_log_leaves,
+                           const uint32_t* d_indices, uint32_t n_idx, uint32_t* out);
 
 // ---- alubench.hip ---------------------------------------------------------------------------
 // whole-chip rate of NTT butterflies (kind 0) or Blake3 compressions (kind 1), no memory traffic

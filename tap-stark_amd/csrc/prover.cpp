@@ -802,38 +802,64 @@ void TwoAdicFriPcs::fri_prove(std::vector<DevBuf<Ef>>& inputs, const std::vector
     for (size_t k = 0; k < o_pass.size(); k++) {
         o_pass[k] = off; off += (size_t)Q * 8;
     }
-    // bf_answer_query :69-90: index_i = index >> i >> 1, all rounds in one launch
-    std::vector<FriGatherDesc> descs(std::max(R, 1u));
-    uint32_t max_ll = 0;
-    for (uint32_t r = 0; r < R; r++) {
-        descs[r].vec = reinterpret_cast<const uint32_t*>(rounds[r].vec);
-        descs[r].tree = rounds[r].tree;
-        descs[r].log_leaves = rounds[r].log_leaves;
-        descs[r].shift = r + 1;
-        descs[r].out_vals = o_fvals[r];
-        descs[r].out_path = o_fpath[r];
-        max_ll = std::max(max_ll, rounds[r].log_leaves);
+    // The whole query phase is ONE launch (launch_gather_queries): the opened rows of every committed batch
+    // (two_adic_pcs.rs:403-409: bits_reduced = log_global_max_height - log_max_height(batch)), and as
+    // descriptors the batches' Merkle paths (no values), bf_answer_query :69-90 for every commit round
+    // (index_i = index >> i >> 1) and the pass-through inputs (values only: the pair holding element
+    // index >> shift).
+    std::vector<RowGatherJob> rjobs(n_in_rounds);
+    uint32_t max_row_w = 0;
+    for (size_t k = 0; k < n_in_rounds; k++) {
+        rjobs[k].mats = lms[k];
+        rjobs[k].shift = log_max_height - input_rounds[k]->log_height;
+        rjobs[k].pad = 0;
+        rjobs[k].out = o_rows[k];
+        max_row_w = std::max(max_row_w, lms[k].total_width);
     }
-    // descriptors, then the indices, in ONE upload
-    std::vector<unsigned char> up(descs.size() * sizeof(FriGatherDesc) + indices.size() * 4);
-    memcpy(up.data(), descs.data(), descs.size() * sizeof(FriGatherDesc));
-    memcpy(up.data() + descs.size() * sizeof(FriGatherDesc), indices.data(), indices.size() * 4);
+    std::vector<FriGatherDesc> descs;
+    uint32_t max_ll = 0;
+    for (size_t k = 0; k < n_in_rounds; k++) {
+        FriGatherDesc d{};
+        d.vec = nullptr;
+        d.tree = input_rounds[k]->tree.p;
+        d.log_leaves = input_rounds[k]->log_height;
+        d.shift = log_max_height - input_rounds[k]->log_height;
+        d.out_path = o_path[k];
+        descs.push_back(d);
+        max_ll = std::max(max_ll, d.log_leaves);
+    }
+    for (uint32_t r = 0; r < R; r++) {
+        FriGatherDesc d{};
+        d.vec = reinterpret_cast<const uint32_t*>(rounds[r].vec);
+        d.tree = rounds[r].tree;
+        d.log_leaves = rounds[r].log_leaves;
+        d.shift = r + 1;
+        d.out_vals = o_fvals[r];
+        d.out_path = o_fpath[r];
+        descs.push_back(d);
+        max_ll = std::max(max_ll, d.log_leaves);
+    }
+    for (size_t k = 0; k < o_pass.size(); k++) {
+        FriGatherDesc d{};
+        d.vec = reinterpret_cast<const uint32_t*>(in_ptr[k]);
+        d.log_leaves = 0;
+        d.shift = log_max_height - log_lens[k] + 1;
+        d.out_vals = o_pass[k];
+        descs.push_back(d);
+    }
+    // row jobs, descriptors, then the indices, in ONE upload
+    const size_t b_rows = rjobs.size() * sizeof(RowGatherJob), b_descs = descs.size() * sizeof(FriGatherDesc);
+    static_assert(sizeof(RowGatherJob) % 8 == 0 && sizeof(FriGatherDesc) % 8 == 0, "tables stay 8-byte aligned");
+    std::vector<unsigned char> up(b_rows + b_descs + indices.size() * 4);
+    if (b_rows) memcpy(up.data(), rjobs.data(), b_rows);
+    if (b_descs) memcpy(up.data() + b_rows, descs.data(), b_descs);
+    memcpy(up.data() + b_rows + b_descs, indices.data(), indices.size() * 4);
     DevBuf<unsigned char> d_up(&ctx, up.size());
     h2d(ctx, d_up.p, up.data(), up.size());
-    struct { FriGatherDesc* p; } d_descs{reinterpret_cast<FriGatherDesc*>(d_up.p)};
-    struct { uint32_t* p; } d_idx{reinterpret_cast<uint32_t*>(d_up.p + descs.size() * sizeof(FriGatherDesc))};
     DevBuf<uint32_t> d_out(&ctx, std::max<size_t>(off, 1));
-    for (size_t k = 0; k < o_pass.size(); k++)  // the pair holding element index >> shift
-        launch_gather_ef_pairs(ctx, in_ptr[k], d_idx.p, Q, log_max_height - log_lens[k] + 1,
-                               d_out.p + o_pass[k]);
-    for (size_t k = 0; k < n_in_rounds; k++) {
-        // two_adic_pcs.rs:403-409: bits_reduced = log_global_max_height - log_max_height(batch)
-        const unsigned bits_reduced = log_max_height - input_rounds[k]->log_height;
-        launch_gather_rows(ctx, lms[k], d_idx.p, Q, bits_reduced, d_out.p + o_rows[k]);
-        launch_gather_paths(ctx, input_rounds[k]->tree.p, input_rounds[k]->log_height, d_idx.p, Q,
-                            bits_reduced, d_out.p + o_path[k]);
-    }
-    launch_gather_fri(ctx, d_descs.p, R, max_ll, d_idx.p, Q, d_out.p);
+    launch_gather_queries(ctx, reinterpret_cast<const RowGatherJob*>(d_up.p), (uint32_t)rjobs.size(), max_row_w,
+                          reinterpret_cast<const FriGatherDesc*>(d_up.p + b_rows), (uint32_t)descs.size(), max_ll,
+                          reinterpret_cast<const uint32_t*>(d_up.p + b_rows + b_descs), Q, d_out.p);
     std::vector<uint32_t> g(std::max<size_t>(off, 1));
     d2h_sync(ctx, g.data(), d_out.p, off * 4);
 

@@ -22,6 +22,8 @@ plan = {
     "config2_pmc_traffic.json": "config2_pmc_traffic.json", "config5_pmc_traffic.json": "config5_pmc_traffic.json",
     "config2_sq_counters.txt": "config2_sq_counters.txt", "config5_sq_counters.txt": "config5_sq_counters.txt",
     "power_vs_working_set.json": "power_vs_working_set.json", "power_per_stage.json": "power_per_stage.json",
+    "chain_stamps.txt": "chain_stamps.txt", "config3_launch_sequence.txt": "config3_launch_sequence.txt",
+    "config2_launch_sequence.txt": "config2_launch_sequence.txt",
 }
 for cfg in ("config3", "config2", "config4", "config5"):
     plan[f"kt_{cfg}/kt_kernel_stats.csv"] = f"{cfg}_rocprofv3_kernel_stats.csv"

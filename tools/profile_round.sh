@@ -26,6 +26,12 @@ python3 tools/shard_stages.py config4 8 > $O/config4_shard_stages.json 2>> $O/be
 python3 tools/shard_stages.py config5 8 replicated localq > $O/config5_shard_stages.json 2>> $O/bench.err
 echo "shard stages done"
 { python3 tools/latency.py; python3 tools/latency.py; } 2>> $O/bench.err | grep -v amdgpu.ids > $O/fri_hipgraph_latency.txt
+if [ -f tap-stark_amd/lib_diag/libtapstark_hip.so ]; then  # python -m tapstark_amd.build -DTS_TAIL_STAMPS
+  TS_LIB_PATH=tap-stark_amd/lib_diag/libtapstark_hip.so python3 tools/tail_stamps.py 2>> $O/bench.err | grep -v amdgpu.ids > $O/chain_stamps.txt
+fi
+bash tools/trace_proof.sh final_c3 config3 > /dev/null && cp gpurun_out/r5/trace_final_c3.txt $O/config3_launch_sequence.txt
+bash tools/trace_proof.sh final_c2 config2 > /dev/null && cp gpurun_out/r5/trace_final_c2.txt $O/config2_launch_sequence.txt
+cd $R
 echo "latency done"
 python3 tools/power_vs_working_set.py > $O/power_vs_working_set.json 2>> $O/bench.err
 python3 tools/power_per_stage.py > $O/power_per_stage.json 2>> $O/bench.err

@@ -61,9 +61,11 @@ __device__ __forceinline__ uint32_t quad_perm(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xf, 0xf, true);
 }
 
+// (rotr(d ^ a, 16) as xor + alignbit here, not the two-SDWA form of blake3.hpp: the SDWA pair draws two
+// hazard s_nops, which cost a lone wave an issue slot each -- 28 per compression)
 #define TS_B3_GQ(mx, my)       \
     a = a + b + (mx);          \
-    d = xor_rotr16(d, a);      \
+    d = rotr(d ^ a, 16);       \
     c = c + d;                 \
     b = rotr(b ^ c, 12);       \
     a = a + b + (my);          \
@@ -88,14 +90,15 @@ __device__ __forceinline__ void compress_quad(const QuadIv& s0, Msg msg, uint32_
     for (int r = 0; r < 7; r++) {
         const uint32_t m0 = msg(4 * r + 0), m1 = msg(4 * r + 1), m2 = msg(4 * r + 2), m3 = msg(4 * r + 3);
         TS_B3_GQ(m0, m1)
-        // diagonalise: this lane's diagonal is (a_j, b_{j+1}, c_{j+2}, d_{j+3})
-        b = quad_perm<0x39>(b);  // from lane (j+1) & 3
-        c = quad_perm<0x4E>(c);  // from lane (j+2) & 3
+        // diagonalise: this lane's diagonal is (a_j, b_{j+1}, c_{j+2}, d_{j+3}).  (Oldest value first -- a G
+        // ends d, c, b: a DPP read needs two wait states after the write of its source.)
         d = quad_perm<0x93>(d);  // from lane (j+3) & 3
+        c = quad_perm<0x4E>(c);  // from lane (j+2) & 3
+        b = quad_perm<0x39>(b);  // from lane (j+1) & 3
         TS_B3_GQ(m2, m3)
-        b = quad_perm<0x93>(b);
-        c = quad_perm<0x4E>(c);
         d = quad_perm<0x39>(d);
+        c = quad_perm<0x4E>(c);
+        b = quad_perm<0x93>(b);
     }
     out_lo = a ^ c;
     out_hi = b ^ d;

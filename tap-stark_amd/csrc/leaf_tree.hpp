@@ -13,7 +13,7 @@ namespace ts {
 // 192 bytes of scratch -- it measured the same 199 / 482 us on 2^22 rows of 2 / 64 elements as at the 4
 // waves its 116 VGPRs allow.  Its issue fill is 0.95; what is left is the clock.)
 template <int LOG_R, class Leaf>
-__global__ void __launch_bounds__(mt::NTH)
+__global__ void __launch_bounds__(mt::NTH, 4)  // four waves per SIMD: 128 VGPRs (it needs 127-130 as the inlining falls)
 k_leaf_tree(Leaf leaf, uint32_t* __restrict__ tree, unsigned log_leaves, int finish,
             uint32_t* __restrict__ ticket, DevChallenger* __restrict__ ch, uint32_t* __restrict__ root_out,
             Ef* __restrict__ beta_out) {

@@ -169,26 +169,89 @@ struct Tree {
         b3::lds_barrier();
     }
 
+    // The same level for the whole-tree kernels' chains (Tree<9>), between the two images `in` (PAR = 0)
+    // and `ab` (PAR = 1) taken in turn: image addresses are constants, so a lane's 28 message addresses
+    // are two register sets it derives once, and a level that fits one pass (<= NTH / 4 parents: every
+    // level of a block of 256 or fewer nodes but the first) is straight-line code -- no pass loop, no
+    // address arithmetic, no register copies.  With one wave on a SIMD EVERY instruction, scalar ones and
+    // waits included, costs the wave its four-cycle issue slot: the run-time-pointer level above issues
+    // ~350 instructions, this one ~270.
+    template <int PAR>
+    __device__ static __forceinline__ void level_fixed(Lds& lds, const Quad& q, uint32_t n_par, uint32_t* out,
+                                                       bool publish_one) {
+        const uint32_t j = threadIdx.x & 3;
+        const char* sb = reinterpret_cast<const char*>(PAR ? lds.ab : lds.in);
+        uint32_t* dst = PAR ? lds.in : lds.ab;
+        auto finish = [&](uint32_t i, uint32_t lo, uint32_t hi) {
+            dst[j * CH + i] = lo;
+            dst[(4 + j) * CH + i] = hi;
+            uint32_t* o = out + 8 * i;
+            if (publish_one) {
+                __hip_atomic_store(o + j, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(o + 4 + j, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                o[j] = lo;
+                o[4 + j] = hi;
+            }
+        };
+        if (4 * n_par <= NTH) {
+            if (threadIdx.x < 4 * n_par) {
+                uint32_t m[28], lo, hi;
+#pragma unroll
+                for (int k = 0; k < 28; k++) m[k] = *reinterpret_cast<const uint32_t*>(sb + q.pm[k]);
+                b3::compress_quad(q.iv, [&](int k) { return m[k]; }, lo, hi);
+                finish(threadIdx.x >> 2, lo, hi);
+            }
+        } else {
+            for (uint32_t t = threadIdx.x, off = 0; t < 4 * n_par; t += NTH, off += 2 * NTH) {
+                uint32_t m[28], lo, hi;
+#pragma unroll
+                for (int k = 0; k < 28; k++) m[k] = *reinterpret_cast<const uint32_t*>(sb + q.pm[k] + off);
+                b3::compress_quad(q.iv, [&](int k) { return m[k]; }, lo, hi);
+                finish(t >> 2, lo, hi);
+            }
+        }
+        b3::lds_barrier();
+    }
+
     // Reduces `count` nodes of image `src` (nodes 0..count-1, both powers of two, count <= CH) to `stop`
     // nodes.  src holds nodes [node0, node0 + count) of relative level `level`; every level produced is
     // stored in the tree.  Returns the image holding the result.  With publish, the single node of the
     // last level (stop == 1) is written through for another workgroup to read.
     // wide_from: levels with at least this many parents run one compression per lane (0 = never).
+    // FROM_IN (Tree<9> only): src is lds.in and the levels alternate between `in` and `ab` (level_fixed);
+    // the producer's nodes are overwritten.
+    template <bool FROM_IN = false>
     __device__ static __forceinline__ const uint32_t* reduce_levels(Lds& lds, const uint32_t* src, uint32_t count,
                                                                     uint32_t stop, const Levels& lv, unsigned level,
                                                                     uint64_t node0, const Quad& q, bool publish,
                                                                     uint32_t wide_from = 0) {
-        unsigned l = 0;
-        for (uint32_t n_par = count >> 1; n_par >= stop; n_par >>= 1, l++) {
-            uint32_t* dst = lds.ab + ((l & 1) ? CH / 2 : 0);
-            level++;
-            node0 >>= 1;
-            level_step(q, src, dst, n_par, lv.at(level, node0), publish && n_par == 1,
-                       wide_from != 0 && n_par >= wide_from);
-            src = dst;
-            TS_TREE_STAMP(10 + l, blockIdx.x == 0 && publish);
+        if constexpr (FROM_IN && LC == 9) {
+            uint32_t n_par = count >> 1;
+            for (;;) {
+                if (n_par < stop) return lds.in;
+                level++;
+                node0 >>= 1;
+                level_fixed<0>(lds, q, n_par, lv.at(level, node0), publish && n_par == 1);
+                n_par >>= 1;
+                if (n_par < stop) return lds.ab;
+                level++;
+                node0 >>= 1;
+                level_fixed<1>(lds, q, n_par, lv.at(level, node0), publish && n_par == 1);
+                n_par >>= 1;
+            }
+        } else {
+            unsigned l = 0;
+            for (uint32_t n_par = count >> 1; n_par >= stop; n_par >>= 1, l++) {
+                uint32_t* dst = lds.ab + ((l & 1) ? CH / 2 : 0);
+                level++;
+                node0 >>= 1;
+                level_step(q, src, dst, n_par, lv.at(level, node0), publish && n_par == 1,
+                           wide_from != 0 && n_par >= wide_from);
+                src = dst;
+            }
+            return src;
         }
-        return src;
     }
 
     // One block: `count` (a power of two <= 8 * CH) nodes [node0, node0 + count) of relative
@@ -202,12 +265,12 @@ struct Tree {
             prod.fill(lds.in, node0, count);
             TS_TREE_STAMP(1, blockIdx.x == 0 && level == 0);
             if (count == 1) return lds.in;
-            return reduce_levels(lds, lds.in, count, 1, lv, level, node0, q, publish);
+            return reduce_levels<true>(lds, lds.in, count, 1, lv, level, node0, q, publish);
         }
         const uint32_t n_chunks = count >> LC;
         for (uint32_t c = 0; c < n_chunks; c++) {
             prod.fill(lds.in, node0 + (uint64_t)c * CH, CH);
-            const uint32_t* x = reduce_levels(lds, lds.in, CH, KEEP, lv, level, node0 + (uint64_t)c * CH, q, false);
+            const uint32_t* x = reduce_levels<true>(lds, lds.in, CH, KEEP, lv, level, node0 + (uint64_t)c * CH, q, false);
             {
                 const uint32_t w = threadIdx.x >> LOG_KEEP, n = threadIdx.x & (KEEP - 1);  // 8 x 32 = 256 lanes
                 lds.keep[w * CH + c * KEEP + n] = x[w * CH + n];

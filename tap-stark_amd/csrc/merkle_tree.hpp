@@ -121,10 +121,9 @@ struct Tree {
     // length -- right where other workgroups fill the SIMDs (leaf_tree_body's blocks), wrong for a
     // finisher that runs alone.  publish_one: the level's single node is written through for another
     // workgroup to read.
-    // (Image addresses as compile-time constants -- the levels unrolled over the three (source,
-    // destination) pairs, no address arithmetic left in a level -- were built and measured in round 5:
-    // 84 more VGPRs, three copies of the code, and the eight levels of a 256-node block took 8.8 us
-    // against 8.5 with the run-time pointers below.  One add per message word is 0.05 us of a 0.85 us level.)
+    // (Run-time image pointers: one copy of the code, one add per message word.  This is the level of the
+    // leaf-tree kernel -- bound by throughput and by its 128-VGPR budget -- and of the chunked blocks; the
+    // chains of the whole-tree kernels take level_fixed below.)
     __device__ static __forceinline__ void level_step(const Quad& q, const uint32_t* src, uint32_t* dst, uint32_t n_par,
                                                       uint32_t* out, bool publish_one, bool wide) {
         if (wide) {
@@ -173,9 +172,12 @@ struct Tree {
     // and `ab` (PAR = 1) taken in turn: image addresses are constants, so a lane's 28 message addresses
     // are two register sets it derives once, and a level that fits one pass (<= NTH / 4 parents: every
     // level of a block of 256 or fewer nodes but the first) is straight-line code -- no pass loop, no
-    // address arithmetic, no register copies.  With one wave on a SIMD EVERY instruction, scalar ones and
-    // waits included, costs the wave its four-cycle issue slot: the run-time-pointer level above issues
-    // ~350 instructions, this one ~270.
+    // address arithmetic, no register copies.  With ONE wave on a SIMD every instruction -- scalar ones,
+    // waits and hazard nops included -- costs the wave a four-cycle issue slot, so a level's time is its
+    // instruction count: ~350 with the run-time pointers above, ~270 here; the eight levels of a 256-node
+    // block 8.5 -> 7.3 us (tools/tail_stamps.py).  (A first attempt -- three image pairs in / ping / pong,
+    // the single pass peeled inside the pass loop -- measured 8.8: the compiler folded the peeled pass
+    // back into the loop, address adds and all, and there were three copies of the code.)
     template <int PAR>
     __device__ static __forceinline__ void level_fixed(Lds& lds, const Quad& q, uint32_t n_par, uint32_t* out,
                                                        bool publish_one) {

@@ -303,17 +303,12 @@ struct StridedLeaf {
     }
     __device__ __forceinline__ void digest(uint64_t r, uint32_t cv[8]) const {
         b3::iv(cv);
-        // column pointer (uniform: scalar registers) + the row's byte offset (one 32-bit register for all
-        // columns; rows < 2^27): the load takes both as they are (global_load ... v_off, s[base]) -- as
-        // base + r first and the column stride added per load it was a 64-bit vector add per element
-        const uint32_t boff = (uint32_t)r * 4u;
-        const char* p = reinterpret_cast<const char*>(base);
-        const uint64_t sb = stride * 4;
+        const uint32_t* p = base + r;
         for (uint32_t blk = 0; blk < n_full; blk++) {
             uint32_t m[16];
 #pragma unroll
-            for (int j = 0; j < 16; j++) m[j] = *reinterpret_cast<const uint32_t*>(p + (uint64_t)j * sb + boff);
-            p += 16 * sb;
+            for (int j = 0; j < 16; j++) m[j] = p[(uint64_t)j * stride];
+            p += 16 * stride;
             const uint32_t flags = (blk == 0 ? b3::CHUNK_START : 0u) |
                                    (blk + 1 == n_full && rem == 0 ? (b3::CHUNK_END | b3::ROOT) : 0u);
             b3::compress(cv, m, 64, flags);
@@ -321,8 +316,7 @@ struct StridedLeaf {
         if (rem != 0) {
             uint32_t m[16];
 #pragma unroll
-            for (int j = 0; j < 16; j++)
-                m[j] = (uint32_t)j < rem ? *reinterpret_cast<const uint32_t*>(p + (uint64_t)j * sb + boff) : 0u;
+            for (int j = 0; j < 16; j++) m[j] = (uint32_t)j < rem ? p[(uint64_t)j * stride] : 0u;
             b3::compress(cv, m, rem * 4, (n_full == 0 ? b3::CHUNK_START : 0u) | b3::CHUNK_END | b3::ROOT);
         }
     }

@@ -9,7 +9,7 @@ cd $R
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_config3_k20.json 2> $O/bench.err
 cd /tmp && export TMPDIR=/tmp
 rm -rf $O/kt_config3
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_config3 -o kt -- python3 $R/tools/prof_prove.py 3 config3 > $O/kt_config3.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_config3 -o kt -- python3 $R/tools/prof_prove.py 10 config3 > $O/kt_config3.log 2>&1
 find $O/kt_config3 -name "*kernel_trace.csv" -delete
 head -3 $O/kt_config3/kt_kernel_stats.csv | cut -c1-50,150-230
 python3 - <<PY

@@ -47,7 +47,7 @@ for cfg in config3 config2 config4 config5; do
   done
 done
 for cfg in config3 config2 config4 config5; do
-  n=3; [ $cfg = config4 ] && n=2
+  n=3; [ $cfg = config4 ] && n=2; [ $cfg = config3 ] && n=10
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$cfg -o kt -- python3 $R/tools/prof_prove.py $n $cfg > $O/kt_$cfg.log 2>&1 || { echo "kt $cfg failed"; tail -5 $O/kt_$cfg.log; exit 1; }
 done
 cd $R

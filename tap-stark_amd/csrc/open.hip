@@ -158,9 +158,19 @@ k_bary_finish(const uint32_t* __restrict__ partial, uint32_t n_blocks, uint32_t 
     __shared__ uint32_t red[4][4];
     const uint32_t j = blockIdx.x * 4 + (threadIdx.x & 3);
     uint32_t v = 0;
-    if (j < n_words)
-        for (uint32_t b = threadIdx.x >> 2; b < n_blocks; b += 64)
-            v = add(v, partial[(uint64_t)b * n_words + j]);
+    if (j < n_words) {
+        // eight loads in flight (as one load and one add per trip every trip waited for its own load: with
+        // 2048 partial blocks that was 32 round trips to L2, 10-14 us for a kernel that moves kilobytes)
+        uint32_t b = threadIdx.x >> 2;
+        for (; b + 7 * 64 < n_blocks; b += 8 * 64) {
+            uint32_t x[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) x[k] = partial[(uint64_t)(b + 64 * k) * n_words + j];
+#pragma unroll
+            for (int k = 0; k < 8; k++) v = add(v, x[k]);
+        }
+        for (; b < n_blocks; b += 64) v = add(v, partial[(uint64_t)b * n_words + j]);
+    }
     // reduce over the 64 threads that share (threadIdx.x & 3): lanes 4 apart within a wave, 4 waves
 #pragma unroll
     for (int off = 32; off >= 4; off >>= 1) v = add(v, __shfl_down(v, off, 64));

@@ -45,9 +45,13 @@ void launch_transpose_to_row_major(Context& ctx, const uint32_t* src, uint64_t c
 //   out: out[c][beta*n + t] = p_c(shift * w_N^bitrev(beta*n+t)),  N = n << log_blowup
 // With a coset range (beta0, n_beta > 0) only the row blocks beta0 .. beta0+n_beta-1 are produced,
 // at out[c][(beta - beta0)*n + t]: the slab of a rank that owns those cosets (sharded prover).
+// Two matrices of one height in ONE set of launches (the two quotient chunks: each is four columns, and a
+// launch set of its own left the chip a quarter full three times over): evals2 != nullptr holds columns
+// gw .. ncols-1 (same column stride), extended on its own coset shift2; `out` takes all ncols columns.
 void coset_lde(Context& ctx, uint32_t* evals, uint64_t in_col_stride, uint32_t ncols, unsigned log_n,
                unsigned log_blowup, uint32_t shift, uint32_t* out, uint64_t out_col_stride,
-               uint32_t beta0 = 0, uint32_t n_beta = 0, bool first_round_done = false);
+               uint32_t beta0 = 0, uint32_t n_beta = 0, bool first_round_done = false,
+               uint32_t* evals2 = nullptr, uint32_t shift2 = 0, uint32_t gw = 0);
 
 // ---- merkle.hip ------------------------------------------------------------------------------
 constexpr int MAX_BATCH_MATS = 64;

@@ -287,10 +287,13 @@ __device__ __forceinline__ void chunk_rounds(uint32_t* s, unsigned sb, uint32_t 
 template <int LM, bool SKIP_R16 = false>
 __global__ void __launch_bounds__(chunk_threads(LM))
 k_intt_contig(uint32_t* __restrict__ data, uint64_t col_stride, unsigned log_n,
-              const uint32_t* __restrict__ Winv) {
+              const uint32_t* __restrict__ Winv, uint32_t* __restrict__ data2, uint32_t gw) {
     __shared__ uint32_t s[padded(1 << LM)];
     const uint32_t c = blockIdx.x;
-    uint32_t* g = data + (uint64_t)blockIdx.y * col_stride + ((uint64_t)c << LM);
+    // columns gw .. of a two-matrix launch live in the second matrix (coset_lde: evals2)
+    uint32_t* col = blockIdx.y < gw ? data + (uint64_t)blockIdx.y * col_stride
+                                    : data2 + (uint64_t)(blockIdx.y - gw) * col_stride;
+    uint32_t* g = col + ((uint64_t)c << LM);
     chunk_load<LM>(s, g);
     chunk_rounds<LM, true, SKIP_R16>(s, log_n - LM, c, Winv);
     chunk_store<LM, false>(s, g);  // read next by k_lde_mid's inverse rounds
@@ -404,7 +407,8 @@ __global__ void __launch_bounds__(NTM)
 k_lde_mid(const uint32_t* __restrict__ evals, uint64_t in_col_stride, uint32_t* __restrict__ out,
           uint64_t out_col_stride, unsigned log_n, unsigned log_len, unsigned log_T,
           unsigned row_shift, unsigned beta0, unsigned n_cosets, const uint32_t* __restrict__ W,
-          const uint32_t* __restrict__ Winv, const uint32_t* __restrict__ scale) {
+          const uint32_t* __restrict__ Winv, const uint32_t* __restrict__ scale_a,
+          const uint32_t* __restrict__ evals2, const uint32_t* __restrict__ scale_b, uint32_t gw) {
     __shared__ uint32_t s[padded(TILE)];
     constexpr int PER_THREAD = TILE / NTM;
     constexpr int LOG_TILE = TILE == 8192 ? 13 : (TILE == 16384 ? 14 : 15);
@@ -449,7 +453,11 @@ k_lde_mid(const uint32_t* __restrict__ evals, uint64_t in_col_stride, uint32_t* 
         bx = (x * (n_tiles >> 4) + pair_local) * 2 + (r & 1);
     }
     const uint32_t j2_0 = bx << log_T;
-    const uint32_t* g = evals + (uint64_t)col_id * in_col_stride + j2_0;
+    // a two-matrix launch (coset_lde: evals2): columns gw .. come from the second matrix and take its
+    // coset's scale table; the output columns follow each other either way
+    const uint32_t* g = (col_id < gw ? evals + (uint64_t)col_id * in_col_stride
+                                     : evals2 + (uint64_t)(col_id - gw) * in_col_stride) + j2_0;
+    const uint32_t* __restrict__ scale = col_id < gw ? scale_a : scale_b;
     const uint32_t total = 1u << (log_len + log_T);
     const uint32_t tmask = (1u << log_T) - 1;
     if constexpr (PLAN == 1 || PLAN == 2) {
@@ -658,8 +666,12 @@ bool launch_transpose_bitrev_r16(Context& ctx, const uint32_t* src, uint32_t* ds
 
 void coset_lde(Context& ctx, uint32_t* evals, uint64_t in_col_stride, uint32_t ncols, unsigned log_n,
                unsigned log_blowup, uint32_t shift, uint32_t* out, uint64_t out_col_stride,
-               uint32_t beta0, uint32_t n_beta, bool first_round_done) {
+               uint32_t beta0, uint32_t n_beta, bool first_round_done, uint32_t* evals2, uint32_t shift2,
+               uint32_t gw) {
     if (ncols == 0) return;
+    TS_REQUIRE(evals2 == nullptr || (gw >= 1 && gw < ncols && shift2 != 0), TS_ERR_INVALID,
+               "coset_lde: second matrix needs its first column and its shift");
+    if (evals2 == nullptr) gw = 0xffffffffu;
     TS_REQUIRE(log_n + log_blowup <= 27, TS_ERR_INVALID, "coset_lde: log_n + log_blowup > 27");
     TS_REQUIRE(ncols >= 1 && ncols <= 65535, TS_ERR_INVALID, "coset_lde: bad column count");
     const unsigned LM = lde_chunk_log(log_n);
@@ -689,6 +701,7 @@ void coset_lde(Context& ctx, uint32_t* evals, uint64_t in_col_stride, uint32_t n
     if (n_beta == 0) n_beta = n_cosets - beta0;
     TS_REQUIRE(beta0 < n_cosets && n_beta <= n_cosets - beta0, TS_ERR_INVALID, "coset_lde: coset range");
     const uint32_t* scale = coset_scale_table(ctx, log_n, log_blowup, shift);
+    const uint32_t* scale2 = evals2 ? coset_scale_table(ctx, log_n, log_blowup, shift2) : nullptr;
 
     if (two_pass) {
         // the vectorised chunk loads need 16-byte aligned columns
@@ -704,9 +717,10 @@ void coset_lde(Context& ctx, uint32_t* evals, uint64_t in_col_stride, uint32_t n
     do {                                                                                                      \
         if (first_round_done)                                                                                 \
             TS_LAUNCH(ctx, (k_intt_contig<LMV, true>), g, dim3(chunk_threads(LMV)), 0, evals, in_col_stride, log_n, \
-                      Winv);                                                                                  \
+                      Winv, evals2, gw);                                                                      \
         else                                                                                                  \
-            TS_LAUNCH(ctx, k_intt_contig<LMV>, g, dim3(chunk_threads(LMV)), 0, evals, in_col_stride, log_n, Winv); \
+            TS_LAUNCH(ctx, k_intt_contig<LMV>, g, dim3(chunk_threads(LMV)), 0, evals, in_col_stride, log_n, Winv, \
+                      evals2, gw);                                                                            \
     } while (0)
             if (LM == 12) TS_INTT(12);
             else if (LM == 13) TS_INTT(13);
@@ -718,7 +732,7 @@ void coset_lde(Context& ctx, uint32_t* evals, uint64_t in_col_stride, uint32_t n
         const dim3 grid1((1u << (LM - log_T)) * ncols);  // PLAN 1 / 2: 1-D, see the kernel
 #define TS_MID_ARGS                                                                            \
     (const uint32_t*)evals, in_col_stride, out, out_col_stride, log_n, sA, log_T, (unsigned)LM, \
-        beta0, n_beta, W, Winv, scale
+        beta0, n_beta, W, Winv, scale, (const uint32_t*)evals2, scale2, gw
         if (!(ctx.lde_pass_mask & 2u)) {
         } else if (sA == 14)
             TS_LAUNCH(ctx, (k_lde_mid<0, 16384>), grid, dim3(NT_MID), 0, TS_MID_ARGS);
@@ -757,7 +771,8 @@ void coset_lde(Context& ctx, uint32_t* evals, uint64_t in_col_stride, uint32_t n
                       out_col_stride, log_n, W);
     } else {
         TS_LAUNCH(ctx, k_lde_mid<0>, dim3(1, ncols), dim3(NT_MID), 0, (const uint32_t*)evals,
-                  in_col_stride, out, out_col_stride, log_n, log_n, 0u, 0u, beta0, n_beta, W, Winv, scale);
+                  in_col_stride, out, out_col_stride, log_n, log_n, 0u, 0u, beta0, n_beta, W, Winv, scale,
+                  (const uint32_t*)evals2, scale2, gw);
     }
     TS_HIP(hipGetLastError());
 }

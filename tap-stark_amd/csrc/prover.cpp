@@ -189,7 +189,34 @@ std::unique_ptr<PcsData> TwoAdicFriPcs::commit(std::vector<DeviceMatrix>& evals,
         DevBuf<uint32_t> batch;
         if (same_height) batch = DevBuf<uint32_t>(&ctx_, total_w * (evals[0].height << fri_.log_blowup));
         size_t batch_col = 0;
-        for (size_t i = 0; i < evals.size(); i++) {
+        // exactly two column-major matrices of one shape (the two quotient chunks of a degree-3 AIR):
+        // ONE set of LDE launches for both (coset_lde: evals2) -- 8 columns instead of 4 twice
+        static const bool pair_knob = [] { const char* e = getenv("TS_LDE_PAIR"); return !e || atoi(e) != 0; }();
+        const bool pair = pair_knob && same_height && evals.size() == 2 && evals[0].width == evals[1].width &&
+                          evals[0].layout == DeviceMatrix::COL_MAJOR_BITREV &&
+                          evals[1].layout == DeviceMatrix::COL_MAJOR_BITREV;
+        if (pair) {
+            for (size_t i = 0; i < 2; i++)
+                TS_REQUIRE(domain_shifts[i] != 0 && domain_shifts[i] < P, TS_ERR_INVALID, "bad domain shift");
+            const uint64_t n = evals[0].height;
+            const unsigned log_n = log2_strict(n);
+            const uint64_t Ni = n << fri_.log_blowup;
+            const uint32_t w = evals[0].width;
+            // two_adic_pcs.rs:235: shift = Val::generator() / domain.shift
+            coset_lde(ctx_, evals[0].buf.p, n, 2 * w, log_n, fri_.log_blowup, mul(GENERATOR, inv_canon(domain_shifts[0])),
+                      batch.p, Ni, 0, 0, false, evals[1].buf.p, mul(GENERATOR, inv_canon(domain_shifts[1])), w);
+            for (size_t i = 0; i < 2; i++) {
+                ColMat cm;
+                cm.d = batch.p + i * (size_t)w * Ni;
+                cm.height = Ni;
+                cm.width = w;
+                cm.col_stride = Ni;
+                data->ldes.push_back(cm);
+            }
+            evals[0].buf.reset();  // consumed, both
+            evals[1].buf.reset();
+        }
+        for (size_t i = 0; i < (pair ? 0 : evals.size()); i++) {
             DeviceMatrix& m = evals[i];
             TS_REQUIRE(domain_shifts[i] != 0 && domain_shifts[i] < P, TS_ERR_INVALID, "bad domain shift");
             const uint64_t n = m.height;

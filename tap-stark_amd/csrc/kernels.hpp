@@ -144,8 +144,17 @@ void launch_check_constraints(Context& ctx, const AirProgram& air, const uint32_
 void launch_bary_weights(Context& ctx, unsigned log_n, const Ef* points_mont, uint32_t n_points,
                          Ef* out, uint32_t coset_gen = 0);
 // out[col][p] = sum_i m[col][i] * d[p][i]   (canonical EF4), i over the first n rows
+// `pending` != nullptr: the finishing pass (partial sums -> out) is left to launch_bary_finish, which takes
+// up to two pending products in one launch
+struct BaryPending {
+    DevBuf<uint32_t> partial[2];
+    uint32_t* out[2] = {nullptr, nullptr};
+    uint32_t n_blocks[2] = {0, 0}, n_words[2] = {0, 0};
+    uint32_t n = 0;
+};
 void launch_bary_dots(Context& ctx, const ColMat& m, unsigned log_n, const Ef* weights,
-                      uint32_t n_points, Ef* out /* width * n_points */);
+                      uint32_t n_points, Ef* out, BaryPending* pending = nullptr);
+void launch_bary_finish(Context& ctx, BaryPending& pending);
 // ro[X] (+)= sum_p off_p * (S(X) - rys_p) / (x_X - z_p),  S(X) = sum_i alpha^i m[i][X]
 struct ReduceArgs {
     Ef z_mont[2];

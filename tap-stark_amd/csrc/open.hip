@@ -151,12 +151,21 @@ k_bary_dots(const uint32_t* __restrict__ m, uint64_t col_stride, uint32_t width,
     }
 }
 
-// out[j] = sum over blocks of partial[block][j]  (mod p); one workgroup per 4 output words
+// out[j] = sum over blocks of partial[block][j]  (mod p); one workgroup per 4 output words.  Up to two
+// jobs in one launch (the trace's sums and the quotient chunks'): workgroups 0 .. g0-1 take job 0.
+struct BaryFinishJob {
+    const uint32_t* partial;
+    uint32_t* out;
+    uint32_t n_blocks, n_words;
+};
 __global__ void __launch_bounds__(256)
-k_bary_finish(const uint32_t* __restrict__ partial, uint32_t n_blocks, uint32_t n_words,
-              uint32_t* __restrict__ out) {
+k_bary_finish(BaryFinishJob j0, BaryFinishJob j1, uint32_t g0) {
     __shared__ uint32_t red[4][4];
-    const uint32_t j = blockIdx.x * 4 + (threadIdx.x & 3);
+    const bool first = blockIdx.x < g0;
+    const uint32_t* __restrict__ partial = first ? j0.partial : j1.partial;
+    uint32_t* __restrict__ out = first ? j0.out : j1.out;
+    const uint32_t n_blocks = first ? j0.n_blocks : j1.n_blocks, n_words = first ? j0.n_words : j1.n_words;
+    const uint32_t j = (first ? blockIdx.x : blockIdx.x - g0) * 4 + (threadIdx.x & 3);
     uint32_t v = 0;
     if (j < n_words) {
         // eight loads in flight (as one load and one add per trip every trip waited for its own load: with
@@ -182,8 +191,23 @@ k_bary_finish(const uint32_t* __restrict__ partial, uint32_t n_blocks, uint32_t 
                      add(red[2][threadIdx.x], red[3][threadIdx.x]));
 }
 
+// the finishing pass of one or two launch_bary_dots(..., pending) calls
+void launch_bary_finish(Context& ctx, BaryPending& pend) {
+    if (pend.n == 0) return;
+    BaryFinishJob j[2] = {{nullptr, nullptr, 0, 0}, {nullptr, nullptr, 0, 0}};
+    uint32_t g[2] = {0, 0};
+    for (uint32_t i = 0; i < pend.n; i++) {
+        j[i] = BaryFinishJob{pend.partial[i].p, pend.out[i], pend.n_blocks[i], pend.n_words[i]};
+        g[i] = (pend.n_words[i] + 3) / 4;
+    }
+    TS_LAUNCH(ctx, k_bary_finish, dim3(g[0] + g[1]), dim3(256), 0, j[0], j[1], g[0]);
+    TS_HIP(hipGetLastError());
+    for (uint32_t i = 0; i < pend.n; i++) pend.partial[i].reset();
+    pend.n = 0;
+}
+
 void launch_bary_dots(Context& ctx, const ColMat& m, unsigned log_n, const Ef* weights,
-                      uint32_t n_points, Ef* out) {
+                      uint32_t n_points, Ef* out, BaryPending* pending) {
     const uint64_t n = 1ull << log_n;
     const bool narrow = m.width <= 8;
     const uint32_t tr = narrow ? 512 : 64;
@@ -211,9 +235,16 @@ void launch_bary_dots(Context& ctx, const ColMat& m, unsigned log_n, const Ef* w
             TS_LAUNCH(ctx, (k_bary_dots<1, 64>), grid, dim3(256), 0, md, m.col_stride, m.width, log_n,
                       weights, partial.p, rows_per_block);
     }
-    TS_LAUNCH(ctx, k_bary_finish, dim3((n_words + 3) / 4), dim3(256), 0, (const uint32_t*)partial.p,
-              n_blocks, n_words, reinterpret_cast<uint32_t*>(out));
     TS_HIP(hipGetLastError());
+    BaryPending own;
+    BaryPending& pend = pending ? *pending : own;
+    if (pend.n == 2) launch_bary_finish(ctx, pend);
+    pend.partial[pend.n] = std::move(partial);
+    pend.out[pend.n] = reinterpret_cast<uint32_t*>(out);
+    pend.n_blocks[pend.n] = n_blocks;
+    pend.n_words[pend.n] = n_words;
+    pend.n++;
+    if (!pending) launch_bary_finish(ctx, pend);
 }
 
 // ------------------------------------------------------------------ reduce (generic)

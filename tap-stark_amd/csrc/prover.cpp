@@ -394,7 +394,8 @@ DevBuf<Ef> TwoAdicFriPcs::open_reduce_slab(const PcsData& trace_data, const PcsD
         launch_bary_weights(ctx_, log_n, pts_mont, 2, weights.p, coset_gen);
         // the last kernels of the stage write the sums straight into the context's mailbox (host memory)
         struct { Ef* p; } sums{reinterpret_cast<Ef*>(ctx_.mailbox(4 * raw.size()))};
-        launch_bary_dots(ctx_, tr, log_n, weights.p, 2, sums.p);  // [col][point]
+        BaryPending pend;  // the trace's partial sums and the chunks' are added up in one launch
+        launch_bary_dots(ctx_, tr, log_n, weights.p, 2, sums.p, &pend);  // [col][point]
         bool chunks_contiguous = true;  // commit() lays the chunk LDEs back to back
         for (uint32_t c = 0; c < qd; c++)
             chunks_contiguous = chunks_contiguous && quotient_data.ldes[c].col_stride == quotient_data.ldes[0].col_stride &&
@@ -402,11 +403,12 @@ DevBuf<Ef> TwoAdicFriPcs::open_reduce_slab(const PcsData& trace_data, const PcsD
         if (chunks_contiguous && qd > 1) {
             ColMat all = quotient_data.ldes[0];
             all.width = 4 * qd;
-            launch_bary_dots(ctx_, all, log_n, weights.p, 1, sums.p + 2 * w);
+            launch_bary_dots(ctx_, all, log_n, weights.p, 1, sums.p + 2 * w, &pend);
         } else {
             for (uint32_t c = 0; c < qd; c++)
-                launch_bary_dots(ctx_, quotient_data.ldes[c], log_n, weights.p, 1, sums.p + 2 * w + 4 * c);
+                launch_bary_dots(ctx_, quotient_data.ldes[c], log_n, weights.p, 1, sums.p + 2 * w + 4 * c, &pend);
         }
+        launch_bary_finish(ctx_, pend);
         ctx_.sync();
         memcpy(raw.data(), sums.p, raw.size() * sizeof(Ef));
     }

@@ -416,7 +416,7 @@ k_fri_tail(const Ef* __restrict__ in, uint32_t L0, uint32_t blowup, DevChallenge
            const uint32_t* __restrict__ Winv, Ef* __restrict__ tail_vecs,
            uint32_t* __restrict__ tail_trees, uint32_t* __restrict__ roots_out,
            Ef* __restrict__ betas_out, Ef* __restrict__ final_out, uint32_t pow_bits,
-           uint32_t* __restrict__ pow_out) {
+           uint32_t* __restrict__ pow_out, const Ef* __restrict__ beta_in) {
     __shared__ Ef bufA[TAIL_MAX];
     __shared__ Ef bufB[TAIL_MAX / 2];
     __shared__ uint32_t dig[2][8 * TAIL_STRIDE];  // digest images [word][node], used in turn
@@ -442,7 +442,15 @@ k_fri_tail(const Ef* __restrict__ in, uint32_t L0, uint32_t blowup, DevChallenge
     Ef* cur = bufA;
     Ef* nxt = bufB;
     STAMP(0);
-    for (uint32_t i = threadIdx.x; i < L0; i += TAIL_NT) cur[i] = load_ef(in + i);
+    if (beta_in != nullptr) {
+        // `in` is the previous round's vector (2 L0 elements): its fold with that round's challenge is this
+        // kernel's first vector (one launch less on the chain than a fold kernel in front)
+        const Ef hb = ef_mul_base(ef_to_mont(load_ef(beta_in)), HALF_MONT);
+        for (uint32_t i = threadIdx.x; i < L0; i += TAIL_NT)
+            cur[i] = fold_one(load_ef(in + 2 * i), load_ef(in + 2 * i + 1), Winv[L0 + i], hb, HALF_MONT);
+    } else {
+        for (uint32_t i = threadIdx.x; i < L0; i += TAIL_NT) cur[i] = load_ef(in + i);
+    }
     __syncthreads();
     STAMP(1);
     uint32_t L = L0, voff = 0, toff = 0, t = 0;
@@ -538,15 +546,15 @@ k_fri_tail(const Ef* __restrict__ in, uint32_t L0, uint32_t blowup, DevChallenge
 
 void launch_fri_tail(Context& ctx, const Ef* in, uint32_t L0, uint32_t blowup, DevChallenger* ch,
                      Ef* tail_vecs, uint32_t* tail_trees, uint32_t* roots_out, Ef* betas_out,
-                     Ef* final_out, uint32_t pow_bits, uint32_t* pow_out) {
+                     Ef* final_out, uint32_t pow_bits, uint32_t* pow_out, const Ef* beta_in) {
     TS_REQUIRE(pow_bits <= 31, TS_ERR_INVALID, "fri_tail: proof-of-work bits > 31");
     TS_REQUIRE(L0 <= (uint32_t)TAIL_MAX && L0 >= 1, TS_ERR_INVALID, "fri_tail: vector too long");
     unsigned log_l = 0;
     while ((1u << log_l) < L0) log_l++;
-    ctx.ensure_twiddles(log_l == 0 ? 1 : log_l);
+    ctx.ensure_twiddles(log_l + (beta_in ? 1 : 0) == 0 ? 1 : log_l + (beta_in ? 1 : 0));
     TS_LAUNCH(ctx, k_fri_tail, dim3(1), dim3(TAIL_NT), 0, in, L0, blowup, ch,
               (const uint32_t*)ctx.d_twiddle_inv, tail_vecs, tail_trees, roots_out, betas_out,
-              final_out, pow_bits, pow_out);
+              final_out, pow_bits, pow_out, beta_in);
     TS_HIP(hipGetLastError());
 }
 

@@ -223,7 +223,10 @@ constexpr int FRI_TAIL_LOG = 10;
 constexpr uint32_t FRI_POW_NONE = 0xffffffffu;
 void launch_fri_tail(Context& ctx, const Ef* in, uint32_t L0, uint32_t blowup, DevChallenger* ch,
                      Ef* tail_vecs, uint32_t* tail_trees, uint32_t* roots_out, Ef* betas_out,
-                     Ef* final_out, uint32_t pow_bits = 0, uint32_t* pow_out = nullptr);
+                     Ef* final_out, uint32_t pow_bits = 0, uint32_t* pow_out = nullptr,
+                     const Ef* beta_in = nullptr);
+// (beta_in != nullptr: `in` holds 2 L0 elements, the previous round's vector, and the kernel starts by
+// folding it with *beta_in)
 void launch_vec_add(Context& ctx, Ef* acc, const Ef* other, uint64_t n);
 // gathers: rows of column-major matrices and Merkle paths at given indices
 void launch_gather_rows(Context& ctx, const LeafMats& mats, const uint32_t* d_indices,

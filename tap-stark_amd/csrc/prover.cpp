@@ -571,7 +571,12 @@ void fri_commit_rounds(Context& ctx, const FriConfig& fri, DevBuf<Ef> folded, ui
         r.vec = folded.p;
         r.tree = tree.p;
         const bool add_pending = next_in < inputs.size() && (1ull << log_lens[next_in]) == h;
-        if (add_pending || !big(h)) {
+        // the tail kernel folds its own first vector (one launch less), unless an input joins it first
+        const bool tail_folds = !add_pending && !big(h) && h > fri.blowup() && next_in >= inputs.size();
+        if (tail_folds) {
+            prev = folded.p;
+            st.keep_vecs.push_back(std::move(folded));
+        } else if (add_pending || !big(h)) {
             // the next vector is needed in memory now: an input is added to it, or the tail takes it
             DevBuf<Ef> out(&ctx, h);
             launch_fri_fold_dev(ctx, folded.p, h, st.d_betas.p + ri, out.p, nullptr);  // :119 fold_matrix
@@ -597,9 +602,9 @@ void fri_commit_rounds(Context& ctx, const FriConfig& fri, DevBuf<Ef> folded, ui
         DevBuf<uint32_t> tail_trees(&ctx, 8 * 2 * (size_t)L0);
         const size_t ri = st.rounds.size();
         static const bool host_grind = [] { const char* e = getenv("TS_HOST_GRIND"); return e && atoi(e) != 0; }();
-        launch_fri_tail(ctx, folded.p, L0, fri.blowup(), dch, tail_vecs.p, tail_trees.p,
+        launch_fri_tail(ctx, prev ? prev : folded.p, L0, fri.blowup(), dch, tail_vecs.p, tail_trees.p,
                         st.d_roots.p + 8 * ri, st.d_betas.p + ri, st.d_final.p, fri.proof_of_work_bits,
-                        host_grind ? nullptr : st.d_chal.p + FRI_POW_WORD);
+                        host_grind ? nullptr : st.d_chal.p + FRI_POW_WORD, prev ? st.d_betas.p + ri - 1 : nullptr);
         uint32_t L = L0;
         size_t voff = 0, toff = 0;
         while (L > fri.blowup()) {

@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 
 import tapstark_amd as ts
-from tapstark_amd.airs import FibonacciAir, splitmix64_stream
+from tapstark_amd.airs import FibonacciAir, SynthMulAir, generate_synth_mul_trace, splitmix64_stream
 
 
 def probe():
@@ -35,6 +35,13 @@ def probe():
     proof = ts.prove(config, cair, ts.BfChallenger(), ts.DeviceMatrix.fibonacci(ctx, 0, 1, n), pis)
     ts.verify(config, cair, ts.BfChallenger(), proof, pis)
     out["proof"] = hashlib.sha256(proof.words.tobytes()).hexdigest()
+    # a degree-3 AIR: two quotient chunks, whose LDEs share one set of launches (TS_LDE_PAIR)
+    air = SynthMulAir(3)
+    cair = ts.CompiledAir(ctx, ts.air_tape(air, 0))
+    trace = generate_synth_mul_trace(1 << 13, 3)
+    proof = ts.prove(config, cair, ts.BfChallenger(), trace, np.zeros(0, dtype=np.uint32))
+    ts.verify(config, cair, ts.BfChallenger(), proof, np.zeros(0, dtype=np.uint32))
+    out["proof_mul3"] = hashlib.sha256(proof.words.tobytes()).hexdigest()
     return out
 
 

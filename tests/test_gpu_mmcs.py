@@ -138,6 +138,7 @@ def test_alu_ceiling_probe(ctx):
     {"TS_LEAF_TREE_R": "0"}, {"TS_LEAF_TREE_R": "1"}, {"TS_LEAF_TREE_R": "3"},
     {"TS_LEAF_TREE_FINISH": "0", "TS_FRI_ROUND_LOG": "0"},
     {"TS_HOST_GRIND": "1"},  # the proof-of-work search on the host instead of in the last FRI kernel
+    {"TS_LDE_PAIR": "0"},    # a set of LDE launches per quotient chunk instead of one for both
 ], ids=lambda k: ",".join(f"{a[3:]}={b}" for a, b in k.items()))
 def test_tree_launch_shapes_agree(ctx, knobs):
     # how a Merkle commitment is cut into launches (leaves and tree in one launch or apart, leaves per

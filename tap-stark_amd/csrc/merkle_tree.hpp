@@ -122,8 +122,8 @@ struct Tree {
     // finisher that runs alone.  publish_one: the level's single node is written through for another
     // workgroup to read.
     // (Run-time image pointers: one copy of the code, one add per message word.  This is the level of the
-    // leaf-tree kernel -- bound by throughput and by its 128-VGPR budget -- and of the chunked blocks; the
-    // chains of the whole-tree kernels take level_fixed below.)
+    // wide levels, of the chunked blocks and of the leaf-tree kernel's finisher; the chains of the
+    // whole-tree kernels and the narrow levels of a leaf-tree block take level_fixed below.)
     __device__ static __forceinline__ void level_step(const Quad& q, const uint32_t* src, uint32_t* dst, uint32_t n_par,
                                                       uint32_t* out, bool publish_one, bool wide) {
         if (wide) {
@@ -178,7 +178,7 @@ struct Tree {
     // block 8.5 -> 7.3 us (tools/tail_stamps.py).  (A first attempt -- three image pairs in / ping / pong,
     // the single pass peeled inside the pass loop -- measured 8.8: the compiler folded the peeled pass
     // back into the loop, address adds and all, and there were three copies of the code.)
-    template <int PAR>
+    template <int PAR, bool SINGLE_PASS_ONLY = false>
     __device__ static __forceinline__ void level_fixed(Lds& lds, const Quad& q, uint32_t n_par, uint32_t* out,
                                                        bool publish_one) {
         const uint32_t j = threadIdx.x & 3;
@@ -196,7 +196,7 @@ struct Tree {
                 o[4 + j] = hi;
             }
         };
-        if (4 * n_par <= NTH) {
+        if (SINGLE_PASS_ONLY || 4 * n_par <= NTH) {
             if (threadIdx.x < 4 * n_par) {
                 uint32_t m[28], lo, hi;
 #pragma unroll
@@ -490,7 +490,28 @@ __device__ __forceinline__ void leaf_tree_body(T8::Lds& lds, uint32_t& s_last, L
     T8::quad_setup(q);
     const unsigned log_b = 8 + LOG_R;
     const uint32_t n_sub = 1u << (log_leaves - log_b);
-    const uint32_t* top = T8::reduce_levels(lds, lds.in, 256, 1, lv, LOG_R, base >> LOG_R, q, finish && n_sub > 1, 64);
+    // the block's eight levels between the images `in` and `ab` in turn: 128 and 64 parents one compression
+    // per lane, then 32 .. 1 four lanes per compression as straight-line levels (level_fixed: while a
+    // workgroup is in these narrow levels most of its waves wait at barriers, so their length is what the
+    // launch's issue fill pays: 0.68 for the 16-column chunk tree against 0.95 for the 64-column trace tree)
+    const bool pub = finish && n_sub > 1;
+    uint64_t node = base >> LOG_R;
+    unsigned level = LOG_R;
+    auto out = [&]() {
+        level++;
+        node >>= 1;
+        return lv.at(level, node);
+    };
+    T8::level_step(q, lds.in, lds.ab, 128, out(), false, true);
+    T8::level_step(q, lds.ab, lds.in, 64, out(), false, true);
+    for (uint32_t n_par = 32;;) {
+        T8::template level_fixed<0, true>(lds, q, n_par, out(), false);
+        n_par >>= 1;
+        T8::template level_fixed<1, true>(lds, q, n_par, out(), pub && n_par == 1);
+        n_par >>= 1;
+        if (n_par == 0) break;
+    }
+    const uint32_t* top = lds.in;
     if (finish) T8::finish_tree(lds, s_last, top, lv, log_b, n_sub, q, ticket, ch, root_out, beta_out);
 }
 

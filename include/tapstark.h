@@ -79,6 +79,9 @@ ts_status ts_ctx_graph_stats(ts_ctx* ctx, uint64_t out[4]);
  * pool could not reserve for (the phase ran eagerly); 5 = ts_prove_sharded calls whose local quotient
  * (ts_shard_options.local_quotient) was redone through the broadcast path because FRI's final
  * polynomial was not constant, i.e. the trace was invalid (fri/src/prover.rs:129-134).
+ * 6 / 7 / 8 = proof-of-work witnesses (fri/src/prover.rs:43) taken from the device search after the
+ * host's one-step check_witness / device candidates the host refused (never expected) / searches the
+ * host ran itself (no device candidate below 2^12, or TS_HOST_GRIND=1).
  * TS_ERR_INVALID for an unknown index. */
 ts_status ts_ctx_stat(ts_ctx* ctx, int which, uint64_t* out);
 
@@ -122,9 +125,34 @@ ts_status ts_air_compile(ts_ctx* ctx, const uint32_t* tape, size_t n_words, ts_a
 ts_status ts_air_info(const ts_air* air, uint32_t* width, uint32_t* n_public,
                       uint32_t* max_constraint_degree, uint32_t* log_quotient_degree);
 /* 1 if the quotient kernel was specialised for this AIR with hiprtc, 0 if the generic on-device
- * interpreter is used (hiprtc missing, or TS_NO_JIT set in the environment) */
+ * interpreter is used (hiprtc missing, TS_NO_JIT set in the environment, the program is above the
+ * compile budget, or a background compilation has not finished yet).
+ * Compile budget (hiprtc's time grows faster than the program): up to TS_JIT_SYNC_INSTR (default 2048)
+ * lowered instructions the kernel is compiled inside ts_air_compile; up to TS_JIT_MAX_INSTR (default
+ * 32768) on a background thread while proofs already run on the interpreter -- the first use after
+ * it finishes switches over, the proof words are the same either way; larger programs stay on the
+ * interpreter, which has no limit on program size or live values. */
 int ts_air_is_jit(const ts_air* air);
+/* joins a background compilation; state: 0 none, 3 specialised kernel loaded, 4 compilation failed */
+ts_status ts_air_jit_wait(ts_ctx* ctx, ts_air* air, int* state, double* compile_seconds);
 void ts_air_free(ts_ctx* ctx, ts_air* air);
+/* Inspection of what the tape was lowered to (none of these needs a GPU; `air` may be host-only).
+ * The reference's counterpart is the monomorphised `Air::eval` inside quotient_values
+ * (uni-stark/src/prover.rs:170-181): user code compiled into the prover.  Here the tape is lowered
+ * to a register program (csrc/air.cpp) that the on-device interpreter runs, and that program to
+ * straight-line HIP source compiled with hiprtc (csrc/jit.cpp); tests interpret the former and
+ * compile the latter against the oracle's direct evaluation of the tape.
+ * ts_air_program: out = [n_regs, n_instr, n_consts, n_instr x {op,dst,a,b}, n_consts x canonical
+ *   value, n_consts x (public-value index or 0xffffffff)]; ops: 0 LOAD(a=row offset,b=column)
+ *   1 CONST(a=const index) 2 SEL(a=0 first|1 last|2 transition) 3 ADD 4 SUB 5 NEG 6 MUL
+ *   7 ASSERT(a=register, b=constraint index).  TS_ERR_BUFFER (with *n_words set) if cap is short.
+ * ts_air_jit_source: the HIP source (not NUL-terminated; *n_bytes set even on TS_ERR_BUFFER).
+ * ts_air_jit_compile: that source through hiprtc for `arch` ("gfx950"); the code object and the
+ *   compile time.  TS_ERR_UNSUPPORTED if hiprtc is missing or the compilation fails. */
+ts_status ts_air_program(const ts_air* air, uint32_t* out, size_t cap_words, size_t* n_words);
+ts_status ts_air_jit_source(const ts_air* air, char* buf, size_t cap, size_t* n_bytes);
+ts_status ts_air_jit_compile(const ts_air* air, const char* arch, void* code_out, size_t cap,
+                             size_t* n_bytes, double* seconds);
 
 /* ------------------------------------------------------------------ PCS */
 /* Pcs::commit, fri/src/two_adic_pcs.rs:227-245: for each (domain, evals): coset LDE with shift

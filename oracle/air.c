@@ -137,6 +137,26 @@ void ts_or_tape_eval_ext(const ts_or_tape* t, const ef4* local, const ef4* next,
     }
 }
 
+/* The value of every constraint on `m` independent (local, next, selectors) inputs, by direct
+ * evaluation of the DAG: what folder.rs:60-64 `assert_zero` receives, before any folding with alpha.
+ * sels = m x {is_first, is_last, is_transition}; out = m x n_constraints.  Used to check the
+ * product's lowered register program (tests interpret it) constraint by constraint. */
+int ts_or_tape_constraint_values(const uint32_t* tape, size_t n_words, const uint32_t* local,
+                                 const uint32_t* next, size_t m, const uint32_t* pis,
+                                 const uint32_t* sels, uint32_t* out) {
+    ts_or_tape t;
+    if (ts_or_tape_parse(tape, n_words, &t)) return -1;
+    uint32_t* v = (uint32_t*)malloc((t.n_nodes + 1) * sizeof(uint32_t));
+    for (size_t i = 0; i < m; i++) {
+        ts_or_tape_eval_base(&t, local + i * t.width, next + i * t.width, pis, sels[3 * i],
+                             sels[3 * i + 1], sels[3 * i + 2], v);
+        for (uint32_t c = 0; c < t.n_constraints; c++)
+            out[i * t.n_constraints + c] = v[t.constraints[c]];
+    }
+    free(v);
+    return 0;
+}
+
 /* check_constraints.rs:18-38: is_first = (i==0), is_last = (i==h-1), is_transition = (i!=h-1),
  * next row wraps around */
 int64_t ts_or_check_constraints(const uint32_t* tape, size_t n_words, const uint32_t* trace,

@@ -109,6 +109,9 @@ int ts_or_tape_validate(const uint32_t* tape, size_t n_words);
 int ts_or_air_max_constraint_degree(const uint32_t* tape, size_t n_words);
 int ts_or_air_log_quotient_degree(const uint32_t* tape, size_t n_words);
 /* uni-stark/src/check_constraints.rs:11-39; returns -1 if all hold, else row*2^16+constraint */
+int ts_or_tape_constraint_values(const uint32_t* tape, size_t n_words, const uint32_t* local,
+                                 const uint32_t* next, size_t m, const uint32_t* pis,
+                                 const uint32_t* sels, uint32_t* out);
 int64_t ts_or_check_constraints(const uint32_t* tape, size_t n_words, const uint32_t* trace,
                                 size_t n, const uint32_t* pis);
 

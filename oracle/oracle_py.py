@@ -216,6 +216,20 @@ def log_quotient_degree(tape) -> int:
     return int(lib().ts_or_air_log_quotient_degree(_p(tape), C.c_size_t(len(tape))))
 
 
+def constraint_values(tape, local, nxt, pis, sels) -> np.ndarray:
+    """(m, n_constraints): every constraint of the tape on m (local row, next row, selector triple)
+    inputs, by direct evaluation of the DAG."""
+    tape, local, nxt, pis, sels = _u32(tape), _u32(local), _u32(nxt), _u32(pis), _u32(sels)
+    if len(pis) == 0:
+        pis = np.zeros(1, dtype=np.uint32)
+    m, k = local.shape[0], int(tape[5])
+    out = np.zeros((m, k), dtype=np.uint32)
+    rc = lib().ts_or_tape_constraint_values(_p(tape), C.c_size_t(len(tape)), _p(local), _p(nxt), C.c_size_t(m),
+                                            _p(pis), _p(sels), _p(out))
+    assert rc == 0, "malformed tape"
+    return out
+
+
 def check_constraints(tape, trace, pis) -> int:
     tape, trace, pis = _u32(tape), _u32(trace), _u32(pis)
     if len(pis) == 0:

@@ -21,7 +21,7 @@ ABI_SYMBOLS = [
     "ts_ctx_stream", "ts_ctx_set_timing", "ts_ctx_take_timings", "ts_ctx_set_kernel_timing",
     "ts_ctx_take_kernel_timings", "ts_ctx_graph_stats", "ts_ctx_stat", "ts_matrix_upload",
     "ts_matrix_from_device", "ts_trace_fibonacci", "ts_trace_synth_mul", "ts_trace_synth_ext", "ts_matrix_dims", "ts_matrix_download", "ts_matrix_free",
-    "ts_air_compile", "ts_air_info", "ts_air_is_jit", "ts_air_free", "ts_pcs_commit", "ts_mmcs_commit", "ts_pcs_data_lde",
+    "ts_air_compile", "ts_air_info", "ts_air_is_jit", "ts_air_jit_wait", "ts_air_free", "ts_air_program", "ts_air_jit_source", "ts_air_jit_compile", "ts_pcs_commit", "ts_mmcs_commit", "ts_pcs_data_lde",
     "ts_pcs_data_info", "ts_pcs_data_matrix_info", "ts_pcs_data_digests", "ts_pcs_open_batch", "ts_pcs_data_free",
     "ts_quotient_chunks", "ts_pcs_open_reduce", "ts_pcs_open", "ts_pcs_verify", "ts_fri_prove", "ts_fri_verify", "ts_fri_fold", "ts_fri_fold_device", "ts_chal_new", "ts_chal_clone",
     "ts_chal_free", "ts_chal_observe", "ts_chal_observe_commitment", "ts_chal_sample",
@@ -138,6 +138,11 @@ def lib() -> C.CDLL:
         l.ts_air_compile.argtypes = [C.c_void_p, u32p, C.c_size_t, voidpp]
         l.ts_air_info.argtypes = [C.c_void_p, u32p, u32p, u32p, u32p]
         l.ts_air_is_jit.argtypes = [C.c_void_p]
+        l.ts_air_jit_wait.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)]
+        l.ts_air_program.argtypes = [C.c_void_p, u32p, C.c_size_t, C.POINTER(C.c_size_t)]
+        l.ts_air_jit_source.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        l.ts_air_jit_compile.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
+                                         C.POINTER(C.c_double)]
         l.ts_pcs_commit.argtypes = [C.c_void_p, C.POINTER(FriConfigC), C.c_uint32, voidpp, u32p,
                                     u32p, voidpp]
         l.ts_mmcs_commit.argtypes = [C.c_void_p, C.c_uint32, voidpp, u32p, voidpp]

@@ -4,6 +4,9 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <thread>
 #include <memory>
 #include <string>
 #include <vector>
@@ -11,12 +14,54 @@
 #include "abi_types.hpp"
 #include "jit.hpp"
 
+// hiprtc's time grows faster than the program (a 4.6k-instruction program compiles in 14 s, an
+// 18.8k one in 146 s: profiles/r06_air_jit_compile.txt), so the specialisation has a budget:
+//   <= TS_JIT_SYNC_INSTR (default 2048, ~3 s)   compiled inside ts_air_compile, as before;
+//   <= TS_JIT_MAX_INSTR  (default 32768)        compiled on a background thread: proofs run on the
+//                                               interpreter (a GPU path too) until the code object is
+//                                               ready, the next use loads it; ts_air_jit_wait joins;
+//   larger                                      interpreter only.
+// Both kernels compute the same words, so which one ran never shows in a proof.
 struct ts_air {
     ts::AirProgram prog;
     ts::DevBuf<uint32_t> code;
     std::string jit_log;
     int device = -1;  // the device the jit module was loaded on (-1: host-only AIR)
+    enum { JIT_NONE = 0, JIT_COMPILING = 1, JIT_CODE_READY = 2, JIT_LOADED = 3, JIT_FAILED = 4 };
+    std::atomic<int> jit_state{JIT_NONE};
+    std::thread jit_thread;
+    std::vector<char> jit_code;
+    double jit_seconds = 0;
+    std::string arch;
+    void start_background_jit() {
+        jit_state = JIT_COMPILING;
+        jit_thread = std::thread([this] {
+            const auto t0 = std::chrono::steady_clock::now();
+            std::string log;
+            const bool ok = ts::jit_compile_code(prog, arch.c_str(), jit_code, log);
+            jit_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (!ok) jit_log = log;
+            jit_state = ok ? JIT_CODE_READY : JIT_FAILED;
+        });
+    }
+    // called on the thread that drives the context (device current): adopt a finished compilation
+    void poll_jit(bool wait) {
+        if (wait && jit_thread.joinable()) jit_thread.join();
+        if (jit_state.load() != JIT_CODE_READY) return;
+        if (jit_thread.joinable()) jit_thread.join();
+        ts::JitKernel jk;
+        if (ts::jit_load_code(jit_code, jk, jit_log)) {
+            prog.jit_module = jk.module;
+            prog.jit_fn = jk.fn;
+            jit_state = JIT_LOADED;
+        } else {
+            jit_state = JIT_FAILED;
+        }
+        jit_code.clear();
+        jit_code.shrink_to_fit();
+    }
     ~ts_air() {
+        if (jit_thread.joinable()) jit_thread.join();
         if (device >= 0 && prog.jit_module) (void)hipSetDevice(device);
         ts::JitKernel jk;
         jk.module = prog.jit_module;
@@ -24,6 +69,11 @@ struct ts_air {
         ts::jit_release(jk);
     }
 };
+// the program as the prover sees it, with a background specialisation adopted if it has finished
+static const ts::AirProgram& ready_prog(const ts_air* air) {
+    const_cast<ts_air*>(air)->poll_jit(false);
+    return air->prog;
+}
 struct ts_challenger {
     ts::BfChallenger c;
     ts_challenger(int perm, bool ext) : c(perm, ext) {}
@@ -230,6 +280,9 @@ ts_status ts_ctx_stat(ts_ctx* ctx, int which, uint64_t* out) {
     case 3: *out = ctx->ctx.bytes_reserved; break;
     case 4: *out = ctx->ctx.fri_graph_reserve_failures; break;
     case 5: *out = ctx->ctx.local_quotient_fallbacks; break;
+    case 6: *out = ctx->ctx.pow_hints_accepted; break;
+    case 7: *out = ctx->ctx.pow_hints_rejected; break;
+    case 8: *out = ctx->ctx.pow_host_grinds; break;
     default: return TS_ERR_INVALID;
     }
     return TS_OK;
@@ -428,23 +481,50 @@ ts_status ts_air_compile(ts_ctx* ctx, const uint32_t* tape, size_t n_words, ts_a
                                   hipMemcpyHostToDevice, ctx->ctx.stream));
         ctx->ctx.sync();
         a->prog.d_code = a->code.p;
-        // specialise the quotient kernel for this AIR (falls back to the interpreter on failure)
-        hipDeviceProp_t prop;
-        TS_HIP(hipGetDeviceProperties(&prop, ctx->ctx.device));
-        std::string arch = prop.gcnArchName;
-        arch = arch.substr(0, arch.find(':'));
-        ts::JitKernel jk;
-        std::string log;
-        if (ts::jit_compile_quotient(a->prog, arch.c_str(), jk, log)) {
-            a->prog.jit_module = jk.module;
-            a->prog.jit_fn = jk.fn;
+        // specialise the quotient kernel for this AIR (the interpreter runs it otherwise)
+        a->arch = ctx->ctx.arch_name;
+        const size_t n_instr = a->prog.code.size() / 4;
+        auto env_or = [](const char* name, size_t dflt) {
+            const char* v = getenv(name);
+            return v && *v ? (size_t)strtoull(v, nullptr, 10) : dflt;
+        };
+        if (getenv("TS_NO_JIT")) {
+            a->jit_log = "disabled by TS_NO_JIT";
+        } else if (n_instr <= env_or("TS_JIT_SYNC_INSTR", 2048)) {
+            ts::JitKernel jk;
+            const auto t0 = std::chrono::steady_clock::now();
+            if (ts::jit_compile_quotient(a->prog, a->arch.c_str(), jk, a->jit_log)) {
+                a->prog.jit_module = jk.module;
+                a->prog.jit_fn = jk.fn;
+                a->jit_state = ts_air::JIT_LOADED;
+            } else {
+                a->jit_state = ts_air::JIT_FAILED;
+            }
+            a->jit_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        } else if (n_instr <= env_or("TS_JIT_MAX_INSTR", 32768)) {
+            a->start_background_jit();
         } else {
-            a->jit_log = log;
+            a->jit_log = "program above TS_JIT_MAX_INSTR: interpreter only";
         }
         *out = a.release();
     });
 }
-int ts_air_is_jit(const ts_air* air) { return air && air->prog.jit_fn ? 1 : 0; }
+int ts_air_is_jit(const ts_air* air) {
+    if (!air) return 0;
+    if (air->device >= 0 && air->jit_state.load() == ts_air::JIT_CODE_READY) {
+        (void)hipSetDevice(air->device);
+        const_cast<ts_air*>(air)->poll_jit(false);
+    }
+    return air->prog.jit_fn ? 1 : 0;
+}
+ts_status ts_air_jit_wait(ts_ctx* ctx, ts_air* air, int* state, double* compile_seconds) {
+    if (!ctx || !air) return TS_ERR_INVALID;
+    return guard(ctx, [&] {
+        air->poll_jit(true);
+        if (state) *state = air->jit_state.load();
+        if (compile_seconds) *compile_seconds = air->jit_seconds;
+    });
+}
 ts_status ts_air_info(const ts_air* air, uint32_t* width, uint32_t* n_public,
                       uint32_t* max_constraint_degree, uint32_t* log_quotient_degree) {
     if (!air) return TS_ERR_INVALID;
@@ -457,6 +537,44 @@ ts_status ts_air_info(const ts_air* air, uint32_t* width, uint32_t* n_public,
 void ts_air_free(ts_ctx* ctx, ts_air* air) {
     (void)ctx;
     delete air;
+}
+ts_status ts_air_program(const ts_air* air, uint32_t* out, size_t cap_words, size_t* n_words) {
+    if (!air || !n_words) return TS_ERR_INVALID;
+    const ts::AirProgram& p = air->prog;
+    const size_t nc = p.const_canonical.size();
+    *n_words = 3 + p.code.size() + 2 * nc;
+    if (!out || cap_words < *n_words) return TS_ERR_BUFFER;
+    out[0] = p.n_regs;
+    out[1] = (uint32_t)(p.code.size() / 4);
+    out[2] = (uint32_t)nc;
+    std::copy(p.code.begin(), p.code.end(), out + 3);
+    std::copy(p.const_canonical.begin(), p.const_canonical.end(), out + 3 + p.code.size());
+    std::copy(p.const_public_idx.begin(), p.const_public_idx.end(), out + 3 + p.code.size() + nc);
+    return TS_OK;
+}
+ts_status ts_air_jit_source(const ts_air* air, char* buf, size_t cap, size_t* n_bytes) {
+    if (!air || !n_bytes) return TS_ERR_INVALID;
+    return guard(nullptr, [&] {
+        const std::string src = ts::jit_quotient_source(air->prog);
+        *n_bytes = src.size();
+        TS_REQUIRE(buf && cap >= src.size(), ts::TS_ERR_BUFFER, "jit source buffer too small");
+        memcpy(buf, src.data(), src.size());
+    });
+}
+ts_status ts_air_jit_compile(const ts_air* air, const char* arch, void* code_out, size_t cap, size_t* n_bytes,
+                             double* seconds) {
+    if (!air || !arch || !n_bytes) return TS_ERR_INVALID;
+    return guard(nullptr, [&] {
+        std::vector<char> code;
+        std::string log;
+        const auto t0 = std::chrono::steady_clock::now();
+        const bool ok = ts::jit_compile_code(air->prog, arch, code, log);
+        if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        TS_REQUIRE(ok, ts::TS_ERR_UNSUPPORTED, ("hiprtc: " + log).c_str());
+        *n_bytes = code.size();
+        TS_REQUIRE(code_out && cap >= code.size(), ts::TS_ERR_BUFFER, "code object buffer too small");
+        memcpy(code_out, code.data(), code.size());
+    });
 }
 
 // ------------------------------------------------------------------ PCS
@@ -577,7 +695,7 @@ ts_status ts_quotient_chunks(ts_ctx* ctx, const ts_pcs_data* trace_data, uint32_
             TS_REQUIRE(public_values, ts::TS_ERR_INVALID, "null public values");
             pis.assign(public_values, public_values + n_public);
         }
-        auto chunks = pcs.quotient_chunks(*trace_data->d, air->prog, pis, load_ef(alpha));
+        auto chunks = pcs.quotient_chunks(*trace_data->d, ready_prog(air), pis, load_ef(alpha));
         for (size_t c = 0; c < chunks.size(); c++) {
             auto m = std::make_unique<ts_matrix>();
             m->m = std::move(chunks[c]);
@@ -760,7 +878,7 @@ ts_status ts_prove(ts_ctx* ctx, const ts_fri_config* cfg, const ts_air* air, ts_
             pis.assign(public_values, public_values + n_public);
         }
         ts::StageTimer t(&ctx->ctx, "prove");
-        std::vector<uint32_t> proof = ts::prove(pcs, air->prog, chal->c, std::move(trace->m), pis);
+        std::vector<uint32_t> proof = ts::prove(pcs, ready_prog(air), chal->c, std::move(trace->m), pis);
         *n_words_out = proof.size();
         TS_REQUIRE(proof.size() <= cap_words, ts::TS_ERR_BUFFER, "proof buffer too small");
         memcpy(proof_out, proof.data(), proof.size() * 4);
@@ -811,7 +929,7 @@ ts_status ts_prove_sharded(ts_ctx* ctx, const ts_fri_config* cfg, const ts_comm*
         ts::StageTimer t(&ctx->ctx, "prove");
         std::vector<uint32_t> proof;
         try {
-            proof = ts::prove_sharded(pcs, c, air->prog, chal->c, std::move(trace_rows->m), pis, opt);
+            proof = ts::prove_sharded(pcs, c, ready_prog(air), chal->c, std::move(trace_rows->m), pis, opt);
         } catch (...) {
             // this rank is leaving the protocol: make the peers' pending collectives fail, not hang
             if (cb.abort) cb.abort(cb.user);
@@ -844,7 +962,7 @@ ts_status ts_prove_tap(ts_ctx* ctx, const ts_fri_config* cfg, const ts_air* air,
         locks.offsets = lock_offsets;
         locks.n_scripts = n_scripts;
         ts::StageTimer t(&ctx->ctx, "prove");
-        std::vector<uint32_t> proof = ts::prove_tap(pcs, air->prog, chal->c, std::move(trace->m), pis, locks);
+        std::vector<uint32_t> proof = ts::prove_tap(pcs, ready_prog(air), chal->c, std::move(trace->m), pis, locks);
         *n_words_out = proof.size();
         TS_REQUIRE(proof.size() <= cap_words, ts::TS_ERR_BUFFER, "proof buffer too small");
         memcpy(proof_out, proof.data(), proof.size() * 4);
@@ -876,7 +994,7 @@ ts_status ts_prove_tap_sharded(ts_ctx* ctx, const ts_fri_config* cfg, const ts_c
         ts::StageTimer t(&ctx->ctx, "prove");
         std::vector<uint32_t> proof;
         try {
-            proof = ts::prove_tap(pcs, air->prog, chal->c, std::move(trace->m), pis, locks, &c);
+            proof = ts::prove_tap(pcs, ready_prog(air), chal->c, std::move(trace->m), pis, locks, &c);
         } catch (...) {
             if (cb.abort) cb.abort(cb.user);  // the peers' pending collectives fail instead of waiting
             throw;

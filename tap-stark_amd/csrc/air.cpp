@@ -1,6 +1,7 @@
 #include "air.hpp"
 
 #include <algorithm>
+#include <map>
 #include <string>
 
 #include "bb.hpp"
@@ -115,13 +116,14 @@ AirProgram compile_air(const uint32_t* tape, size_t n_words) {
         p.code.push_back(a);
         p.code.push_back(b);
     };
+    std::map<std::pair<uint32_t, uint32_t>, uint32_t> const_slot;  // (public index | ~0u, value) -> slot
     auto add_const = [&](uint32_t canonical, uint32_t public_idx) -> uint32_t {
-        for (size_t k = 0; k < p.const_canonical.size(); k++)
-            if (p.const_public_idx[k] == public_idx && (public_idx != ~0u || p.const_canonical[k] == canonical))
-                return (uint32_t)k;
-        p.const_canonical.push_back(canonical);
-        p.const_public_idx.push_back(public_idx);
-        return (uint32_t)(p.const_canonical.size() - 1);
+        auto [it, fresh] = const_slot.try_emplace({public_idx, canonical}, (uint32_t)p.const_canonical.size());
+        if (fresh) {
+            p.const_canonical.push_back(canonical);
+            p.const_public_idx.push_back(public_idx);
+        }
+        return it->second;
     };
     auto release = [&](uint32_t node) {
         if (--uses[node] == 0) {

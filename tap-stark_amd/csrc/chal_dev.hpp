@@ -76,6 +76,14 @@ __device__ inline Ef dc_observe_root_and_sample(DevChallenger* c, const uint32_t
     return r;
 }
 
+// Orders one wave's LDS stores before its later LDS loads by other lanes (lock-step lanes of one wave
+// need no s_barrier; the fences keep the compiler from moving the accesses across).
+__device__ __forceinline__ void dc_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // The same step on FOUR lanes, for the kernels whose last workgroup holds the root in an LDS digest
 // image (word w of node n at img[w * STRIDE + n]; node 0 = the root).  With an empty input buffer and
 // Blake3's permutation, observing the 8 words of a root fills the buffer exactly: the 8th observe
@@ -106,6 +114,7 @@ __device__ __forceinline__ void dc_round_quad(DevChallenger* lc, uint32_t* img, 
             if (beta_lds != nullptr) *beta_lds = beta;
             if (beta_out != nullptr) *reinterpret_cast<uint4*>(beta_out) = make_uint4(beta.c[0], beta.c[1], beta.c[2], beta.c[3]);
         }
+        dc_wave_sync();
         return;
     }
     if (tid < 8) {
@@ -115,6 +124,10 @@ __device__ __forceinline__ void dc_round_quad(DevChallenger* lc, uint32_t* img, 
         img[tid * STRIDE + 1] = lc->state[8 + tid];  // the capacity half: node 1
         lc->state[tid] = 0;
     }
+    // lanes 0..3 read what lanes 0..7 just stored: same wave, so no s_barrier, but the LDS stores must
+    // be ordered before the loads for the compiler too (wave-scope release/acquire: no instruction
+    // beyond the lgkmcnt wait the loads need anyway)
+    dc_wave_sync();
     if (tid < 4) {
         uint32_t m[28];
 #pragma unroll
@@ -134,6 +147,7 @@ __device__ __forceinline__ void dc_round_quad(DevChallenger* lc, uint32_t* img, 
         if (beta_lds != nullptr) beta_lds->c[i] = c;
         if (beta_out != nullptr) beta_out->c[i] = c;
     }
+    dc_wave_sync();  // the caller's lanes read lc->state / out_buf next (copy-out of the challenger)
 }
 #endif
 

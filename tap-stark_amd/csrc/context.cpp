@@ -19,6 +19,9 @@ Context::Context(int dev) : device(dev) {
     hipDeviceProp_t prop;
     TS_HIP(hipGetDeviceProperties(&prop, dev));
     num_cus = prop.multiProcessorCount;
+    max_lds_per_block = prop.sharedMemPerBlock;  // gfx950: 160 KiB
+    arch_name = prop.gcnArchName;
+    arch_name = arch_name.substr(0, arch_name.find(':'));
     TS_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
 }
 
@@ -36,6 +39,7 @@ Context::~Context() {
     for (auto& kv : live_blocks) (void)hipFree(kv.first);
     if (h_pinned) (void)hipHostFree(h_pinned);
     if (h_mailbox) (void)hipHostFree(h_mailbox);
+    if (h_mailbox_big) (void)hipHostFree(h_mailbox_big);
     if (h_arena) (void)hipHostFree(h_arena);
     if (stream) (void)hipStreamDestroy(stream);
 }
@@ -181,7 +185,19 @@ const void* Context::stage(const void* src, size_t bytes) {
 
 uint32_t* Context::mailbox(size_t words) {
     constexpr size_t WORDS = 16384;  // 64 KiB
-    TS_REQUIRE(words <= WORDS / 4, TS_ERR_INVALID, "mailbox: message too large");
+    if (words > WORDS / 4) {
+        // a message of its own size class (the opened values of a trace wider than ~500 columns): one
+        // page-locked buffer grown on demand; its previous reader has synced, and growing it syncs again
+        if (words > h_mailbox_big_words) {
+            sync();
+            if (h_mailbox_big) (void)hipHostFree(h_mailbox_big);
+            h_mailbox_big = nullptr;
+            h_mailbox_big_words = 0;
+            TS_HIP(hipHostMalloc((void**)&h_mailbox_big, words * 4, hipHostMallocDefault));
+            h_mailbox_big_words = words;
+        }
+        return h_mailbox_big;
+    }
     if (!h_mailbox) TS_HIP(hipHostMalloc((void**)&h_mailbox, WORDS * 4, hipHostMallocDefault));
     const size_t need = (words + 15) & ~(size_t)15;
     if (mailbox_off + need > WORDS) mailbox_off = 0;  // every earlier slot has been read: its reader synced

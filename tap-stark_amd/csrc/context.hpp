@@ -53,6 +53,8 @@ struct Context {
     hipStream_t stream = nullptr;
     std::string last_error;
     int num_cus = 256;
+    size_t max_lds_per_block = 64 * 1024;
+    std::string arch_name;  // "gfx950"
 
     // caching allocator: blocks are rounded up and recycled by exact rounded size
     std::multimap<size_t, void*> free_blocks;
@@ -106,6 +108,8 @@ struct Context {
     // sync that read it.
     uint32_t* h_mailbox = nullptr;
     size_t mailbox_off = 0;
+    uint32_t* h_mailbox_big = nullptr;  // messages above a quarter of the page: one at a time
+    size_t h_mailbox_big_words = 0;
     uint32_t* mailbox(size_t words);
 
     // pinned host staging
@@ -150,6 +154,9 @@ struct Context {
     std::map<std::vector<uint32_t>, std::vector<size_t>> fri_graph_sizes;  // shape key -> block sizes
     uint64_t fri_graph_replays = 0, fri_graph_fallbacks = 0;
     uint64_t fri_graph_reserve_failures = 0;  // Context::reserve refused: the phase ran eagerly
+    // fri_pow_witness (prover.cpp): witnesses taken from the device search after the host's one-step check,
+    // device candidates the host refused (never expected), and searches run on the host
+    uint64_t pow_hints_accepted = 0, pow_hints_rejected = 0, pow_host_grinds = 0;
     uint64_t local_quotient_fallbacks = 0;    // prove_sharded: local quotient -> broadcast path (invalid trace)
     bool reserve(const std::vector<size_t>& sizes);
     // ends the deferral: blocks in `revive` stay live (returned: which of them had been parked),

@@ -45,7 +45,7 @@ void fri_commit_rounds(Context& ctx, const FriConfig& fri, DevBuf<Ef> folded, ui
 Ef fri_commit_finish(Context& ctx, const FriConfig& fri, BfChallenger& challenger, FriCommit& st);
 // prover.rs:43 challenger.grind(bits): takes the device's hint if one step of the host transcript
 // confirms it, grinds on the host otherwise
-uint32_t fri_pow_witness(BfChallenger& challenger, unsigned bits, const FriCommit& st);
+uint32_t fri_pow_witness(Context& ctx, BfChallenger& challenger, unsigned bits, const FriCommit& st);
 
 // small host helpers
 void h2d(Context& ctx, void* dst, const void* src, size_t bytes);

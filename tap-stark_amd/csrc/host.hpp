@@ -79,6 +79,7 @@ struct PcsData {
     unsigned log_height = 0;
     DevBuf<uint32_t> tree;  // merkle_total_digests(log_height) x 8 words
     DevBuf<const uint32_t*> col_table;  // one base pointer per column of the concatenated row
+    bool col_table_uploaded = false;    // mmcs_commit uploads it only for the table-addressed leaf kernels
     uint32_t root[8] = {0};
     LeafMats leaf_mats() const;
 };

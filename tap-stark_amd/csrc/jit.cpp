@@ -143,11 +143,7 @@ std::string jit_quotient_source(const AirProgram& air) {
     return s.str();
 }
 
-bool jit_compile_quotient(const AirProgram& air, const char* arch, JitKernel& out, std::string& log) {
-    if (getenv("TS_NO_JIT")) {
-        log = "disabled by TS_NO_JIT";
-        return false;
-    }
+bool jit_compile_code(const AirProgram& air, const char* arch, std::vector<char>& code, std::string& log) {
     Rtc& r = rtc();
     if (!r.ok) {
         log = "libhiprtc not available";
@@ -179,9 +175,23 @@ bool jit_compile_quotient(const AirProgram& air, const char* arch, JitKernel& ou
         return false;
     }
     r.code_size(prog, &sz);
-    std::vector<char> code(sz);
+    code.resize(sz);
     r.get_code(prog, code.data());
     r.destroy(&prog);
+    return true;
+}
+
+bool jit_compile_quotient(const AirProgram& air, const char* arch, JitKernel& out, std::string& log) {
+    if (getenv("TS_NO_JIT")) {
+        log = "disabled by TS_NO_JIT";
+        return false;
+    }
+    std::vector<char> code;
+    if (!jit_compile_code(air, arch, code, log)) return false;
+    return jit_load_code(code, out, log);
+}
+
+bool jit_load_code(const std::vector<char>& code, JitKernel& out, std::string& log) {
     hipModule_t mod = nullptr;
     if (hipModuleLoadData(&mod, code.data()) != hipSuccess) {
         log += " hipModuleLoadData failed";

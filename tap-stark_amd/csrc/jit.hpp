@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <string>
+#include <vector>
 
 #include "air.hpp"
 
@@ -15,6 +16,10 @@ struct JitKernel {
 
 // HIP source of the specialised kernel (exposed for tests / inspection)
 std::string jit_quotient_source(const AirProgram& air);
+// the gfx code object of that source (hiprtc; needs no GPU): false with the reason / compiler output in `log`
+bool jit_compile_code(const AirProgram& air, const char* arch, std::vector<char>& code, std::string& log);
+// loads a code object on the current device
+bool jit_load_code(const std::vector<char>& code, JitKernel& out, std::string& log);
 // false (with a reason in `log`) if hiprtc is missing, disabled (TS_NO_JIT) or compilation fails
 bool jit_compile_quotient(const AirProgram& air, const char* arch, JitKernel& out, std::string& log);
 void jit_release(JitKernel& k);

@@ -54,7 +54,9 @@ LeafMats PcsData::leaf_mats() const {
         lm.row_shift[i] = (uint8_t)(log_height - log2_strict(ldes[i].height));
         lm.total_width += ldes[i].width;
     }
-    lm.cols = col_table.p;
+    // the table is only uploaded when a leaf kernel addressed columns through it (mmcs_commit); readers
+    // of a strided-committed batch use d[] / col_stride and must not be handed uninitialised pointers
+    lm.cols = col_table_uploaded ? col_table.p : nullptr;
     return lm;
 }
 
@@ -89,6 +91,7 @@ void mmcs_commit(Context& ctx, PcsData& data) {
         auto upload_table = [&] {  // only the leaf kernels that address columns through the table read it
             if (!table_uploaded) h2d(ctx, data.col_table.p, cols.data(), cols.size() * sizeof(const uint32_t*));
             table_uploaded = true;
+            data.col_table_uploaded = true;
         };
         auto group_mats = [&](const Group& g) {
             LeafMats lm;
@@ -651,14 +654,17 @@ Ef fri_commit_finish(Context& ctx, const FriConfig& fri, BfChallenger& challenge
     return final_poly;
 }
 
-uint32_t fri_pow_witness(BfChallenger& challenger, unsigned bits, const FriCommit& st) {
+uint32_t fri_pow_witness(Context& ctx, BfChallenger& challenger, unsigned bits, const FriCommit& st) {
     if (st.pow_hint < (1u << 12)) {
         BfChallenger clone = challenger;
         if (clone.check_witness(bits, st.pow_hint)) {
             challenger = clone;
+            ctx.pow_hints_accepted++;
             return st.pow_hint;
         }
+        ctx.pow_hints_rejected++;  // never expected: the device search and the host sponge disagree
     }
+    ctx.pow_host_grinds++;
     return challenger.grind(bits);
 }
 
@@ -807,7 +813,7 @@ void TwoAdicFriPcs::fri_prove(std::vector<DevBuf<Ef>>& inputs, const std::vector
     uint32_t pow_witness;
     {
         StageTimer t(&ctx, "grind for proof-of-work witness");
-        pow_witness = fri_pow_witness(challenger, fri.proof_of_work_bits, st);
+        pow_witness = fri_pow_witness(ctx, challenger, fri.proof_of_work_bits, st);
     }
 
     // ---- query phase :45-59

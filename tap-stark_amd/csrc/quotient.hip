@@ -5,10 +5,15 @@
 // One thread per row of the quotient domain 31*H_{n*qd}, addressed in the LDE's own storage order
 // (bit-reversed), so that `local` is a coalesced read and `next` (natural index + qd) is a second
 // coalesced read for all but one wavefront in 2^(L-6).  The constraint program is interpreted with
-// wave-uniform control flow; its register file lives in LDS ([reg][thread], conflict-free).
+// wave-uniform control flow; its register file lives in LDS ([reg][thread], conflict-free) or, for
+// programs with more live registers than LDS holds, in a global slab per workgroup.
 // folder.rs:60-64 accumulates acc = acc*alpha + c_i; here the same value is formed as
 // sum_i c_i * alpha^(K-1-i) with precomputed powers (4 base multiplications per constraint instead
 // of an EF4 x EF4 product) -- exact field arithmetic, identical result.
+#include <stdlib.h>
+
+#include <algorithm>
+
 #include "air.hpp"
 #include "kernels.hpp"
 
@@ -95,69 +100,116 @@ struct QuotConsts {
     uint32_t inv_zh_canonical[MAX_QUOTIENT_CHUNKS];  // 1/Z_H per coset, CANONICAL: acc(Mont) * it -> canonical
 };
 
-template <int NTHREADS>
+// Register file of the interpreter: [reg][thread], in LDS while it fits (conflict-free, the common
+// case), otherwise in a global scratch slab of the workgroup ([workgroup][reg][thread]: coalesced, L2
+// resident for moderate programs) with a persistent grid walking the row tiles, so that the slab is
+// sized by the grid and not by the domain.  There is no cap on live registers: a program the JIT
+// declines (jit.cpp: instruction budget) still runs on the device.
+struct RegFilePlan {
+    int nthreads;
+    bool global;
+    size_t lds_bytes;
+    unsigned grid;
+    size_t scratch_words;
+};
+
+static RegFilePlan plan_reg_file(Context& ctx, uint32_t n_regs, uint64_t rows) {
+    RegFilePlan pl;
+    pl.nthreads = 256;
+    while (pl.nthreads > 64 && (size_t)n_regs * pl.nthreads * 4 > 48 * 1024) pl.nthreads >>= 1;
+    pl.lds_bytes = (size_t)n_regs * pl.nthreads * 4;
+    pl.global = pl.lds_bytes > ctx.max_lds_per_block || getenv("TS_INTERP_GLOBAL_REGS") != nullptr;
+    const uint64_t tiles = (rows + pl.nthreads - 1) / pl.nthreads;
+    if (pl.global) {
+        pl.nthreads = 64;
+        pl.lds_bytes = 0;
+        const uint64_t t64 = (rows + 63) / 64;
+        // 8 waves per CU hide the slab's latency; the slab stays below 1 GiB
+        uint64_t grid = std::min<uint64_t>(t64, (uint64_t)ctx.num_cus * 8);
+        const uint64_t cap = (1ull << 28) / ((uint64_t)n_regs * 64);
+        grid = std::max<uint64_t>(1, std::min(grid, cap));
+        pl.grid = (unsigned)grid;
+        pl.scratch_words = (size_t)grid * n_regs * 64;
+    } else {
+        pl.grid = (unsigned)tiles;
+        pl.scratch_words = 0;
+    }
+    return pl;
+}
+
+template <int NTHREADS, bool GLOBAL_REGS>
 __global__ void __launch_bounds__(NTHREADS)
 k_quotient(const uint32_t* __restrict__ code, uint32_t n_instr, uint32_t n_regs,
            const uint32_t* __restrict__ lde, uint64_t col_stride, unsigned log_n, unsigned log_qd,
            const uint32_t* __restrict__ consts_mont, const uint32_t* __restrict__ alpha_pows,
            const uint32_t* __restrict__ is_first, const uint32_t* __restrict__ is_last,
            const uint32_t* __restrict__ is_transition, QuotConsts qc, QuotOut out,
-           uint32_t row_begin, uint32_t row_end) {
-    extern __shared__ uint32_t regs[];  // [n_regs][NTHREADS]
+           uint32_t row_begin, uint32_t row_end, uint32_t* __restrict__ reg_slabs, uint32_t n_tiles) {
+    extern __shared__ uint32_t lds_regs[];  // [n_regs][NTHREADS] unless GLOBAL_REGS
     const unsigned L = log_n + log_qd;
-    const uint32_t r = row_begin + blockIdx.x * NTHREADS + threadIdx.x;
     const uint32_t total = 1u << L;
-    const bool active = r < row_end;
-    const uint32_t rr = active ? r : row_begin;
-    const uint32_t i = bitrev32(rr, L);
-    const uint32_t i_next = (i + (1u << log_qd)) & (total - 1);  // prover.rs:139-140,165
-    const uint32_t r_next = bitrev32(i_next, L);
-    const uint32_t sel0 = is_first[rr], sel1 = is_last[rr], sel2 = is_transition[rr];
-    const uint32_t* row_local = lde + rr;
-    const uint32_t* row_next = lde + r_next;
-    uint32_t* my = regs + threadIdx.x;
-    uint32_t acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
+    uint32_t* my = GLOBAL_REGS ? reg_slabs + (size_t)blockIdx.x * n_regs * NTHREADS + threadIdx.x
+                               : lds_regs + threadIdx.x;
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint32_t r = row_begin + tile * NTHREADS + threadIdx.x;
+        const bool active = r < row_end;
+        const uint32_t rr = active ? r : row_begin;
+        const uint32_t i = bitrev32(rr, L);
+        const uint32_t i_next = (i + (1u << log_qd)) & (total - 1);  // prover.rs:139-140,165
+        const uint32_t r_next = bitrev32(i_next, L);
+        const uint32_t sel0 = is_first[rr], sel1 = is_last[rr], sel2 = is_transition[rr];
+        const uint32_t* row_local = lde + rr;
+        const uint32_t* row_next = lde + r_next;
+        uint32_t acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
 
-    for (uint32_t pc = 0; pc < n_instr; pc++) {
-        // wave-uniform instruction fetch (scalar loads)
-        const uint32_t op = code[4 * pc], dst = code[4 * pc + 1], a = code[4 * pc + 2],
-                       b = code[4 * pc + 3];
-        uint32_t v;
-        switch (op) {
-            case D_LOAD: {
-                const uint32_t* base = a ? row_next : row_local;
-                v = to_mont(base[(uint64_t)b * col_stride]);
-                break;
+        for (uint32_t pc = 0; pc < n_instr; pc++) {
+            // wave-uniform instruction fetch (scalar loads)
+            const uint32_t op = code[4 * pc], dst = code[4 * pc + 1], a = code[4 * pc + 2],
+                           b = code[4 * pc + 3];
+            uint32_t v;
+            switch (op) {
+                case D_LOAD: {
+                    const uint32_t* base = a ? row_next : row_local;
+                    v = to_mont(base[(uint64_t)b * col_stride]);
+                    break;
+                }
+                case D_CONST: v = consts_mont[a]; break;
+                case D_SEL: v = a == 0 ? sel0 : (a == 1 ? sel1 : sel2); break;
+                case D_ADD: v = add(my[(size_t)a * NTHREADS], my[(size_t)b * NTHREADS]); break;
+                case D_SUB: v = sub(my[(size_t)a * NTHREADS], my[(size_t)b * NTHREADS]); break;
+                case D_NEG: v = neg(my[(size_t)a * NTHREADS]); break;
+                case D_MUL: v = mont_mul(my[(size_t)a * NTHREADS], my[(size_t)b * NTHREADS]); break;
+                default: {  // D_ASSERT
+                    const uint32_t c = my[(size_t)a * NTHREADS];
+                    const uint32_t* ap = alpha_pows + 4 * b;
+                    acc0 = add(acc0, mont_mul(c, ap[0]));
+                    acc1 = add(acc1, mont_mul(c, ap[1]));
+                    acc2 = add(acc2, mont_mul(c, ap[2]));
+                    acc3 = add(acc3, mont_mul(c, ap[3]));
+                    continue;
+                }
             }
-            case D_CONST: v = consts_mont[a]; break;
-            case D_SEL: v = a == 0 ? sel0 : (a == 1 ? sel1 : sel2); break;
-            case D_ADD: v = add(my[a * NTHREADS], my[b * NTHREADS]); break;
-            case D_SUB: v = sub(my[a * NTHREADS], my[b * NTHREADS]); break;
-            case D_NEG: v = neg(my[a * NTHREADS]); break;
-            case D_MUL: v = mont_mul(my[a * NTHREADS], my[b * NTHREADS]); break;
-            default: {  // D_ASSERT
-                const uint32_t c = my[a * NTHREADS];
-                const uint32_t* ap = alpha_pows + 4 * b;
-                acc0 = add(acc0, mont_mul(c, ap[0]));
-                acc1 = add(acc1, mont_mul(c, ap[1]));
-                acc2 = add(acc2, mont_mul(c, ap[2]));
-                acc3 = add(acc3, mont_mul(c, ap[3]));
-                continue;
-            }
+            my[(size_t)dst * NTHREADS] = v;
         }
-        my[dst * NTHREADS] = v;
+        if (!active) continue;
+        // quotient(x) = constraints(x) / Z_H(x)  (prover.rs:183); flatten + split (prover.rs:78-80):
+        // natural row i -> chunk i % qd, position i / qd; stored bit-reversed = r & (n-1)
+        const uint32_t c = bitrev32(r >> log_n, log_qd);
+        const uint32_t iz = qc.inv_zh_canonical[c];
+        const uint64_t n = 1ull << log_n;
+        uint32_t* o = out.chunk[c] + (r & (n - 1));
+        o[0] = mont_mul(acc0, iz);
+        o[n] = mont_mul(acc1, iz);
+        o[2 * n] = mont_mul(acc2, iz);
+        o[3 * n] = mont_mul(acc3, iz);
     }
-    if (!active) return;
-    // quotient(x) = constraints(x) / Z_H(x)  (prover.rs:183); flatten + split (prover.rs:78-80):
-    // natural row i -> chunk i % qd, position i / qd; stored bit-reversed = r & (n-1)
-    const uint32_t c = bitrev32(r >> log_n, log_qd);
-    const uint32_t iz = qc.inv_zh_canonical[c];
-    const uint64_t n = 1ull << log_n;
-    uint32_t* o = out.chunk[c] + (r & (n - 1));
-    o[0] = mont_mul(acc0, iz);
-    o[n] = mont_mul(acc1, iz);
-    o[2 * n] = mont_mul(acc2, iz);
-    o[3 * n] = mont_mul(acc3, iz);
+}
+
+template <class K>
+static void allow_lds(K kernel, size_t lds) {
+    // above 64 KiB the dynamic LDS size has to be granted per function (gfx950: 160 KiB per workgroup)
+    if (lds > 48 * 1024)
+        TS_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 }
 
 void launch_quotient(Context& ctx, const AirProgram& air, const ColMat& trace_lde, unsigned log_n,
@@ -189,20 +241,21 @@ void launch_quotient(Context& ctx, const AirProgram& air, const ColMat& trace_ld
                                      256, 1, 1, 0, ctx.stream, args, nullptr));
         return;
     }
-    // LDS register file: <= 48 KiB per workgroup
-    int nthreads = 256;
-    while (nthreads > 64 && (size_t)air.n_regs * nthreads * 4 > 48 * 1024) nthreads >>= 1;
-    TS_REQUIRE((size_t)air.n_regs * nthreads * 4 <= 64 * 1024, TS_ERR_UNSUPPORTED,
-               "constraint program needs too many live registers for the interpreter");
-    const size_t lds = (size_t)air.n_regs * nthreads * 4;
-    const unsigned grid = (unsigned)((total + nthreads - 1) / nthreads);
-#define TS_LAUNCH_Q(NTH)                                                                          \
-    TS_LAUNCH(ctx, k_quotient<NTH>, dim3(grid), dim3(NTH), lds, air.d_code, n_instr, \
-                       air.n_regs, trace_lde.d, trace_lde.col_stride, log_n, log_qd, d_consts_mont, \
-                       d_alpha_pows_mont, is_first, is_last, is_transition, qc, out, rb, re)
-    if (nthreads == 256) TS_LAUNCH_Q(256);
-    else if (nthreads == 128) TS_LAUNCH_Q(128);
-    else TS_LAUNCH_Q(64);
+    const RegFilePlan pl = plan_reg_file(ctx, air.n_regs, total);
+    DevBuf<uint32_t> slabs;
+    if (pl.global) slabs = DevBuf<uint32_t>(&ctx, pl.scratch_words);
+    const uint32_t n_tiles = (uint32_t)((total + pl.nthreads - 1) / pl.nthreads);
+#define TS_LAUNCH_Q(NTH, GLOB)                                                                          \
+    do {                                                                                                \
+        allow_lds(k_quotient<NTH, GLOB>, pl.lds_bytes);                                                 \
+        TS_LAUNCH(ctx, (k_quotient<NTH, GLOB>), dim3(pl.grid), dim3(NTH), pl.lds_bytes, air.d_code, n_instr, \
+                  air.n_regs, trace_lde.d, trace_lde.col_stride, log_n, log_qd, d_consts_mont,          \
+                  d_alpha_pows_mont, is_first, is_last, is_transition, qc, out, rb, re, slabs.p, n_tiles); \
+    } while (0)
+    if (pl.global) TS_LAUNCH_Q(64, true);
+    else if (pl.nthreads == 256) TS_LAUNCH_Q(256, false);
+    else if (pl.nthreads == 128) TS_LAUNCH_Q(128, false);
+    else TS_LAUNCH_Q(64, false);
 #undef TS_LAUNCH_Q
     TS_HIP(hipGetLastError());
 }
@@ -252,61 +305,70 @@ void launch_chunk_mix(Context& ctx, uint32_t* const* d_chunk_ptrs, uint32_t qd, 
 // is_last_row = (i == h-1), is_transition = (i != h-1) and the next row wrapping around.
 // One thread per row of the row-major trace; the first violation (row * 2^16 + constraint index,
 // smallest wins) is left in *violation.
-template <int NTHREADS>
+template <int NTHREADS, bool GLOBAL_REGS>
 __global__ void __launch_bounds__(NTHREADS)
-k_check_constraints(const uint32_t* __restrict__ code, uint32_t n_instr, const uint32_t* __restrict__ trace,
-                    uint32_t width, uint64_t n, const uint32_t* __restrict__ consts_mont,
-                    unsigned long long* __restrict__ violation) {
-    extern __shared__ uint32_t regs[];
-    const uint64_t i = (uint64_t)blockIdx.x * NTHREADS + threadIdx.x;
-    const bool active = i < n;
-    const uint64_t ii = active ? i : 0;
-    const uint32_t* row_local = trace + ii * width;
-    const uint32_t* row_next = trace + ((ii + 1) % n) * width;
-    const uint32_t sel0 = ii == 0 ? R_MOD_P : 0u;
-    const uint32_t sel1 = ii == n - 1 ? R_MOD_P : 0u;
-    const uint32_t sel2 = ii != n - 1 ? R_MOD_P : 0u;
-    uint32_t* my = regs + threadIdx.x;
-    unsigned long long bad = ~0ull;
-    for (uint32_t pc = 0; pc < n_instr; pc++) {
-        const uint32_t op = code[4 * pc], dst = code[4 * pc + 1], a = code[4 * pc + 2],
-                       b = code[4 * pc + 3];
-        uint32_t v;
-        switch (op) {
-            case D_LOAD: v = to_mont((a ? row_next : row_local)[b]); break;
-            case D_CONST: v = consts_mont[a]; break;
-            case D_SEL: v = a == 0 ? sel0 : (a == 1 ? sel1 : sel2); break;
-            case D_ADD: v = add(my[a * NTHREADS], my[b * NTHREADS]); break;
-            case D_SUB: v = sub(my[a * NTHREADS], my[b * NTHREADS]); break;
-            case D_NEG: v = neg(my[a * NTHREADS]); break;
-            case D_MUL: v = mont_mul(my[a * NTHREADS], my[b * NTHREADS]); break;
-            default: {  // D_ASSERT
-                if (my[a * NTHREADS] != 0 && bad == ~0ull) bad = ii * 65536ull + b;
-                continue;
+k_check_constraints(const uint32_t* __restrict__ code, uint32_t n_instr, uint32_t n_regs,
+                    const uint32_t* __restrict__ trace, uint32_t width, uint64_t n,
+                    const uint32_t* __restrict__ consts_mont, unsigned long long* __restrict__ violation,
+                    uint32_t* __restrict__ reg_slabs, uint32_t n_tiles) {
+    extern __shared__ uint32_t lds_regs[];
+    uint32_t* my = GLOBAL_REGS ? reg_slabs + (size_t)blockIdx.x * n_regs * NTHREADS + threadIdx.x
+                               : lds_regs + threadIdx.x;
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint64_t i = (uint64_t)tile * NTHREADS + threadIdx.x;
+        const bool active = i < n;
+        const uint64_t ii = active ? i : 0;
+        const uint32_t* row_local = trace + ii * width;
+        const uint32_t* row_next = trace + ((ii + 1) % n) * width;
+        const uint32_t sel0 = ii == 0 ? R_MOD_P : 0u;
+        const uint32_t sel1 = ii == n - 1 ? R_MOD_P : 0u;
+        const uint32_t sel2 = ii != n - 1 ? R_MOD_P : 0u;
+        unsigned long long bad = ~0ull;
+        for (uint32_t pc = 0; pc < n_instr; pc++) {
+            const uint32_t op = code[4 * pc], dst = code[4 * pc + 1], a = code[4 * pc + 2],
+                           b = code[4 * pc + 3];
+            uint32_t v;
+            switch (op) {
+                case D_LOAD: v = to_mont((a ? row_next : row_local)[b]); break;
+                case D_CONST: v = consts_mont[a]; break;
+                case D_SEL: v = a == 0 ? sel0 : (a == 1 ? sel1 : sel2); break;
+                case D_ADD: v = add(my[(size_t)a * NTHREADS], my[(size_t)b * NTHREADS]); break;
+                case D_SUB: v = sub(my[(size_t)a * NTHREADS], my[(size_t)b * NTHREADS]); break;
+                case D_NEG: v = neg(my[(size_t)a * NTHREADS]); break;
+                case D_MUL: v = mont_mul(my[(size_t)a * NTHREADS], my[(size_t)b * NTHREADS]); break;
+                default: {  // D_ASSERT
+                    if (my[(size_t)a * NTHREADS] != 0 && bad == ~0ull) bad = ii * 65536ull + b;
+                    continue;
+                }
             }
+            my[(size_t)dst * NTHREADS] = v;
         }
-        my[dst * NTHREADS] = v;
+        if (active && bad != ~0ull) atomicMin(violation, bad);
     }
-    if (active && bad != ~0ull) atomicMin(violation, bad);
 }
 
 void launch_check_constraints(Context& ctx, const AirProgram& air, const uint32_t* trace_row_major,
                               uint64_t n, const uint32_t* d_consts_mont,
                               unsigned long long* d_violation) {
     TS_REQUIRE(air.d_code != nullptr, TS_ERR_INVALID, "air program not uploaded");
+    // the report is row * 2^16 + constraint index (the oracle's and stark.py's format)
+    TS_REQUIRE(air.n_constraints <= 65536, TS_ERR_UNSUPPORTED, "check_constraints: more than 65536 constraints");
     const uint32_t n_instr = (uint32_t)(air.code.size() / 4);
-    int nthreads = 256;
-    while (nthreads > 64 && (size_t)air.n_regs * nthreads * 4 > 48 * 1024) nthreads >>= 1;
-    TS_REQUIRE((size_t)air.n_regs * nthreads * 4 <= 64 * 1024, TS_ERR_UNSUPPORTED,
-               "constraint program needs too many live registers for the interpreter");
-    const size_t lds = (size_t)air.n_regs * nthreads * 4;
-    const unsigned grid = (unsigned)((n + nthreads - 1) / nthreads);
-#define TS_LAUNCH_C(NTH)                                                                       \
-    TS_LAUNCH(ctx, k_check_constraints<NTH>, dim3(grid), dim3(NTH), lds, air.d_code, n_instr,  \
-              trace_row_major, air.width, n, d_consts_mont, d_violation)
-    if (nthreads == 256) TS_LAUNCH_C(256);
-    else if (nthreads == 128) TS_LAUNCH_C(128);
-    else TS_LAUNCH_C(64);
+    const RegFilePlan pl = plan_reg_file(ctx, air.n_regs, n);
+    DevBuf<uint32_t> slabs;
+    if (pl.global) slabs = DevBuf<uint32_t>(&ctx, pl.scratch_words);
+    const uint32_t n_tiles = (uint32_t)((n + pl.nthreads - 1) / pl.nthreads);
+#define TS_LAUNCH_C(NTH, GLOB)                                                                         \
+    do {                                                                                               \
+        allow_lds(k_check_constraints<NTH, GLOB>, pl.lds_bytes);                                       \
+        TS_LAUNCH(ctx, (k_check_constraints<NTH, GLOB>), dim3(pl.grid), dim3(NTH), pl.lds_bytes,       \
+                  air.d_code, n_instr, air.n_regs, trace_row_major, air.width, n, d_consts_mont,       \
+                  d_violation, slabs.p, n_tiles);                                                      \
+    } while (0)
+    if (pl.global) TS_LAUNCH_C(64, true);
+    else if (pl.nthreads == 256) TS_LAUNCH_C(256, false);
+    else if (pl.nthreads == 128) TS_LAUNCH_C(128, false);
+    else TS_LAUNCH_C(64, false);
 #undef TS_LAUNCH_C
     TS_HIP(hipGetLastError());
 }

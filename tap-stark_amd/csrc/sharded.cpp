@@ -169,6 +169,7 @@ std::unique_ptr<ShardedData> commit_sharded(Shard& sh, std::vector<DeviceMatrix>
             for (uint32_t c = 0; c < cm.width; c++) cols.push_back(cm.d + (uint64_t)c * cm.col_stride);
         loc.col_table = DevBuf<const uint32_t*>(&ctx, cols.size());
         h2d(ctx, loc.col_table.p, cols.data(), cols.size() * sizeof(const uint32_t*));
+        loc.col_table_uploaded = true;
         LeafMats lm = loc.leaf_mats();
         if (loc.ldes.size() > 1) {  // laid back to back above: one matrix of the summed width for the leaf hash
             bool contiguous = true;
@@ -445,7 +446,7 @@ std::vector<uint32_t> prove_sharded(TwoAdicFriPcs& pcs, const Comm& comm, const 
     uint32_t pow_witness;
     {
         StageTimer t(&ctx, "grind for proof-of-work witness");
-        pow_witness = fri_pow_witness(challenger, fri.proof_of_work_bits, st);  // prover.rs:43
+        pow_witness = fri_pow_witness(ctx, challenger, fri.proof_of_work_bits, st);  // prover.rs:43
     }
 
     // ---- query phase (prover.rs:45-59): a rank answers the queries that fall into its slab

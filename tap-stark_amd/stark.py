@@ -242,7 +242,57 @@ class CompiledAir:
         self._l.ts_air_info(h, C.byref(w), C.byref(npub), C.byref(deg), C.byref(lqd))
         self.width, self.n_public = int(w.value), int(npub.value)
         self.max_constraint_degree, self.log_quotient_degree = int(deg.value), int(lqd.value)
-        self.is_jit = bool(self._l.ts_air_is_jit(h))
+
+    @property
+    def is_jit(self) -> bool:
+        """The hiprtc-specialised quotient kernel is loaded (else the on-device interpreter runs;
+        large programs are compiled in the background and switch over when ready)."""
+        return bool(self._l.ts_air_is_jit(self.h))
+
+    def jit_wait(self) -> tuple[int, float]:
+        """Joins a background specialisation: (state 0 none | 3 loaded | 4 failed, compile seconds)."""
+        st, secs = C.c_int(), C.c_double()
+        rc = self._l.ts_air_jit_wait(self.ctx.h, self.h, C.byref(st), C.byref(secs))
+        if rc:
+            raise self._err(rc)
+        return int(st.value), float(secs.value)
+
+    def _err(self, rc: int):
+        msg = self._l.ts_last_error(self.ctx.h if self.ctx else None) or b""
+        return _lib.TsError(rc, msg.decode())
+
+    def program(self) -> dict:
+        """The register program the tape was lowered to (``ts_air_program``): ``n_regs``, ``code``
+        (n_instr, 4) = {op, dst, a, b}, ``consts`` (canonical), ``const_public`` (index or 0xffffffff)."""
+        n = C.c_size_t()
+        self._l.ts_air_program(self.h, None, 0, C.byref(n))
+        out = np.zeros(n.value, dtype=np.uint32)
+        rc = self._l.ts_air_program(self.h, _p(out), len(out), C.byref(n))
+        if rc:
+            raise self._err(rc)
+        n_regs, n_instr, n_consts = (int(v) for v in out[:3])
+        code = out[3:3 + 4 * n_instr].reshape(n_instr, 4)
+        consts = out[3 + 4 * n_instr:3 + 4 * n_instr + n_consts]
+        return {"n_regs": n_regs, "code": code, "consts": consts, "const_public": out[3 + 4 * n_instr + n_consts:]}
+
+    def jit_source(self) -> str:
+        n = C.c_size_t()
+        self._l.ts_air_jit_source(self.h, None, 0, C.byref(n))
+        buf = C.create_string_buffer(n.value)
+        rc = self._l.ts_air_jit_source(self.h, buf, n.value, C.byref(n))
+        if rc:
+            raise self._err(rc)
+        return buf.raw[:n.value].decode()
+
+    def jit_compile(self, arch: str = "gfx950") -> tuple[bytes, float]:
+        """(code object, compile seconds) of the hiprtc-specialised quotient kernel; no GPU needed."""
+        cap = 64 << 20
+        buf = C.create_string_buffer(cap)
+        n, secs = C.c_size_t(), C.c_double()
+        rc = self._l.ts_air_jit_compile(self.h, arch.encode(), buf, cap, C.byref(n), C.byref(secs))
+        if rc:
+            raise self._err(rc)
+        return buf.raw[:n.value], float(secs.value)
 
     def __del__(self):
         try:

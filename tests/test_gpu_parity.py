@@ -684,6 +684,10 @@ EDGE_CASES = [
     ("mul64-q100", lambda: (SynthMulAir(64), generate_synth_mul_trace(1 << 10)), False, (2, 100, 8)),
     ("mul64-b5", lambda: (SynthMulAir(64), generate_synth_mul_trace(1 << 8)), False, (5, 4, 8)),
     ("mul200", lambda: (SynthMulAir(200), generate_synth_mul_trace(1 << 6, 200)), False, (2, 4, 8)),
+    # wider than the mailbox page's quarter (8w + 16qd > 4096 words): the opened-value sums take the
+    # large-message path (csrc/context.cpp Context::mailbox)
+    ("mul640", lambda: (SynthMulAir(640), generate_synth_mul_trace(1 << 5, 640)), False, (2, 4, 8)),
+    ("mul1500", lambda: (SynthMulAir(1500), generate_synth_mul_trace(1 << 3, 1500)), False, (2, 3, 4)),
 ]
 
 
@@ -708,6 +712,8 @@ def test_proof_of_work_witness_found_on_the_device(ctx, orc, bits):
     # for bit counts whose witnesses lie in the first pass (<= 8 bits, mostly) and beyond it (10, 11 bits:
     # one candidate in ~340 / ~680 passes)
     seen = []
+    stat0 = [ctx.stat(k) for k in (6, 7, 8)]
+    n_proved = 0
     for a0 in range(4):
         trace = generate_fibonacci_trace(a0, 1, 1 << 6)
         pis = fibonacci_public_values(trace)
@@ -723,7 +729,16 @@ def test_proof_of_work_witness_found_on_the_device(ctx, orc, bits):
         proof = ts.prove(ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(*cfg), ctx)), FibonacciAir(), ts.BfChallenger(), trace, pis)
         assert len(proof.words) == len(want) and (proof.words == want).all()
         seen.append(proof.pow_witness)
+        n_proved += 1
     assert seen, "no transcript had a witness"
+    # the witness really came from k_fri_tail's search: every proof's candidate was accepted by the host's
+    # one-step check, none refused, and the host never searched (ts_ctx_stat 6 / 7 / 8)
+    accepted, rejected, host = (ctx.stat(k) - s0 for k, s0 in zip((6, 7, 8), stat0))
+    assert rejected == 0
+    if os.environ.get("TS_HOST_GRIND"):
+        assert accepted == 0 and host == n_proved
+    else:
+        assert accepted == n_proved and host == 0, (accepted, host, n_proved)
     if bits == 0:
         assert seen == [0] * len(seen)
     if bits >= 10:

@@ -715,6 +715,7 @@ def main():
         n_windows -= 1
     total = warmup + n_windows * args.steps
     last = {}
+    lane_log = [[] for _ in range(S)]  # per lane: (t ts_prove called, t returned, s waited at the start gate)
     gsize, n_groups, comm = 1, 1, None
     if sharded:
         # one proof per step over all ranks: rank g is handed natural rows [g n/G, (g+1) n/G)
@@ -783,8 +784,11 @@ def main():
                 m = ts.DeviceMatrix.upload(c, host_trace)
             else:
                 m = mats[i] if pregen else make_trace(c)
+            tg = time.perf_counter()
             start_gate()
+            t0 = time.perf_counter()
             last["proof"] = ts.prove(conf, ca, ts.BfChallenger(), m, pis)
+            lane_log[i % S].append((t0, time.perf_counter(), t0 - tg))  # ts_prove call, return, time held at the gate
             if pregen:
                 mats[i] = None  # the matrix handle is spent
 
@@ -854,35 +858,83 @@ def main():
         del prime
         if S > 1:
             stagger["ms"] = args.stagger_ms if args.stagger_ms >= 0 else 0.25 * single_ms
-        # Sustained priming (setup, untimed, on the record as extra.sustained_prime_s): the lanes prove
-        # freshly generated traces together for a fraction of a second before the W warm-up steps.  The first
-        # process on a fresh box needs ~0.1 s of this load before clocks and power management settle: one
-        # run in five of a cold box showed windows of 3.18 / 2.85 / 2.81 ms per step where every later run
-        # gave 2.80-2.84 in all three.  The metric is sustained proofs per second; TS_BENCH_PRIME_S=0 turns
-        # the priming off.
-        prime_s = float(os.environ.get("TS_BENCH_PRIME_S", "0.35"))
-        if prime_s > 0:
-            t_end = time.perf_counter() + prime_s
-
-            def prime_job(l):
-                c, conf, ca = lanes[l]
-                while time.perf_counter() < t_end:
-                    start_gate()
-                    ts.prove(conf, ca, ts.BfChallenger(), make_trace(c), pis)
-            if S > 1:
-                list(pool.map(prime_job, range(S)))
-            else:
-                prime_job(0)
+        # Sustained priming (setup, untimed, on the record as `priming`): before the W warm-up steps the
+        # lanes prove freshly generated traces in probes of K steps -- the timed window's own shape: same
+        # lanes, same start gate, a device sync on both sides -- until two consecutive probes agree within
+        # 1.5 %, for at most TS_BENCH_PRIME_S (default 2 s) in all.  A fresh box needs a fraction of a
+        # second of this load before clocks and power management settle (cold first windows of 3.18 ms per
+        # step against 2.8 in every later one were seen, and the driver's r05 run: 2.908 against 2.690
+        # sustained in the same process).  The metric is sustained proofs per second; TS_BENCH_PRIME_S=0
+        # turns the priming off.
+        prime_cap = float(os.environ.get("TS_BENCH_PRIME_S", "2.0"))
+        probes = []
+        t_prime0 = time.perf_counter()
+        while prime_cap > 0 and time.perf_counter() - t_prime0 < prime_cap:
+            pm = [make_trace(lanes[i % S][0]) for i in range(args.steps)]
             for c, _, _ in lanes:
                 c.synchronize()
-        primed["s"] = prime_s
+
+            def probe_job(l):
+                c, conf, ca = lanes[l]
+                for i in range(l, args.steps, S):
+                    start_gate()
+                    ts.prove(conf, ca, ts.BfChallenger(), pm[i], pis)
+            tp = time.perf_counter()
+            if S > 1:
+                list(pool.map(probe_job, range(S)))
+            else:
+                probe_job(0)
+            for c, _, _ in lanes:
+                c.synchronize()
+            probes.append(round(1e3 * (time.perf_counter() - tp) / args.steps, 4))
+            if len(probes) >= 2 and abs(probes[-1] - probes[-2]) <= 0.015 * min(probes[-1], probes[-2]):
+                break
+        primed["s"] = round(time.perf_counter() - t_prime0, 3)
+        primed["probes_ms_per_step"] = probes
+        primed["settled"] = bool(len(probes) >= 2 and abs(probes[-1] - probes[-2]) <= 0.015 * min(probes[-1], probes[-2]))
 
     phase_done("start-up (imports, rendezvous, context, AIR compile)")
+    # clock / power sampler over the timed windows: a CHILD process (amdsmi only), so that it takes
+    # nothing from this process's interpreter lock; rank 0 only; TS_BENCH_SAMPLER=0 turns it off
+    sampler = None
+    if env.rank == 0 and os.environ.get("TS_BENCH_SAMPLER", "1") != "0":
+        from tapstark_amd.benchutil import GpuSamplerProcess
+        sampler = GpuSamplerProcess(dev, 0.01)
+    for lg in lane_log:
+        lg.clear()
     # sharded: the ranks of a group share each step's n*w cells
     res = run_timed(env, step, args.steps, warmup, local_sync,
                     units_per_step=float(n * w) / (gsize if sharded else 1), run_steps=run_steps,
                     extra_windows=n_windows - 1)
+    if sampler is not None:
+        sampler.stop()
     phase_done("replicas: warm-up + timed windows")
+    # per window: ms/step, the clock and power the chip held, and what the host side did on each lane
+    # (the longest pause between one ts_prove returning and the next being called, and how much of the
+    # pauses was the start gate) -- so that a slow window names its cause
+    per_window = []
+    for k, (w0, w1) in enumerate(res.get("windows_t") or []):
+        row = {"window": k + 1, "ms_per_step": round(res["windows_ms_per_step"][k], 4)}
+        if sampler is not None:
+            row.update(sampler.window(w0, w1) if not sampler.error or sampler.samples else {"sampler_error": sampler.error})
+        gaps, gate, first_call, last_ret, lat = [], 0.0, [], [], []
+        for lg in lane_log:
+            evs = [e for e in lg if w0 <= e[0] <= w1]
+            if not evs:
+                continue
+            first_call.append(evs[0][0] - w0)
+            last_ret.append(w1 - evs[-1][1])
+            gate += sum(e[2] for e in evs)
+            lat += [e[1] - e[0] for e in evs]
+            gaps += [b[0] - a[1] for a, b in zip(evs, evs[1:])]
+        if lat:
+            row.update({"longest_host_gap_ms": round(1e3 * max(gaps), 3) if gaps else 0.0,
+                        "host_gaps_total_ms": round(1e3 * sum(gaps), 3), "of_which_start_gate_ms": round(1e3 * gate, 3),
+                        "first_call_after_window_start_ms": [round(1e3 * x, 3) for x in first_call],
+                        "window_end_after_last_return_ms": [round(1e3 * x, 3) for x in last_ret],
+                        "proof_latency_in_window_ms_median": round(1e3 * sorted(lat)[len(lat) // 2], 3),
+                        "proof_latency_in_window_ms_max": round(1e3 * max(lat), 3)})
+        per_window.append(row)
     shard_stages = None
     if sharded:
         import torch.distributed as dist
@@ -914,6 +966,10 @@ def main():
             "metric": f"trace cells/sec (proofs/sec alongside), 2^{args.log_n}x{w} BabyBear trace",
             "value": res["value"], "unit": "trace cells/sec", "n_gpus": env.world,
             "steps": args.steps, "warmup": warmup, "ms_per_step": res["ms_per_step"],
+            # every timed window of K steps (value / ms_per_step are the first), with the clock, power and
+            # host-side gaps of each; `priming`: the untimed probes run before the warm-up steps
+            "windows_ms_per_step": [round(x, 4) for x in wins],
+            "windows": per_window, "priming": dict(primed),
             "higher_is_better": True,
             "scaling": ("strong" if n_groups == 1 else "strong within a group, weak across groups")
                        if sharded else "weak", "vs_baseline": None,
@@ -941,6 +997,7 @@ def main():
                       "note": f"{len(wins)} back-to-back timed windows of {args.steps} steps each, every one "
                               "bracketed by barrier + device sync; `value` / `ms_per_step` are window 1",
                       "lanes": S, "stagger_ms": round(stagger["ms"], 3), "sustained_prime_s": primed["s"],
+                      "sampler_error": getattr(sampler, "error", None),
                       "one_proof_alone_ms_before_the_run": None if single_ms is None else round(single_ms, 3),
                       "self_launched": bool(os.environ.get("TS_BENCH_SELF_LAUNCHED"))},
             "shard_stages_ms_per_rank": shard_stages,
@@ -1023,6 +1080,40 @@ def main():
         emit(out)
 
 
+# Live counter passes run `rocprofv3 -- python tools/prof_prove.py` as children.  On a timeout the whole
+# process GROUP is killed (the profiled python is a grandchild that would otherwise keep the pipes and
+# its GPU context), the wait after the kill is bounded, and the passes share one time budget.
+_PMC_BUDGET = {"left_s": float(os.environ.get("TS_BENCH_PMC_BUDGET_S", "90"))}
+
+
+def run_child_bounded(cmd, cwd, env, timeout_s: float):
+    """(returncode, stdout, stderr) or raises TimeoutError; never blocks past timeout_s + 5 s."""
+    import signal
+    import subprocess
+
+    timeout_s = min(timeout_s, _PMC_BUDGET["left_s"])
+    if timeout_s <= 1:
+        raise TimeoutError("live counter passes: time budget (TS_BENCH_PMC_BUDGET_S) used up")
+    t0 = time.perf_counter()
+    p = subprocess.Popen(cmd, cwd=cwd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                         start_new_session=True)
+    try:
+        out, err = p.communicate(timeout=timeout_s)
+        return p.returncode, out, err
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(p.pid, signal.SIGKILL)
+        except OSError:
+            pass
+        try:
+            p.communicate(timeout=5)
+        except Exception:  # noqa: BLE001
+            pass
+        raise TimeoutError(f"child still running after {timeout_s:.0f} s: process group killed")
+    finally:
+        _PMC_BUDGET["left_s"] -= time.perf_counter() - t0
+
+
 def live_pmc_traffic(workload: str, kernel: str, timeout_s: float = 150.0):
     """HBM-side traffic of `kernel` measured NOW: two child processes, `rocprofv3 --pmc FETCH_SIZE` and
     `rocprofv3 --pmc WRITE_SIZE` (separate passes, counters only, the program itself after `--`) around
@@ -1051,10 +1142,10 @@ def live_pmc_traffic(workload: str, kernel: str, timeout_s: float = 150.0):
                    sys.executable or "/usr/bin/python3", os.path.join(ROOT, "tools", "prof_prove.py"), "2", workload]
             env = dict(os.environ, TMPDIR="/tmp")
             env.pop("TS_BENCH_SELF_LAUNCHED", None)
-            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            rc, r_out, r_err = run_child_bounded(cmd, "/tmp", env, timeout_s)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
-            if r.returncode != 0 or not files:
-                return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode}): {(r.stderr or r.stdout)[-200:]}"
+            if rc != 0 or not files:
+                return None, f"rocprofv3 --pmc {counter} failed (rc {rc}): {(r_err or r_out)[-200:]}"
             v, c = 0.0, 0
             for row in csv.DictReader(open(files[0])):
                 if row["Counter_Name"] != counter:
@@ -1101,10 +1192,10 @@ def live_valu_instructions(workload: str, timeout_s: float = 150.0):
         cmd = [exe, "--pmc", "SQ_INSTS_VALU", "--output-format", "csv", "-d", tmp, "-o", "sq", "--",
                sys.executable or "/usr/bin/python3", os.path.join(ROOT, "tools", "prof_prove.py"), str(n_proofs), workload]
         env = dict(os.environ, TMPDIR="/tmp")
-        r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+        rc, r_out, r_err = run_child_bounded(cmd, "/tmp", env, timeout_s)
         files = glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True)
-        if r.returncode != 0 or not files:
-            return None, f"rocprofv3 --pmc SQ_INSTS_VALU failed (rc {r.returncode}): {(r.stderr or r.stdout)[-200:]}"
+        if rc != 0 or not files:
+            return None, f"rocprofv3 --pmc SQ_INSTS_VALU failed (rc {rc}): {(r_err or r_out)[-200:]}"
         tot = 0.0
         for row in csv.DictReader(open(files[0])):
             if row["Counter_Name"] != "SQ_INSTS_VALU":
@@ -1143,9 +1234,16 @@ def rank0_legs(ts, args, env, ctx, config, cair, lanes, S, pool, local_sync, mak
         ts.prove(config, cair, ts.BfChallenger(), m, pis)
     kt = ctx.take_kernel_timings()
     ctx.set_kernel_timing(False)
+    # stage timers: five proofs, the MEDIAN of every stage (one sample showed a host hiccup as a 0.67-ms
+    # query phase in the driver's r05 record)
     ctx.set_timing(True)
-    ts.prove(config, cair, ts.BfChallenger(), make_trace(ctx), pis)
-    stages = ctx.take_timings()
+    stage_runs = []
+    for _ in range(5):
+        ts.prove(config, cair, ts.BfChallenger(), make_trace(ctx), pis)
+        one = {}
+        for k, v in ctx.take_timings():  # a stage name can occur twice (trace commit, quotient commit)
+            one[k] = one.get(k, 0.0) + v
+        stage_runs.append(one)
     ctx.set_timing(False)
     # one proof alone on the GPU, no timers inside (the stage timers synchronise at every stage
     # boundary): host wall clock around ts_prove, which returns with the proof on the host
@@ -1157,9 +1255,7 @@ def rank0_legs(ts, args, env, ctx, config, cair, lanes, S, pool, local_sync, mak
         ts.prove(config, cair, ts.BfChallenger(), m_, pis)
         lat.append(1e3 * (time.perf_counter() - t0))
     single_latency = sorted(lat)[len(lat) // 2]
-    stage_sum = {}
-    for k, v in stages:  # a stage name can occur twice (trace commit, quotient commit)
-        stage_sum[k] = round(stage_sum.get(k, 0.0) + v, 3)
+    stage_sum = {k: round(sorted(r.get(k, 0.0) for r in stage_runs)[len(stage_runs) // 2], 3) for k in stage_runs[0]}
     alg = algorithmic_bytes_per_proof(n, w, cfg[0], qd)
 
     leaf_tree_path = any("k_leaf_tree" in k for k in kt)

@@ -112,6 +112,7 @@ int ts_or_air_log_quotient_degree(const uint32_t* tape, size_t n_words);
 int ts_or_tape_constraint_values(const uint32_t* tape, size_t n_words, const uint32_t* local,
                                  const uint32_t* next, size_t m, const uint32_t* pis,
                                  const uint32_t* sels, uint32_t* out);
+void ts_or_set_debug_assertions(int on); /* prover.rs:40-41; default on */
 int64_t ts_or_check_constraints(const uint32_t* tape, size_t n_words, const uint32_t* trace,
                                 size_t n, const uint32_t* pis);
 

@@ -290,15 +290,21 @@ def open_reduce(trace_lde, chunk_ldes, log_n, log_blowup, zeta, alpha):
 
 # --------------------------------------------------------------- whole proofs
 def prove(cfg: FriConfig, tape, trace, pis, chal: OracleChallenger | None = None,
-          cap_words: int = 1 << 24) -> np.ndarray:
+          cap_words: int = 1 << 24, debug_assertions: bool = True) -> np.ndarray:
+    """debug_assertions=False: a release build of the reference (prover.rs:40-41 compiles
+    check_constraints out), which proves an invalid trace without complaint."""
     tape, trace, pis = _u32(tape), _u32(trace), _u32(pis)
     if len(pis) == 0:
         pis = np.zeros(1, dtype=np.uint32)
     chal = chal or OracleChallenger()
     log_n = trace.shape[0].bit_length() - 1
     out = np.zeros(cap_words, dtype=np.uint32)
-    n = lib().ts_or_prove(C.byref(cfg), _p(tape), C.c_size_t(len(tape)), C.byref(chal.c),
-                          _p(trace), C.c_uint(log_n), _p(pis), _p(out), C.c_size_t(cap_words))
+    lib().ts_or_set_debug_assertions(1 if debug_assertions else 0)
+    try:
+        n = lib().ts_or_prove(C.byref(cfg), _p(tape), C.c_size_t(len(tape)), C.byref(chal.c),
+                              _p(trace), C.c_uint(log_n), _p(pis), _p(out), C.c_size_t(cap_words))
+    finally:
+        lib().ts_or_set_debug_assertions(1)
     if n < 0:
         raise RuntimeError(f"oracle prove failed: {n}")
     return out[:n].copy()

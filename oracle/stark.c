@@ -457,6 +457,11 @@ static int pcs_open(const ts_or_fri_config* cfg, int n_rounds, const open_round*
 
 #define TSPF_MAGIC 0x46505354u
 
+/* prover.rs:40-41: `#[cfg(debug_assertions)] check_constraints(...)`.  On by default (a debug build of
+ * the reference); off = a release build, which proves whatever trace it is given. */
+static int g_debug_assertions = 1;
+void ts_or_set_debug_assertions(int on) { g_debug_assertions = on; }
+
 int64_t ts_or_prove(const ts_or_fri_config* cfg, const uint32_t* tape, size_t n_tape,
                     ts_or_challenger* chal, const uint32_t* trace, unsigned log_n,
                     const uint32_t* pis, uint32_t* proof_out, size_t cap_words) {
@@ -464,7 +469,7 @@ int64_t ts_or_prove(const ts_or_fri_config* cfg, const uint32_t* tape, size_t n_
     if (ts_or_tape_parse(tape, n_tape, &t)) return -2;
     size_t n = (size_t)1 << log_n, w = t.width;
     /* prover.rs:40-41 (debug_assertions) */
-    if (ts_or_check_constraints(tape, n_tape, trace, n, pis) >= 0) return -3;
+    if (g_debug_assertions && ts_or_check_constraints(tape, n_tape, trace, n, pis) >= 0) return -3;
     unsigned lqd = (unsigned)ts_or_air_log_quotient_degree(tape, n_tape); /* :46 */
     size_t qd = (size_t)1 << lqd;
     if (lqd > cfg->log_blowup) return -2; /* two_adic_pcs.rs:256 */

@@ -97,7 +97,7 @@ def run_timed(env: DistEnv, step: Callable[[int], None], steps: int, warmup: int
             for i in range(first, first + count):
                 step(i)
     run_steps(0, warmup)
-    windows = []
+    windows, marks = [], []
     for k in range(1 + max(0, extra_windows)):
         env.barrier(local_sync)
         t0 = time.perf_counter()
@@ -106,12 +106,14 @@ def run_timed(env: DistEnv, step: Callable[[int], None], steps: int, warmup: int
             print(f"[bench t={time.monotonic() * 1e3:.3f} ms] timed window {k} starts", file=sys.stderr, flush=True)
         run_steps(warmup + k * steps, steps)
         env.barrier(local_sync)
-        windows.append(env.max_over_ranks(time.perf_counter() - t0))
+        t1 = time.perf_counter()
+        marks.append((t0, t1))  # this rank's clock (time.perf_counter), for per-window sampler / lane statistics
+        windows.append(env.max_over_ranks(t1 - t0))
     elapsed = windows[0]
     total_units = env.sum_over_ranks(units_per_step * steps)
     return {"elapsed_s": elapsed, "ms_per_step": 1e3 * elapsed / steps,
             "value": total_units / elapsed, "steps_per_sec": env.world * steps / elapsed,
-            "windows_ms_per_step": [1e3 * e / steps for e in windows]}
+            "windows_ms_per_step": [1e3 * e / steps for e in windows], "windows_t": marks}
 
 
 def split_stage_timings(items) -> tuple[dict, list]:
@@ -134,6 +136,100 @@ def split_stage_timings(items) -> tuple[dict, list]:
         table.append({"collective": kind, "what": k, "bytes": nbytes, "count": row["count"],
                       "ms_total": round(row["ms_total"], 3), "ms_max": round(row["ms_max"], 3)})
     return stages, table
+
+
+_SAMPLER_SRC = r"""
+import json, select, sys, time
+import amdsmi
+amdsmi.amdsmi_init()
+h = amdsmi.amdsmi_get_processor_handles()[int(sys.argv[1])]
+period = float(sys.argv[2])
+out = open(sys.argv[3], "w")  # a file, not the pipe: a long run must not block on a full pipe
+sys.stdout.write("ready\n"); sys.stdout.flush()
+while True:
+    if select.select([sys.stdin], [], [], 0)[0]:
+        break  # the parent closed / wrote to our stdin: stop
+    t = time.perf_counter()  # CLOCK_MONOTONIC: the same clock as the parent's perf_counter
+    try:
+        m = amdsmi.amdsmi_get_gpu_metrics_info(h)
+        clks = [c for c in m.get("current_gfxclks", []) if isinstance(c, int) and 0 < c < 10000]
+        out.write(json.dumps({"t": t, "clk": (sum(clks) / len(clks)) if clks else m.get("current_gfxclk"),
+                              "w": m.get("current_socket_power"), "uclk": m.get("current_uclk"),
+                              "temp": m.get("temperature_hotspot")}) + "\n")
+    except Exception as e:
+        out.write(json.dumps({"t": t, "error": repr(e)}) + "\n")
+    rest = period - (time.perf_counter() - t)
+    if rest > 0:
+        time.sleep(rest)
+out.flush()
+"""
+
+
+class GpuSamplerProcess:
+    """The same samples from a CHILD process (amdsmi only, no HIP): usable INSIDE the timed region,
+    because it takes no time from this process's interpreter lock -- a sampler thread here would hold
+    it for a fraction of a millisecond per sample, and the lanes need it between two proofs.  The child
+    stamps samples with time.perf_counter (CLOCK_MONOTONIC, shared by all processes of the machine), so
+    `window(t0, t1)` can cut them by this process's own timestamps."""
+
+    def __init__(self, device_index: int = 0, period_s: float = 0.01):
+        import subprocess
+        import sys
+        import tempfile
+        self.samples, self.error, self._p = [], None, None
+        fd, self._path = tempfile.mkstemp(prefix="ts_smi_", suffix=".jsonl")
+        os.close(fd)
+        try:
+            self._p = subprocess.Popen([sys.executable, "-c", _SAMPLER_SRC, str(device_index), str(period_s), self._path],
+                                       stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                                       text=True)
+            first = self._p.stdout.readline()
+            if first.strip() != "ready":
+                self.error = "sampler child did not start (amdsmi missing?)"
+                self._p.kill()
+                self._p = None
+        except Exception as e:  # noqa: BLE001
+            self.error = repr(e)
+            self._p = None
+
+    def stop(self):
+        import json
+        if self._p is None:
+            return
+        out = ""
+        try:
+            self._p.stdin.close()
+            self._p.wait(timeout=5)
+        except Exception as e:  # noqa: BLE001
+            self.error = repr(e)
+            self._p.kill()
+        self._p = None
+        try:
+            with open(self._path) as f:
+                out = f.read()
+            os.unlink(self._path)
+        except OSError as e:
+            self.error = repr(e)
+        for line in out.splitlines():
+            try:
+                s = json.loads(line)
+            except ValueError:
+                continue
+            if "error" in s:
+                self.error = s["error"]
+            else:
+                self.samples.append(s)
+
+    def window(self, t0: float, t1: float) -> dict:
+        def med(xs):
+            xs = sorted(x for x in xs if isinstance(x, (int, float)))
+            return xs[len(xs) // 2] if xs else None
+        ss = [s for s in self.samples if t0 <= s["t"] <= t1]
+        clk = [s["clk"] for s in ss]
+        return {"samples": len(ss), "gfxclk_mhz_median": med(clk),
+                "gfxclk_mhz_min": min((c for c in clk if isinstance(c, (int, float))), default=None),
+                "socket_power_w_median": med([s["w"] for s in ss]),
+                "hotspot_c_max": max((s["temp"] for s in ss if isinstance(s["temp"], (int, float))), default=None)}
 
 
 class GpuSampler:

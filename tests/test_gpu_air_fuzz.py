@@ -10,7 +10,8 @@ interpreter (csrc/quotient.hip) -- against the oracle's direct evaluation of the
 * check_constraints       vs orc.check_constraints        (check_constraints.rs:11-39)
 * whole proofs (a subset) vs orc.prove, word for word; valid-trace cases also verified
 
-Default: 240 seeds (TS_AIR_FUZZ=<n> for a campaign; the summary goes to gpurun_out/air_fuzz/)."""
+Default: 240 seeds (TS_AIR_FUZZ=<n> [TS_AIR_FUZZ_FIRST=<seed>] for a campaign slice; the summary goes
+to gpurun_out/air_fuzz/)."""
 import json
 import os
 import time
@@ -27,11 +28,23 @@ P = 0x78000001
 N_CASES = int(os.environ.get("TS_AIR_FUZZ", "240"))
 N_CHUNKS = 20
 # background-compiled programs are waited for (and the specialised kernel compared) up to this size
-WAIT_JIT_INSTR = int(os.environ.get("TS_AIR_FUZZ_WAIT_INSTR", "6000"))
+WAIT_JIT_INSTR = int(os.environ.get("TS_AIR_FUZZ_WAIT_INSTR", "3000"))
 SUMMARY = {"cases": 0, "valid_cases": 0, "jit_compared": 0, "interp_compared": 0, "proofs_compared": 0,
            "check_constraints_compared": 0, "background_jit": 0, "jit_not_waited": 0, "mismatches": [],
            "refusals": [], "max_nodes": 0, "max_constraints": 0, "max_regs": 0, "max_instr": 0,
-           "by_degree": {}, "jit_compile_s_max": 0.0, "jit_compile_s_total": 0.0}
+           "by_degree": {}, "jit_compile_s_max": 0.0, "jit_compile_s_total": 0.0, "phase_s": {}}
+FIRST = int(os.environ.get("TS_AIR_FUZZ_FIRST", "0"))  # campaigns are run in slices: seeds FIRST .. FIRST + N
+
+
+class _Phase:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        self.t0 = time.time()
+
+    def __exit__(self, *a):
+        SUMMARY["phase_s"][self.name] = round(SUMMARY["phase_s"].get(self.name, 0.0) + time.time() - self.t0, 3)
 
 
 @pytest.fixture(scope="module")
@@ -50,7 +63,8 @@ def _write_summary():
     SUMMARY["n_requested"] = N_CASES
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "air_fuzz")
     os.makedirs(out, exist_ok=True)
-    with open(os.path.join(out, f"summary_{N_CASES}.json"), "w") as f:
+    SUMMARY["first_seed"] = FIRST
+    with open(os.path.join(out, f"summary_{FIRST}_{N_CASES}.json"), "w") as f:
         json.dump(SUMMARY, f, indent=1)
 
 
@@ -72,19 +86,22 @@ def _check_chunks(pcs, data, cair, pis, alpha, want, what, seed):
 
 
 def run_case(ctx, orc, monkeypatch, seed: int):
-    air, log_n = random_air_case(seed)
-    n = 1 << log_n
-    tape = ts.air_tape(air, air.n_public)
-    n_nodes, n_cons = int(tape[4]), int(tape[5])
-    if air.valid:
-        trace, pis, _ = generate_random_air_trace(air, n)
-    else:
-        trace = splitmix64_stream(seed + 1, n * air.width()).reshape(n, air.width())
-        pis = splitmix64_stream(seed + 2, max(air.n_public, 1))[:air.n_public]
+    with _Phase("generate"):
+        air, log_n = random_air_case(seed)
+        n = 1 << log_n
+        tape = ts.air_tape(air, air.n_public)
+        n_nodes, n_cons = int(tape[4]), int(tape[5])
+        if air.valid:
+            trace, pis, _ = generate_random_air_trace(air, n)
+        else:
+            trace = splitmix64_stream(seed + 1, n * air.width()).reshape(n, air.width())
+            pis = splitmix64_stream(seed + 2, max(air.n_public, 1))[:air.n_public]
     t0 = time.time()
-    cair = _compile(ctx, tape, monkeypatch, True)
+    with _Phase("ts_air_compile(jit)"):
+        cair = _compile(ctx, tape, monkeypatch, True)
     dt = time.time() - t0
-    interp = _compile(ctx, tape, monkeypatch, False)
+    with _Phase("ts_air_compile(interp)"):
+        interp = _compile(ctx, tape, monkeypatch, False)
     assert not interp.is_jit
     prog = cair.program()
     S = SUMMARY
@@ -102,15 +119,18 @@ def run_case(ctx, orc, monkeypatch, seed: int):
     pcs = ts.TwoAdicFriPcs(ts.FriConfig(b, 3, 2), ctx)
     _, data = pcs.commit([((log_n, 1), trace.copy())])
     alpha = splitmix64_stream(seed + 3, 4)
-    lde = orc.commit_lde(trace, 1, b)
-    want = orc.split_quotient(orc.quotient_values(tape, lde, log_n, b, pis, alpha), log_n, lqd)
-    _check_chunks(pcs, data, interp, pis, alpha, want, "interp", seed)
+    with _Phase("oracle quotient"):
+        lde = orc.commit_lde(trace, 1, b)
+        want = orc.split_quotient(orc.quotient_values(tape, lde, log_n, b, pis, alpha), log_n, lqd)
+    with _Phase("gpu quotient"):
+        _check_chunks(pcs, data, interp, pis, alpha, want, "interp", seed)
     S["interp_compared"] += 1
     background = not cair.is_jit
     if background:
         S["background_jit"] += 1
         if len(prog["code"]) <= WAIT_JIT_INSTR:
-            state, secs = cair.jit_wait()
+            with _Phase("jit_wait"):
+                state, secs = cair.jit_wait()
             assert state == 3 and cair.is_jit, f"seed {seed}: background specialisation failed (state {state})"
             dt = secs
         else:
@@ -118,24 +138,28 @@ def run_case(ctx, orc, monkeypatch, seed: int):
     if cair.is_jit:
         S["jit_compile_s_max"] = max(S["jit_compile_s_max"], round(dt, 2))
         S["jit_compile_s_total"] = round(S["jit_compile_s_total"] + dt, 2)
-        _check_chunks(pcs, data, cair, pis, alpha, want, "jit", seed)
+        with _Phase("gpu quotient"):
+            _check_chunks(pcs, data, cair, pis, alpha, want, "jit", seed)
         S["jit_compared"] += 1
     # check_constraints: the trace as it is, and with one cell changed
-    got = ts.check_constraints(interp, trace, pis, ctx)
-    assert got == orc.check_constraints(tape, trace, pis), seed
-    if air.valid:
-        assert got == -1, seed
-    bad = trace.copy()
-    bad[(seed * 7) % n, seed % air.width()] ^= 1
-    assert ts.check_constraints(interp, bad, pis, ctx) == orc.check_constraints(tape, bad, pis), seed
+    with _Phase("check_constraints"):
+        got = ts.check_constraints(interp, trace, pis, ctx)
+        assert got == orc.check_constraints(tape, trace, pis), seed
+        if air.valid:
+            assert got == -1, seed
+        bad = trace.copy()
+        bad[(seed * 7) % n, seed % air.width()] ^= 1
+        assert ts.check_constraints(interp, bad, pis, ctx) == orc.check_constraints(tape, bad, pis), seed
     S["check_constraints_compared"] += 2
     # whole proofs
     if seed % 4 == 0 or air.valid and seed % 2 == 0:
         cfg = (b, 3, 2)
         config = ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(*cfg), ctx))
+        with _Phase("oracle prove"):
+            ref = orc.prove(orc.FriConfig(*cfg), tape, trace, pis, debug_assertions=air.valid)
         for which in (cair, interp):
-            proof = ts.prove(config, which, ts.BfChallenger(), trace.copy(), pis)
-            ref = orc.prove(orc.FriConfig(*cfg), tape, trace, pis)
+            with _Phase("gpu prove"):
+                proof = ts.prove(config, which, ts.BfChallenger(), trace.copy(), pis)
             assert len(ref) == len(proof.words) and (ref == proof.words).all(), f"seed {seed}: proof differs"
             S["proofs_compared"] += 1
         rc = orc.verify(orc.FriConfig(*cfg), tape, proof.words, pis)
@@ -148,7 +172,7 @@ def run_case(ctx, orc, monkeypatch, seed: int):
 def test_random_airs(ctx, orc, monkeypatch, chunk):
     per = (N_CASES + N_CHUNKS - 1) // N_CHUNKS
     for seed in range(chunk * per, min((chunk + 1) * per, N_CASES)):
-        run_case(ctx, orc, monkeypatch, seed)
+        run_case(ctx, orc, monkeypatch, FIRST + seed)
 
 
 def _resources(code: bytes) -> dict:
@@ -202,10 +226,10 @@ def test_large_tape(ctx, orc, monkeypatch):
     rec["interp_quotient_s"] = round(time.time() - t0, 4)
     assert ts.check_constraints(cair, trace, pis, ctx) == orc.check_constraints(tape, trace, pis)
     config = ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(b, 3, 2), ctx))
-    ref = orc.prove(orc.FriConfig(b, 3, 2), tape, trace, pis)
+    ref = orc.prove(orc.FriConfig(b, 3, 2), tape, trace, pis, debug_assertions=False)
     proof = ts.prove(config, cair, ts.BfChallenger(), trace.copy(), pis)
     assert (ref == proof.words).all()
-    if os.environ.get("TS_AIR_FUZZ_LARGE_JIT", "1") != "0":
+    if os.environ.get("TS_AIR_FUZZ_LARGE_JIT", "0") != "0":  # ~60 s of hiprtc: campaign runs only
         state, secs = cair.jit_wait()
         rec["jit_state"], rec["hiprtc_compile_s"] = state, round(secs, 1)
         assert state == 3 and cair.is_jit
@@ -214,7 +238,7 @@ def test_large_tape(ctx, orc, monkeypatch):
         rec["jit_quotient_s"] = round(time.time() - t0, 4)
         proof = ts.prove(config, cair, ts.BfChallenger(), trace.copy(), pis)
         assert (ref == proof.words).all()
-        code, _ = None, None
+        rec["jit_kernel"] = _resources(cair.jit_compile()[0]) if os.environ.get("TS_AIR_FUZZ_LARGE_RES") else None
     SUMMARY["large_tape"] = rec
 
 

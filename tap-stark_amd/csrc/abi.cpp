@@ -4,8 +4,9 @@
 #include <string.h>
 
 #include <algorithm>
-#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 #include <memory>
 #include <string>
@@ -22,46 +23,80 @@
 //                                               ready, the next use loads it; ts_air_jit_wait joins;
 //   larger                                      interpreter only.
 // Both kernels compute the same words, so which one ran never shows in a proof.
+// A background compilation outlives the ts_air that asked for it (hiprtc cannot be interrupted, and
+// ts_air_free must not wait a minute for it): the job is shared between the worker thread and the AIR;
+// workers still running when the library is unloaded are joined then (they are inside libhiprtc).
+struct JitJob {
+    std::string src, arch, log;
+    std::vector<char> code;
+    double seconds = 0;
+    bool done = false, ok = false;
+    std::mutex m;
+    std::condition_variable cv;
+};
+struct JitWorkers {
+    std::mutex m;
+    std::vector<std::thread> threads;
+    void start(std::shared_ptr<JitJob> job) {
+        std::lock_guard<std::mutex> g(m);
+        threads.emplace_back([job] {
+            const auto t0 = std::chrono::steady_clock::now();
+            std::vector<char> code;
+            std::string log;
+            const bool ok = ts::jit_compile_source(job->src, job->arch.c_str(), code, log);
+            std::lock_guard<std::mutex> g2(job->m);
+            job->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            job->code = std::move(code);
+            job->log = std::move(log);
+            job->ok = ok;
+            job->done = true;
+            job->cv.notify_all();
+        });
+    }
+    ~JitWorkers() {
+        for (auto& t : threads)
+            if (t.joinable()) t.join();
+    }
+};
+static JitWorkers g_jit_workers;
+
 struct ts_air {
     ts::AirProgram prog;
     ts::DevBuf<uint32_t> code;
     std::string jit_log;
     int device = -1;  // the device the jit module was loaded on (-1: host-only AIR)
-    enum { JIT_NONE = 0, JIT_COMPILING = 1, JIT_CODE_READY = 2, JIT_LOADED = 3, JIT_FAILED = 4 };
-    std::atomic<int> jit_state{JIT_NONE};
-    std::thread jit_thread;
-    std::vector<char> jit_code;
+    enum { JIT_NONE = 0, JIT_COMPILING = 1, JIT_LOADED = 3, JIT_FAILED = 4 };
+    int jit_state = JIT_NONE;
+    std::shared_ptr<JitJob> job;
     double jit_seconds = 0;
     std::string arch;
     void start_background_jit() {
+        job = std::make_shared<JitJob>();
+        job->src = ts::jit_quotient_source(prog);
+        job->arch = arch;
         jit_state = JIT_COMPILING;
-        jit_thread = std::thread([this] {
-            const auto t0 = std::chrono::steady_clock::now();
-            std::string log;
-            const bool ok = ts::jit_compile_code(prog, arch.c_str(), jit_code, log);
-            jit_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            if (!ok) jit_log = log;
-            jit_state = ok ? JIT_CODE_READY : JIT_FAILED;
-        });
+        g_jit_workers.start(job);
     }
     // called on the thread that drives the context (device current): adopt a finished compilation
     void poll_jit(bool wait) {
-        if (wait && jit_thread.joinable()) jit_thread.join();
-        if (jit_state.load() != JIT_CODE_READY) return;
-        if (jit_thread.joinable()) jit_thread.join();
+        if (!job) return;
+        std::unique_lock<std::mutex> lk(job->m);
+        if (wait) job->cv.wait(lk, [&] { return job->done; });
+        if (!job->done) return;
+        jit_seconds = job->seconds;
         ts::JitKernel jk;
-        if (ts::jit_load_code(jit_code, jk, jit_log)) {
+        if (job->ok && ts::jit_load_code(job->code, jk, job->log)) {
             prog.jit_module = jk.module;
             prog.jit_fn = jk.fn;
             jit_state = JIT_LOADED;
         } else {
+            jit_log = job->log;
             jit_state = JIT_FAILED;
         }
-        jit_code.clear();
-        jit_code.shrink_to_fit();
+        lk.unlock();
+        job.reset();
     }
     ~ts_air() {
-        if (jit_thread.joinable()) jit_thread.join();
         if (device >= 0 && prog.jit_module) (void)hipSetDevice(device);
         ts::JitKernel jk;
         jk.module = prog.jit_module;
@@ -511,7 +546,7 @@ ts_status ts_air_compile(ts_ctx* ctx, const uint32_t* tape, size_t n_words, ts_a
 }
 int ts_air_is_jit(const ts_air* air) {
     if (!air) return 0;
-    if (air->device >= 0 && air->jit_state.load() == ts_air::JIT_CODE_READY) {
+    if (air->device >= 0 && air->job) {
         (void)hipSetDevice(air->device);
         const_cast<ts_air*>(air)->poll_jit(false);
     }
@@ -521,7 +556,7 @@ ts_status ts_air_jit_wait(ts_ctx* ctx, ts_air* air, int* state, double* compile_
     if (!ctx || !air) return TS_ERR_INVALID;
     return guard(ctx, [&] {
         air->poll_jit(true);
-        if (state) *state = air->jit_state.load();
+        if (state) *state = air->jit_state;
         if (compile_seconds) *compile_seconds = air->jit_seconds;
     });
 }

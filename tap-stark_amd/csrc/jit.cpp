@@ -144,12 +144,15 @@ std::string jit_quotient_source(const AirProgram& air) {
 }
 
 bool jit_compile_code(const AirProgram& air, const char* arch, std::vector<char>& code, std::string& log) {
+    return jit_compile_source(jit_quotient_source(air), arch, code, log);
+}
+
+bool jit_compile_source(const std::string& src, const char* arch, std::vector<char>& code, std::string& log) {
     Rtc& r = rtc();
     if (!r.ok) {
         log = "libhiprtc not available";
         return false;
     }
-    const std::string src = jit_quotient_source(air);
     if (const char* dump = getenv("TS_JIT_DUMP")) {  // the generated source, for offline inspection (hipcc -S)
         if (FILE* f = fopen(dump, "w")) {
             fwrite(src.data(), 1, src.size(), f);

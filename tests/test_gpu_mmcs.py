@@ -180,5 +180,6 @@ def test_stage_bench_and_context_counters(ctx):
     st = ctx.graph_stats()
     assert [ctx.stat(i) for i in range(4)] == [st["replays"], st["fallbacks"], st["shapes"], st["pool_bytes"]]
     assert ctx.stat(4) == st["reserve_failures"] and ctx.stat(5) >= 0
+    assert ctx.stat(7) == 0  # proof-of-work candidates of the device search refused by the host: never
     with pytest.raises(TsError):
-        ctx.stat(6)
+        ctx.stat(9)

@@ -65,6 +65,12 @@ def wall_budget() -> dict:
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# Protocol dry-run on a CPU (tests/test_bench_dist_cpu.py): TS_BENCH_STUB_LIB names a directory holding a
+# stand-in `tapstark_amd` package (tests/stub_lib: objects that sleep); everything else in this file runs
+# as it will on the node.  The record says so in `data` and `stub_lib`; no number in it is a measurement.
+STUB_LIB = os.environ.get("TS_BENCH_STUB_LIB")
+if STUB_LIB:
+    sys.path.insert(0, os.path.abspath(STUB_LIB))
 
 HBM_PEAK = 8.0e12  # B/s, /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
 
@@ -480,7 +486,8 @@ def sharded_block(name: str, ts, env, ctx, dev, watchdog: Watchdog | None, state
                 gr = dist.new_group(list(range(gi * gsize, (gi + 1) * gsize)))
                 if env.rank // gsize == gi:
                     group = gr
-        use_native = os.environ.get("TS_BENCH_COMM", "rccl") == "rccl" and dist.get_backend() == "nccl"
+        # (the stub library's dry-run takes the native branch too: its RcclComm checks the id hand-out)
+        use_native = os.environ.get("TS_BENCH_COMM", "rccl") == "rccl" and (dist.get_backend() == "nccl" or bool(STUB_LIB))
         if use_native:
             from tapstark_amd import comm as tcomm
             ids = [None] * world
@@ -666,7 +673,7 @@ def main():
     import numpy as np
     import torch
 
-    if not share_gpu:
+    if not share_gpu and not STUB_LIB:
         local_world = int(os.environ.get("LOCAL_WORLD_SIZE", env.world))
         have = torch.cuda.device_count()
         if have < local_world or env.local_rank >= have:
@@ -674,9 +681,9 @@ def main():
                              "(TS_BENCH_SHARE_GPU=1 puts every rank on GPU 0 for a rehearsal)")
 
     import tapstark_amd as ts
-    from tapstark_amd.build import build
 
     if not os.path.exists(ts._lib.LIB_PATH):  # normally built by __graft_entry__.build() beforehand
+        from tapstark_amd.build import build
         if env.rank == 0:
             build()
         if env.dist is not None:
@@ -974,9 +981,12 @@ def main():
             "scaling": ("strong" if n_groups == 1 else "strong within a group, weak across groups")
                        if sharded else "weak", "vs_baseline": None,
             "dtype": "u32",  # BabyBear arithmetic on u32 lanes (64-bit intermediates)
-            "data": ("synthetic (trace uploaded from host memory INSIDE the timed region: PCIe-inclusive)"
+            "data": ("STUB LIBRARY (TS_BENCH_STUB_LIB): protocol dry-run on a CPU, no prover ran, no number is a measurement"
+                     if STUB_LIB else
+                     "synthetic (trace uploaded from host memory INSIDE the timed region: PCIe-inclusive)"
                      if args.host_traces else
                      "synthetic (trace generated on the device, resident in HBM before the timed region)"),
+            "stub_lib": bool(STUB_LIB),
             "config": {"workload": desc, "rows": n, "width": w, "log_blowup": cfg[0],
                        "num_queries": cfg[1], "proof_of_work_bits": cfg[2], "quotient_degree": qd,
                        "parallelism": (f"{n_groups} group(s) of {gsize} GPU(s), one proof sharded over each group, "

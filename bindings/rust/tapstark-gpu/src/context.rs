@@ -12,7 +12,7 @@ unsafe impl Send for GpuContext {}
 
 impl GpuContext {
     pub fn new(device: i32) -> Self {
-        assert_eq!(unsafe { ts_abi_version() }, 4, "libtapstark_hip ABI version");
+        assert_eq!(unsafe { ts_abi_version() }, 5, "libtapstark_hip ABI version");
         let mut raw = ptr::null_mut();
         let rc = unsafe { ts_ctx_create(device, &mut raw) };
         assert_eq!(rc, TS_OK, "ts_ctx_create({device}) failed: {}", last_error(ptr::null()));

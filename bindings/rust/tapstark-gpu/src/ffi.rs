@@ -1,4 +1,4 @@
-//! `extern "C"` declarations of include/tapstark.h (ABI version 4).  One line per entry point the
+//! `extern "C"` declarations of include/tapstark.h (ABI version 5).  One line per entry point the
 //! Rust side uses; the header is the authority for argument meaning.
 #![allow(non_camel_case_types)]
 use core::ffi::{c_char, c_int, c_uint, c_void};
@@ -34,9 +34,9 @@ pub struct ts_comm {
 #[repr(C)]
 #[derive(Clone, Copy, Default)]
 pub struct ts_shard_options {
+    pub struct_size: u32, // = size_of::<ts_shard_options>() (the library refuses any other layout)
     pub min_local_log: u32,
     pub trace_replicated: u32,
-    pub column_sharded_inverse: u32, // ignored since round 5 (kept for layout)
     pub local_quotient: u32,
 }
 
@@ -80,6 +80,9 @@ extern "C" {
     pub fn ts_air_info(air: *const ts_air, width: *mut u32, n_public: *mut u32, max_degree: *mut u32,
                        log_quotient_degree: *mut u32) -> ts_status;
     pub fn ts_air_free(ctx: *mut ts_ctx, air: *mut ts_air);
+    pub fn ts_air_is_jit(air: *const ts_air) -> c_int;
+    pub fn ts_air_jit_wait(ctx: *mut ts_ctx, air: *mut ts_air, state: *mut c_int, compile_seconds: *mut f64) -> ts_status;
+    pub fn ts_air_program(air: *const ts_air, out: *mut u32, cap_words: usize, n_words: *mut usize) -> ts_status;
 
     pub fn ts_pcs_commit(ctx: *mut ts_ctx, cfg: *const ts_fri_config, n_mats: u32,
                          evals: *const *mut ts_matrix, domain_shifts: *const u32, root_out: *mut u32,

@@ -2,7 +2,7 @@
 //!
 //! **Uncompiled in this repository's pipeline** (no Rust toolchain in the build image; see
 //! Cargo.toml).  Written against tap-stark at the commit SURVEY.md names and include/tapstark.h
-//! ABI version 4.  The tested callers of the same C ABI are the ctypes binding
+//! ABI version 5.  The tested callers of the same C ABI are the ctypes binding
 //! (tap-stark_amd/stark.py) and examples/fib_air.cpp.
 //!
 //! ```ignore

@@ -140,6 +140,7 @@ int main(int argc, char** argv) {
             if (use_rccl && ts_comm_rccl_create(ctx, uid, r, G, &comm, &rc) != TS_OK) return fail("communicator");
             ts_shard_options opt;
             memset(&opt, 0, sizeof opt);
+            opt.struct_size = sizeof opt;
             opt.trace_replicated = 1;
             opt.local_quotient = localq ? 1 : 0;
             std::vector<uint32_t> out(1u << 22);

@@ -329,14 +329,12 @@ ts_status ts_comm_local_group_set_timeout(ts_comm_group* group, int seconds);
  * is bit-identical to ts_prove's on the whole trace.  FRI rounds stay sharded while a rank holds
  * >= 2^min_local_log values. */
 typedef struct {
+    uint32_t struct_size;      /* = sizeof(ts_shard_options): a caller built against another layout of this
+                                  struct (ABI 4 had a field here that did nothing) is refused with
+                                  TS_ERR_INVALID instead of having its fields read as something else */
     uint32_t min_local_log;    /* 0 = default (12) */
     uint32_t trace_replicated; /* 1: `trace_rows` is the WHOLE trace on every rank (e.g. made by
                                   ts_trace_* on each device); the trace all-gather is skipped */
-    uint32_t column_sharded_inverse; /* ignored since round 5 (kept for layout): the option -- the
-                                  per-column part of the inverse NTT on w/G columns per rank + an
-                                  all-gather of the half-transformed columns, SURVEY.md section 8(e)
-                                  steps 1-2 -- cost more in bulk all-gathers than it saved; the inverse
-                                  transform is replicated on every rank.  The proof never depended on it. */
     uint32_t local_quotient;   /* 1: every rank evaluates the quotient (uni-stark/src/prover.rs:65-80) on
                                   its OWN cosets and derives its slab of the chunk LDEs from that: no rank
                                   waits for the owner of the quotient domain, no chunk broadcast.  Needs

@@ -74,8 +74,8 @@ class RcclInfoC(C.Structure):
 
 class ShardOptionsC(C.Structure):
     """``ts_shard_options`` (include/tapstark.h)."""
-    _fields_ = [("min_local_log", C.c_uint32), ("trace_replicated", C.c_uint32),
-                ("column_sharded_inverse", C.c_uint32), ("local_quotient", C.c_uint32)]
+    _fields_ = [("struct_size", C.c_uint32), ("min_local_log", C.c_uint32), ("trace_replicated", C.c_uint32),
+                ("local_quotient", C.c_uint32)]
 
 
 _lib = None

@@ -230,7 +230,7 @@ ts_status ts_proof_from_postcard_v(const uint8_t* bytes, size_t n_bytes, int tsp
     });
 }
 
-uint32_t ts_abi_version(void) { return 4; }  // 4: ts_rccl_info.checked (struct grew), ts_ctx_graph_stats
+uint32_t ts_abi_version(void) { return 5; }  // 5: ts_shard_options (struct_size first, the dead column_sharded_inverse gone), ts_air_program / _jit_*
 
 int ts_device_count(void) {
     int n = 0;
@@ -955,6 +955,9 @@ ts_status ts_prove_sharded(ts_ctx* ctx, const ts_fri_config* cfg, const ts_comm*
         const ts_comm cb = *comm;
         ts::Comm c = wrap_comm(cb);
         ts::ShardOptions opt;
+        if (options)
+            TS_REQUIRE(options->struct_size == sizeof(ts_shard_options), ts::TS_ERR_INVALID,
+                       "ts_shard_options.struct_size != sizeof(ts_shard_options): caller built against another ABI");
         if (options && options->min_local_log) {
             TS_REQUIRE(options->min_local_log <= 27, ts::TS_ERR_INVALID, "min_local_log > 27");
             opt.min_local_log = options->min_local_log;

@@ -778,7 +778,7 @@ def prove_sharded(config: StarkConfig, air, challenger: BfChallenger, trace_rows
     n_words = C.c_size_t()
     cfg = pcs.fri._c()
     pis_p = _p(pis) if len(pis) else None
-    opts = _lib.ShardOptionsC(min_local_log, int(trace_replicated), 0,
+    opts = _lib.ShardOptionsC(C.sizeof(_lib.ShardOptionsC), min_local_log, int(trace_replicated),
                               int(local_quotient))
     rc = ctx._l.ts_prove_sharded(ctx.h, C.byref(cfg), C.byref(comm.c), air.h, challenger.h,
                                  trace_rows.h, pis_p, len(pis), C.byref(opts), _p(out), cap,

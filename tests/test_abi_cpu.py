@@ -29,7 +29,7 @@ def test_header_symbols_all_exported(lib):
     assert declared == set(_lib.ABI_SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.ts_abi_version() == 4
+    assert lib.ts_abi_version() == 5
 
 
 def test_device_count_and_null_context_diagnostics(lib):

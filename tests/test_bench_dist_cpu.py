@@ -217,3 +217,86 @@ def test_watchdog_fires_on_its_thread_and_names_the_phase():
     body = src[src.index("def on_timeout(phase):"):src.index("env.dist.barrier()  # rank 0 comes here later")]
     assert "os._exit(3)" in body and "os._exit(0)" not in body
     assert "except BaseException" not in src[src.index("# ---- N > 1: BASELINE configs 4 and 5"):]
+
+
+# ------------------------------------------------------------------ dry-run of the 8-GPU lease on a CPU
+def _run_bench_stub_lib(args, extra_env=None, timeout=600, launcher=None):
+    """bench.py's REAL path (lanes, gate, priming, windows, record, rank-0 legs, sharded blocks) against
+    tests/stub_lib (objects that sleep), gloo for the barrier / reductions."""
+    env = dict(os.environ, TS_BENCH_STUB_LIB=os.path.join(ROOT, "tests", "stub_lib"), TS_BENCH_BACKEND="gloo",
+               TS_BENCH_LIVE_PMC="0", TS_BENCH_PRIME_S="0.2", TS_STUB_STEP_S="0.003", TS_BENCH_SHARD_STEPS="2",
+               TS_BENCH_SAMPLER="0", **(extra_env or {}))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR", "LOCAL_WORLD_SIZE", "TS_BENCH_STUB"):
+        env.pop(k, None)
+    cmd = (launcher or [sys.executable]) + [os.path.join(ROOT, "bench.py"), *args]
+    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def _check_contract_line(rec, n_gpus, steps):
+    import math
+
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "windows_ms_per_step", "windows", "priming"):
+        assert key in rec, key
+    assert rec["n_gpus"] == n_gpus and rec["steps"] == steps and rec["scaling"] == "weak"
+    assert rec["unit"] == "trace cells/sec" and rec["dtype"] == "u32" and rec["vs_baseline"] is None
+    assert rec["stub_lib"] is True and "STUB LIBRARY" in rec["data"]
+    assert "model" not in rec["config"] and rec["config"]["rows"] == 1 << 20 and rec["config"]["width"] == 64
+    # value = the cells ALL ranks proved / the slowest rank's time; ms_per_step is that time / K
+    cells = n_gpus * steps * float((1 << 20) * 64)
+    assert math.isclose(rec["value"], cells / (rec["ms_per_step"] * steps * 1e-3), rel_tol=1e-9)
+    assert math.isclose(rec["proofs_per_sec"], n_gpus * steps / (rec["ms_per_step"] * steps * 1e-3), rel_tol=1e-9)
+    assert math.isclose(rec["windows_ms_per_step"][0], rec["ms_per_step"], rel_tol=1e-3)
+    assert len(rec["windows"]) == len(rec["windows_ms_per_step"]) == 3
+    assert rec["priming"]["probes_ms_per_step"], "the priming probes are on the record"
+
+
+def test_dry_run_of_the_eight_gpu_lease():
+    """`python -m torch.distributed.run --nproc-per-node 8 bench.py --gpus 8 ...` (the driver's line) with the
+    stub library: the record rank 0 prints is the one the driver will parse -- n_gpus 8, value = sum of
+    cells / max time -- and both sharded blocks ran over ONE group of 8 through the native-communicator
+    branch (unique id made by rank 0, handed round, every rank's group checked)."""
+    import json
+
+    port = _free_port()
+    r = _run_bench_stub_lib(["--gpus", "8", "--steps", "8", "--warmup", "4"],
+                            launcher=[sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node",
+                                      "8", "--master-addr", "127.0.0.1", "--master-port", str(port)], timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line, from rank 0"
+    rec = json.loads(lines[0])
+    _check_contract_line(rec, 8, 8)
+    assert rec["extra"]["self_launched"] is False
+    for blk, w in (("sharded_config4", 64), ("sharded_config5", 163)):
+        b = rec[blk]
+        assert "error" not in b, b
+        assert b["group_size"] == 8 and b["n_groups"] == 1 and b["n_ranks_seen_by_rccl"] == 8
+        assert set(b["variants"]) == {"replicated", "localq"} and b["all_variants_same_proof"] is True
+        for v in b["variants"].values():
+            assert v["all_ranks_same_proof"] is True and len(v["shard_stages_ms_per_rank"]) == 8
+            assert v["collectives_count"] >= 1 and len(v["collectives_ms_total_per_rank"]) == 8
+    assert rec["wall_budget"]["elapsed_total_s"] < rec["wall_budget"]["limit_s"]
+
+
+def test_dry_run_scale_n1_equals_bench_n1():
+    """The driver's SCALE series starts at N = 1 with the same command as BENCH: the same line (metric,
+    config, the rank-0 legs with roofline and cpu_baseline keys) whether launched plainly or as a
+    one-rank torch.distributed.run job."""
+    import json
+
+    plain = _run_bench_stub_lib(["--gpus", "1", "--steps", "8", "--warmup", "4", "--no-cpu-baseline"])
+    assert plain.returncode == 0, plain.stderr[-3000:]
+    a = json.loads([l for l in plain.stdout.splitlines() if l.startswith("{")][-1])
+    port = _free_port()
+    tr = _run_bench_stub_lib(["--gpus", "1", "--steps", "8", "--warmup", "4", "--no-cpu-baseline"],
+                             launcher=[sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node",
+                                       "1", "--master-addr", "127.0.0.1", "--master-port", str(port)])
+    assert tr.returncode == 0, tr.stderr[-3000:]
+    b = json.loads([l for l in tr.stdout.splitlines() if l.startswith("{")][-1])
+    for rec in (a, b):
+        _check_contract_line(rec, 1, 8)
+        assert rec["roofline"]["bound"] == "hbm" and "frac" in rec["roofline"] and "traffic" in rec["roofline"]
+        assert "cpu_baseline" in rec and "stages_ms" in rec and rec["single_proof_latency_ms"] > 0
+    strip = lambda c: {k: v for k, v in c.items() if k != "parallelism"}  # (it quotes the measured start spacing)
+    assert a["metric"] == b["metric"] and strip(a["config"]) == strip(b["config"]) and set(a) == set(b)

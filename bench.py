@@ -651,6 +651,9 @@ def main():
         sys.stdout.flush()
         if isinstance(record, dict) and "wall_budget" not in record:
             record["wall_budget"] = wall_budget()
+        if isinstance(record, dict) and "headline_windows" in record:
+            # the driver's record keeps the END of this line verbatim: the per-window table goes last
+            record["headline_windows"] = record.pop("headline_windows")
         os.write(real_stdout, (json.dumps(record) + "\n").encode())
 
     if stub:
@@ -977,6 +980,15 @@ def main():
             # host-side gaps of each; `priming`: the untimed probes run before the warm-up steps
             "windows_ms_per_step": [round(x, 4) for x in wins],
             "windows": per_window, "priming": dict(primed),
+            "headline_windows": {
+                "ms_per_step": [round(x, 4) for x in wins],
+                "gfxclk_mhz_median": [r_.get("gfxclk_mhz_median") for r_ in per_window],
+                "socket_power_w_median": [r_.get("socket_power_w_median") for r_ in per_window],
+                "longest_host_gap_ms": [r_.get("longest_host_gap_ms") for r_ in per_window],
+                "priming_probes_ms_per_step": primed.get("probes_ms_per_step"), "priming_s": primed.get("s"),
+                "note": "every timed window of K steps (value = the first); clock / power from an amdsmi child "
+                        "process during the window; host gap = longest pause between a ts_prove returning and "
+                        "the next call on one lane; the sustained 160-step leg is clocks.prover_sustained"},
             "higher_is_better": True,
             "scaling": ("strong" if n_groups == 1 else "strong within a group, weak across groups")
                        if sharded else "weak", "vs_baseline": None,
@@ -1019,6 +1031,13 @@ def main():
         # the two fields VERDICT r3 asked for, at the top level of the line
         out["proof_blake3"] = cb.get("gpu_proof_blake3")
         out["matches_oracle"] = cb.get("matches_oracle")
+        try:
+            ps_ = out["clocks"]["prover_sustained"]
+            out["headline_windows"]["sustained_leg"] = {"steps": ps_["steps"], "ms_per_step": ps_["ms_per_step"],
+                                                        "gfxclk_mhz_median": ps_["gfxclk_mhz_median"],
+                                                        "socket_power_w_median": ps_["socket_power_w_median"]}
+        except Exception:  # noqa: BLE001
+            pass
     phase_done("rank-0 legs (kernel timers, latency, h2d, clocks, cpu_baseline)")
 
     # ---- N > 1: BASELINE configs 4 and 5 as one sharded proof each, in the same lease

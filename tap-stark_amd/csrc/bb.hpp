@@ -50,13 +50,15 @@ TS_HD uint32_t mulhi32(uint32_t a, uint32_t b) {
 }
 
 // Montgomery reduction of t < p * 2^32: returns t * 2^-32 mod p in [0, p).
-// (Measured on gfx950, tools/microbench*.hip: every 3-operand VOP3 integer op -- v_mul_lo_u32,
-// v_mul_hi_u32, v_mad_u64_u32, v_lshl_add_u32, v_alignbit_b32 -- costs ~2.5 issue slots against 1
-// for a VOP2 add/sub/min, so one v_mul_lo_u32 beats the two shift-adds that p^-1 = 2^31+2^27+1
-// would allow.)
+// (Measured on gfx950 with the SQ counters, profiles/r02_alu_loops_sq.txt: in register-resident loops of
+// this very code SQ_ACTIVE_INST_VALU equals SQ_INSTS_VALU quad-cycles, i.e. EVERY integer VALU
+// instruction -- VOP2 add/sub/min and VOP3 v_mul_lo_u32 / v_mul_hi_u32 / v_mad_u64_u32 alike -- holds
+// its SIMD for one 4-cycle issue slot.  The cost of a formulation is therefore its instruction COUNT;
+// an earlier note here priced VOP3 ops at ~2.5 slots from wall-clock microbenchmarks, which the
+// counters refuted.)
 // Additive form: m = -t p^-1 mod 2^32 makes t + m p divisible by 2^32; the quotient is < 2p, so one
 // sub + min finishes.  On the device that is v_mul_lo_u32, v_mad_u64_u32 (product and 64-bit add in
-// one instruction), v_sub, v_min: one VOP2 op fewer than the subtractive form (mul_lo, mul_hi, sub,
+// one instruction), v_sub, v_min: one instruction fewer than the subtractive form (mul_lo, mul_hi, sub,
 // add, min).  t + m p < p 2^32 + 2^32 p < 2^64.
 TS_HD uint32_t mont_reduce(uint64_t t) {
     uint32_t m = (uint32_t)t * P_NEG_INV;

@@ -304,11 +304,14 @@ def cpu_baseline(gpu_proof_words=None) -> dict:
     runs = sorted(timed(trace) for _ in range(3))
     dt = runs[1]
     full_proof = kept["proof"] if log_n == 20 else None
-    # one thread, on 1/16 of the rows (about the same wall time per run)
-    log_n1 = max(log_n - 4, 10)
-    trace1 = generate_synth_mul_trace(1 << log_n1)
+    # one thread, on 1/16 of the rows (about the same wall time per run); TS_BENCH_CPU_ONE_THREAD_FULL=1
+    # runs it ONCE at the full size instead (~2 min: outside the default run's time budget; the record of
+    # such a run is profiles/r06_cpu_one_thread_full.json)
+    one_full = bool(os.environ.get("TS_BENCH_CPU_ONE_THREAD_FULL")) and log_n == 20
+    log_n1 = log_n if one_full else max(log_n - 4, 10)
+    trace1 = trace if one_full else generate_synth_mul_trace(1 << log_n1)
     _omp_set_threads(1)
-    dt1 = min(timed(trace1), timed(trace1))
+    dt1 = timed(trace1) if one_full else min(timed(trace1), timed(trace1))
     _omp_set_threads(cores)
     rec = {"value": (64 << log_n) / dt, "unit": "trace cells/sec", "cores": cores, "kind": "port",
            "sample": f"oracle prove() of SynthMulAir-64 2^{log_n}x64, log_blowup=2, 28 queries"
@@ -319,7 +322,11 @@ def cpu_baseline(gpu_proof_words=None) -> dict:
            "runs_s": [round(r, 3) for r in runs],
            "full_size": log_n == 20,
            "one_thread": {"value": (64 << log_n1) / dt1, "unit": "trace cells/sec", "cores": 1,
-                          "sample": f"the same prover on 2^{log_n1}x64, best of 2 ({dt1:.2f} s), 1 thread"}}
+                          "full_size": log_n1 == 20,
+                          "sample": f"the same prover on 2^{log_n1}x64, "
+                                    + ("one run" if one_full else "best of 2") + f" ({dt1:.2f} s), 1 thread"
+                                    + ("" if log_n1 == 20 else "; NOT the full size: a rate on 1/16 of the rows "
+                                       "(the full-size single-thread run is profiles/r06_cpu_one_thread_full.json)")}}
     if full_proof is not None:
         rec["oracle_proof_blake3"] = orc.blake3(full_proof.tobytes()).hex()
         if gpu_proof_words is not None:

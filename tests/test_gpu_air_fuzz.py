@@ -265,3 +265,63 @@ def test_jit_budget_knobs(ctx, orc, monkeypatch):
         c = ts.CompiledAir(ctx, tape)  # background
         assert c.jit_wait()[0] == 3 and c.is_jit
     assert ts.CompiledAir(ctx, tape).is_jit
+
+
+# ------------------------------------------------------------------ random AIRs through the sharded prover
+def _thread_ranks(G, rank_fn):
+    import threading
+
+    out, errors = [None] * G, [None] * G
+
+    def main(r):
+        try:
+            out[r] = rank_fn(r)
+        except BaseException as e:  # noqa: BLE001
+            errors[r] = e
+
+    threads = [threading.Thread(target=main, args=(r,)) for r in range(G)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert not any(t.is_alive() for t in threads), "a rank is stuck in a collective"
+    for r in range(G):
+        assert errors[r] is None, f"rank {r}: {errors[r]!r}"
+    return out
+
+
+@pytest.mark.parametrize("seed", [0, 3, 6, 9, 12, 15, 18, 21, 24, 27, 1, 4])
+def test_random_airs_sharded(ctx, orc, seed):
+    """The same random AIRs as ONE proof over G thread-ranks (csrc/sharded.cpp): the quotient is then
+    evaluated on row ranges / on each rank's own cosets with their shifts and mixed back
+    (local_quotient), a different consumer of the lowered program.  Valid-trace seeds (multiples of 3)
+    must give ts_prove's = the oracle's proof on both paths; the free-form ones (invalid trace) go
+    through the local path's fall-back."""
+    from tapstark_amd.comm import LocalCommGroup
+
+    air, log_n = random_air_case(seed)
+    log_n = max(log_n, 5)
+    n = 1 << log_n
+    tape = ts.air_tape(air, air.n_public)
+    if air.valid:
+        trace, pis, _ = generate_random_air_trace(air, n)
+    else:
+        trace = splitmix64_stream(seed + 1, n * air.width()).reshape(n, air.width())
+        pis = splitmix64_stream(seed + 2, max(air.n_public, 1))[:air.n_public]
+    lqd = orc.log_quotient_degree(tape)
+    for b, G in ((max(lqd, 1), 2), (max(lqd, 1) + 1, 4)):
+        cfg = (b, 4, 3)
+        want = orc.prove(orc.FriConfig(*cfg), tape, trace, pis, debug_assertions=False)
+        for localq in (False, True):
+            group = LocalCommGroup(G)
+
+            def rank(r):
+                c = ts.Context(0)
+                conf = ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(*cfg), c))
+                rows = np.ascontiguousarray(trace[r * n // G:(r + 1) * n // G])
+                return ts.prove_sharded(conf, ts.CompiledAir(c, tape), ts.BfChallenger(), rows, pis, group.comm(r),
+                                        min_local_log=2, local_quotient=localq).words
+
+            for r, words in enumerate(_thread_ranks(G, rank)):
+                assert len(words) == len(want) and (words == want).all(), \
+                    f"seed {seed} G={G} b={b} localq={localq} rank {r}: proof differs from the oracle's"

@@ -78,14 +78,21 @@ struct ts_air {
         g_jit_workers.start(job);
     }
     // called on the thread that drives the context (device current): adopt a finished compilation
+    std::mutex poll_m;  // two threads proving with one ts_air: the adoption happens once
     void poll_jit(bool wait) {
+        std::lock_guard<std::mutex> pg(poll_m);
         if (!job) return;
         std::unique_lock<std::mutex> lk(job->m);
         if (wait) job->cv.wait(lk, [&] { return job->done; });
         if (!job->done) return;
         jit_seconds = job->seconds;
         ts::JitKernel jk;
-        if (job->ok && ts::jit_load_code(job->code, jk, job->log)) {
+        int cur = -1;
+        (void)hipGetDevice(&cur);
+        if (device >= 0 && cur != device) (void)hipSetDevice(device);  // the module belongs to the AIR's device
+        const bool loaded = job->ok && ts::jit_load_code(job->code, jk, job->log);
+        if (device >= 0 && cur >= 0 && cur != device) (void)hipSetDevice(cur);
+        if (loaded) {
             prog.jit_module = jk.module;
             prog.jit_fn = jk.fn;
             jit_state = JIT_LOADED;

@@ -118,14 +118,19 @@ static RegFilePlan plan_reg_file(Context& ctx, uint32_t n_regs, uint64_t rows) {
     pl.nthreads = 256;
     while (pl.nthreads > 64 && (size_t)n_regs * pl.nthreads * 4 > 48 * 1024) pl.nthreads >>= 1;
     pl.lds_bytes = (size_t)n_regs * pl.nthreads * 4;
-    pl.global = pl.lds_bytes > ctx.max_lds_per_block || getenv("TS_INTERP_GLOBAL_REGS") != nullptr;
+    // LDS only while a 256-lane workgroup's file stays small (several workgroups per CU); beyond that the
+    // global slab is FASTER, not just possible: 424 registers in LDS leave one wave per CU (16.6 ms on a
+    // 2^18-row domain against 3.9 from the slab, profiles/r06_quotient_paths.txt).  Knobs for measurements.
+    const size_t lds_max_regs = [] { const char* e = getenv("TS_INTERP_LDS_MAX_REGS"); return e ? (size_t)atoi(e) : (size_t)48; }();
+    const unsigned waves_per_cu = [] { const char* e = getenv("TS_INTERP_WAVES_PER_CU"); return e ? (unsigned)atoi(e) : 8u; }();
+    pl.global = n_regs > lds_max_regs || pl.lds_bytes > ctx.max_lds_per_block || getenv("TS_INTERP_GLOBAL_REGS") != nullptr;
     const uint64_t tiles = (rows + pl.nthreads - 1) / pl.nthreads;
     if (pl.global) {
         pl.nthreads = 64;
         pl.lds_bytes = 0;
         const uint64_t t64 = (rows + 63) / 64;
-        // 8 waves per CU hide the slab's latency; the slab stays below 1 GiB
-        uint64_t grid = std::min<uint64_t>(t64, (uint64_t)ctx.num_cus * 8);
+        // a few waves per SIMD hide the slab's latency; the slab stays below 1 GiB
+        uint64_t grid = std::min<uint64_t>(t64, (uint64_t)ctx.num_cus * waves_per_cu);
         const uint64_t cap = (1ull << 28) / ((uint64_t)n_regs * 64);
         grid = std::max<uint64_t>(1, std::min(grid, cap));
         pl.grid = (unsigned)grid;

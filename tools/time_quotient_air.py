@@ -23,16 +23,21 @@ AIRS = [("SynthMulAir-64", SynthMulAir(64), 0), ("SynthExt-163", SynthExtAir(163
         ("Random(200 cols, 300 constraints, deg 5)", RandomAir(4242, 200, 300, 5, n_public=4, share_pct=35, max_depth=6), 4),
         ("Random(200 cols, 1000 constraints, deg 5)", RandomAir(4242, 200, 1000, 5, n_public=4, share_pct=35, max_depth=7), 4),
         ("Random(200 cols, 3000 constraints, deg 5)", RandomAir(4242, 200, 3000, 5, n_public=4, share_pct=20, max_depth=7), 4)]
+only = os.environ.get("TS_TQ_ONLY")  # substring filter on the AIR name
+paths = os.environ.get("TS_TQ_PATHS", "jit,interp-lds,interp-global").split(",")
 n = 1 << log_n
 for name, air, npub in AIRS:
+    if only and only not in name:
+        continue
     tape = ts.air_tape(air, npub)
     w = air.width()
     trace = splitmix64_stream(7, n * w).reshape(n, w)
     pis = splitmix64_stream(8, max(npub, 1))[:npub]
     alpha = splitmix64_stream(9, 4)
     ref = None
-    for path in ("jit", "interp-lds", "interp-global"):
-        env = {"jit": {}, "interp-lds": {"TS_NO_JIT": "1"}, "interp-global": {"TS_NO_JIT": "1", "TS_INTERP_GLOBAL_REGS": "1"}}[path]
+    for path in paths:
+        env = {"jit": {}, "interp-lds": {"TS_NO_JIT": "1", "TS_INTERP_LDS_MAX_REGS": "1000000"},
+               "interp-global": {"TS_NO_JIT": "1", "TS_INTERP_GLOBAL_REGS": "1"}, "interp": {"TS_NO_JIT": "1"}}[path]
         for k in ("TS_NO_JIT", "TS_INTERP_GLOBAL_REGS"):
             os.environ.pop(k, None)
         os.environ.update(env)
@@ -71,7 +76,8 @@ for name, air, npub in AIRS:
         rows = n << cair.log_quotient_degree
         rec.update({"quotient_rows": rows, "kernel_ms": round(ms, 4),
                     "program_instructions_per_s": round(rows * len(prog["code"]) / (ms * 1e-3), 3),
-                    "kernel": [k for k in kt if "k_quotient" in k][0]})
+                    "kernel": [k for k in kt if "k_quotient" in k][0],
+                    "waves_per_cu": os.environ.get("TS_INTERP_WAVES_PER_CU")})
         print(json.dumps(rec), flush=True)
         os.environ.pop("TS_NO_JIT", None)
         os.environ.pop("TS_INTERP_GLOBAL_REGS", None)

@@ -129,7 +129,8 @@ ts_status ts_air_info(const ts_air* air, uint32_t* width, uint32_t* n_public,
  * compile budget, or a background compilation has not finished yet).
  * Compile budget (hiprtc's time grows faster than the program): up to TS_JIT_SYNC_INSTR (default 2048)
  * lowered instructions the kernel is compiled inside ts_air_compile; up to TS_JIT_MAX_INSTR (default
- * 32768) on a background thread while proofs already run on the interpreter -- the first use after
+ * 32768) by a child process (the helper `ts_jitc` beside the library; TS_JITC_PATH overrides; without it
+ * such programs stay on the interpreter) while proofs already run on the interpreter -- the first use after
  * it finishes switches over, the proof words are the same either way; larger programs stay on the
  * interpreter, which has no limit on program size or live values. */
 int ts_air_is_jit(const ts_air* air);

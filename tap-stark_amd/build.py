@@ -90,6 +90,11 @@ def build(force: bool = False, verbose: bool = False, asan: bool = False, define
             list(ex.map(run, jobs))
     if jobs or not os.path.exists(lib):
         run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *(san if asan else []), "-o", lib, *objs])
+    # the out-of-process hiprtc helper of the background AIR specialisation (plain host C++, beside the library)
+    helper_src = os.path.join(PKG, "jitc", "ts_jitc.cpp")
+    helper = os.path.join(lib_dir, "ts_jitc")
+    if force or not os.path.exists(helper) or os.path.getmtime(helper) < os.path.getmtime(helper_src):
+        run(["g++", "-O2", "-std=c++17", "-o", helper, helper_src, "-ldl"])
     return lib
 
 

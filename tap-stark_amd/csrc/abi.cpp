@@ -1,13 +1,17 @@
 // extern "C" boundary (include/tapstark.h): plain pointers and sizes, status codes, no exceptions
 // across the ABI.
+#include <dlfcn.h>
+#include <signal.h>
+#include <spawn.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+#include <sys/wait.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <chrono>
-#include <condition_variable>
 #include <mutex>
-#include <thread>
 #include <memory>
 #include <string>
 #include <vector>
@@ -18,47 +22,46 @@
 // hiprtc's time grows faster than the program (a 4.6k-instruction program compiles in 14 s, an
 // 18.8k one in 146 s: profiles/r06_air_jit_compile.txt), so the specialisation has a budget:
 //   <= TS_JIT_SYNC_INSTR (default 2048, ~3 s)   compiled inside ts_air_compile, as before;
-//   <= TS_JIT_MAX_INSTR  (default 32768)        compiled on a background thread: proofs run on the
+//   <= TS_JIT_MAX_INSTR  (default 32768)        compiled by a child process (ts_jitc): proofs run on the
 //                                               interpreter (a GPU path too) until the code object is
 //                                               ready, the next use loads it; ts_air_jit_wait joins;
 //   larger                                      interpreter only.
 // Both kernels compute the same words, so which one ran never shows in a proof.
-// A background compilation outlives the ts_air that asked for it (hiprtc cannot be interrupted, and
-// ts_air_free must not wait a minute for it): the job is shared between the worker thread and the AIR;
-// workers still running when the library is unloaded are joined then (they are inside libhiprtc).
-struct JitJob {
-    std::string src, arch, log;
-    std::vector<char> code;
-    double seconds = 0;
-    bool done = false, ok = false;
-    std::mutex m;
-    std::condition_variable cv;
-};
-struct JitWorkers {
-    std::mutex m;
-    std::vector<std::thread> threads;
-    void start(std::shared_ptr<JitJob> job) {
-        std::lock_guard<std::mutex> g(m);
-        threads.emplace_back([job] {
-            const auto t0 = std::chrono::steady_clock::now();
-            std::vector<char> code;
-            std::string log;
-            const bool ok = ts::jit_compile_source(job->src, job->arch.c_str(), code, log);
-            std::lock_guard<std::mutex> g2(job->m);
-            job->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            job->code = std::move(code);
-            job->log = std::move(log);
-            job->ok = ok;
-            job->done = true;
-            job->cv.notify_all();
-        });
+// A background compilation runs in a CHILD PROCESS (tap-stark_amd/jitc/ts_jitc.cpp, built beside the
+// library): hiprtc serialises compilations inside one process, cannot be interrupted, and a thread still
+// inside it when the host exits meets the compiler's static destructors.  The child compiles beside the
+// prover and beside other children, is killed when its AIR is freed, and leaves nothing behind but a
+// code object in a private temporary directory.
+static std::string jitc_path() {
+    if (const char* e = getenv("TS_JITC_PATH")) return e;
+    Dl_info info;
+    if (dladdr((void*)&jitc_path, &info) && info.dli_fname) {
+        std::string p = info.dli_fname;
+        const size_t k = p.rfind('/');
+        return (k == std::string::npos ? std::string(".") : p.substr(0, k)) + "/ts_jitc";
     }
-    ~JitWorkers() {
-        for (auto& t : threads)
-            if (t.joinable()) t.join();
+    return "ts_jitc";
+}
+
+struct JitChild {
+    pid_t pid = -1;
+    std::string dir, src, out, log;
+    std::chrono::steady_clock::time_point t0;
+    void cleanup() {
+        for (const std::string& f : {src, out, out + ".part", log})
+            if (!f.empty()) (void)unlink(f.c_str());
+        if (!dir.empty()) (void)rmdir(dir.c_str());
+        dir.clear();
+    }
+    ~JitChild() {
+        if (pid > 0) {  // still compiling for an AIR nobody wants any more
+            (void)kill(pid, SIGKILL);
+            int st = 0;
+            (void)waitpid(pid, &st, 0);
+        }
+        cleanup();
     }
 };
-static JitWorkers g_jit_workers;
 
 struct ts_air {
     ts::AirProgram prog;
@@ -67,43 +70,97 @@ struct ts_air {
     int device = -1;  // the device the jit module was loaded on (-1: host-only AIR)
     enum { JIT_NONE = 0, JIT_COMPILING = 1, JIT_LOADED = 3, JIT_FAILED = 4 };
     int jit_state = JIT_NONE;
-    std::shared_ptr<JitJob> job;
+    std::unique_ptr<JitChild> job;
     double jit_seconds = 0;
     std::string arch;
-    void start_background_jit() {
-        job = std::make_shared<JitJob>();
-        job->src = ts::jit_quotient_source(prog);
-        job->arch = arch;
-        jit_state = JIT_COMPILING;
-        g_jit_workers.start(job);
-    }
-    // called on the thread that drives the context (device current): adopt a finished compilation
     std::mutex poll_m;  // two threads proving with one ts_air: the adoption happens once
+
+    void start_background_jit() {
+        const std::string helper = jitc_path();
+        if (access(helper.c_str(), X_OK) != 0) {
+            jit_log = "background specialisation needs the helper " + helper + " (not found): interpreter only";
+            return;
+        }
+        auto j = std::make_unique<JitChild>();
+        const char* tmp = getenv("TMPDIR");
+        std::string tmpl = std::string(tmp && *tmp ? tmp : "/tmp") + "/ts_jit_XXXXXX";
+        std::vector<char> buf(tmpl.begin(), tmpl.end());
+        buf.push_back(0);
+        if (!mkdtemp(buf.data())) {
+            jit_log = "mkdtemp failed: interpreter only";
+            return;
+        }
+        j->dir = buf.data();
+        j->src = j->dir + "/quotient_jit.hip";
+        j->out = j->dir + "/quotient_jit.co";
+        j->log = j->dir + "/log.txt";
+        const std::string src = ts::jit_quotient_source(prog);
+        FILE* f = fopen(j->src.c_str(), "wb");
+        if (!f || fwrite(src.data(), 1, src.size(), f) != src.size()) {
+            if (f) fclose(f);
+            jit_log = "cannot write the kernel source: interpreter only";
+            return;
+        }
+        fclose(f);
+        char* argv[] = {const_cast<char*>(helper.c_str()), const_cast<char*>(arch.c_str()),
+                        const_cast<char*>(j->src.c_str()), const_cast<char*>(j->out.c_str()),
+                        const_cast<char*>(j->log.c_str()), nullptr};
+        j->t0 = std::chrono::steady_clock::now();
+        pid_t pid = -1;
+        if (posix_spawn(&pid, helper.c_str(), nullptr, nullptr, argv, environ) != 0) {
+            jit_log = "posix_spawn of " + helper + " failed: interpreter only";
+            return;
+        }
+        j->pid = pid;
+        job = std::move(j);
+        jit_state = JIT_COMPILING;
+    }
+    // called on the thread that drives the context: adopt a finished compilation
     void poll_jit(bool wait) {
         std::lock_guard<std::mutex> pg(poll_m);
         if (!job) return;
-        std::unique_lock<std::mutex> lk(job->m);
-        if (wait) job->cv.wait(lk, [&] { return job->done; });
-        if (!job->done) return;
-        jit_seconds = job->seconds;
+        int st = 0;
+        const pid_t r = waitpid(job->pid, &st, wait ? 0 : WNOHANG);
+        if (r == 0) return;  // still compiling
+        job->pid = -1;
+        jit_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - job->t0).count();
+        std::vector<char> code_obj;
+        bool ok = r > 0 && WIFEXITED(st) && WEXITSTATUS(st) == 0;
+        if (ok) {
+            if (FILE* f = fopen(job->out.c_str(), "rb")) {
+                char buf[1 << 16];
+                size_t n;
+                while ((n = fread(buf, 1, sizeof buf, f)) > 0) code_obj.insert(code_obj.end(), buf, buf + n);
+                fclose(f);
+            }
+            ok = !code_obj.empty();
+        }
+        if (!ok) {
+            if (FILE* f = fopen(job->log.c_str(), "rb")) {
+                char buf[4096];
+                const size_t n = fread(buf, 1, sizeof buf, f);
+                jit_log.assign(buf, n);
+                fclose(f);
+            }
+            if (jit_log.empty()) jit_log = "the compiler child ended without a code object";
+        }
         ts::JitKernel jk;
         int cur = -1;
         (void)hipGetDevice(&cur);
         if (device >= 0 && cur != device) (void)hipSetDevice(device);  // the module belongs to the AIR's device
-        const bool loaded = job->ok && ts::jit_load_code(job->code, jk, job->log);
+        const bool loaded = ok && ts::jit_load_code(code_obj, jk, jit_log);
         if (device >= 0 && cur >= 0 && cur != device) (void)hipSetDevice(cur);
         if (loaded) {
             prog.jit_module = jk.module;
             prog.jit_fn = jk.fn;
             jit_state = JIT_LOADED;
         } else {
-            jit_log = job->log;
             jit_state = JIT_FAILED;
         }
-        lk.unlock();
         job.reset();
     }
     ~ts_air() {
+        job.reset();
         if (device >= 0 && prog.jit_module) (void)hipSetDevice(device);
         ts::JitKernel jk;
         jk.module = prog.jit_module;
@@ -116,6 +173,8 @@ static const ts::AirProgram& ready_prog(const ts_air* air) {
     const_cast<ts_air*>(air)->poll_jit(false);
     return air->prog;
 }
+extern char** environ;
+
 struct ts_challenger {
     ts::BfChallenger c;
     ts_challenger(int perm, bool ext) : c(perm, ext) {}

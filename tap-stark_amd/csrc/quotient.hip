@@ -122,16 +122,18 @@ static RegFilePlan plan_reg_file(Context& ctx, uint32_t n_regs, uint64_t rows) {
     // global slab is FASTER, not just possible: 424 registers in LDS leave one wave per CU (16.6 ms on a
     // 2^18-row domain against 3.9 from the slab, profiles/r06_quotient_paths.txt).  Knobs for measurements.
     const size_t lds_max_regs = [] { const char* e = getenv("TS_INTERP_LDS_MAX_REGS"); return e ? (size_t)atoi(e) : (size_t)48; }();
-    const unsigned waves_per_cu = [] { const char* e = getenv("TS_INTERP_WAVES_PER_CU"); return e ? (unsigned)atoi(e) : 8u; }();
+    const unsigned waves_per_cu = [] { const char* e = getenv("TS_INTERP_WAVES_PER_CU"); return e ? (unsigned)atoi(e) : 16u; }();
     pl.global = n_regs > lds_max_regs || pl.lds_bytes > ctx.max_lds_per_block || getenv("TS_INTERP_GLOBAL_REGS") != nullptr;
     const uint64_t tiles = (rows + pl.nthreads - 1) / pl.nthreads;
     if (pl.global) {
         pl.nthreads = 64;
         pl.lds_bytes = 0;
         const uint64_t t64 = (rows + 63) / 64;
-        // a few waves per SIMD hide the slab's latency; the slab stays below 1 GiB
+        // a few waves per SIMD hide the slab's latency (16 per CU: 1.5x over 8, 32 adds nothing); the slab stays
+        // below 4 GiB of the 288 (a smaller, cache-resident slab is slower: the grid is what matters)
         uint64_t grid = std::min<uint64_t>(t64, (uint64_t)ctx.num_cus * waves_per_cu);
-        const uint64_t cap = (1ull << 28) / ((uint64_t)n_regs * 64);
+        const uint64_t slab_mb = [] { const char* e = getenv("TS_INTERP_SLAB_MB"); return e ? (uint64_t)atoi(e) : (uint64_t)4096; }();
+        const uint64_t cap = (slab_mb << 18) / ((uint64_t)n_regs * 64);
         grid = std::max<uint64_t>(1, std::min(grid, cap));
         pl.grid = (unsigned)grid;
         pl.scratch_words = (size_t)grid * n_regs * 64;
@@ -167,10 +169,18 @@ k_quotient(const uint32_t* __restrict__ code, uint32_t n_instr, uint32_t n_regs,
         const uint32_t* row_next = lde + r_next;
         uint32_t acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
 
+        // Wave-uniform instruction fetch (scalar loads), one instruction ahead.  The value an instruction
+        // produces stays in a VGPR for the next one (`fwd`): in a post-order evaluation the next instruction
+        // nearly always consumes it, and reading it back from the register file would put a memory round
+        // trip (LDS or, worse, the slab) on every link of the dependency chain.
+        const uint4* code4 = reinterpret_cast<const uint4*>(code);
+        uint4 ins = code4[0];
+        uint32_t fwd_reg = ~0u, fwd_val = 0;
+        auto rd = [&](uint32_t reg) { return reg == fwd_reg ? fwd_val : my[(size_t)reg * NTHREADS]; };
         for (uint32_t pc = 0; pc < n_instr; pc++) {
-            // wave-uniform instruction fetch (scalar loads)
-            const uint32_t op = code[4 * pc], dst = code[4 * pc + 1], a = code[4 * pc + 2],
-                           b = code[4 * pc + 3];
+            const uint4 nxt = code4[pc + 1 < n_instr ? pc + 1 : pc];
+            const uint32_t op = ins.x, dst = ins.y, a = ins.z, b = ins.w;
+            ins = nxt;
             uint32_t v;
             switch (op) {
                 case D_LOAD: {
@@ -180,12 +190,12 @@ k_quotient(const uint32_t* __restrict__ code, uint32_t n_instr, uint32_t n_regs,
                 }
                 case D_CONST: v = consts_mont[a]; break;
                 case D_SEL: v = a == 0 ? sel0 : (a == 1 ? sel1 : sel2); break;
-                case D_ADD: v = add(my[(size_t)a * NTHREADS], my[(size_t)b * NTHREADS]); break;
-                case D_SUB: v = sub(my[(size_t)a * NTHREADS], my[(size_t)b * NTHREADS]); break;
-                case D_NEG: v = neg(my[(size_t)a * NTHREADS]); break;
-                case D_MUL: v = mont_mul(my[(size_t)a * NTHREADS], my[(size_t)b * NTHREADS]); break;
+                case D_ADD: v = add(rd(a), rd(b)); break;
+                case D_SUB: v = sub(rd(a), rd(b)); break;
+                case D_NEG: v = neg(rd(a)); break;
+                case D_MUL: v = mont_mul(rd(a), rd(b)); break;
                 default: {  // D_ASSERT
-                    const uint32_t c = my[(size_t)a * NTHREADS];
+                    const uint32_t c = rd(a);
                     const uint32_t* ap = alpha_pows + 4 * b;
                     acc0 = add(acc0, mont_mul(c, ap[0]));
                     acc1 = add(acc1, mont_mul(c, ap[1]));
@@ -195,6 +205,8 @@ k_quotient(const uint32_t* __restrict__ code, uint32_t n_instr, uint32_t n_regs,
                 }
             }
             my[(size_t)dst * NTHREADS] = v;
+            fwd_reg = dst;
+            fwd_val = v;
         }
         if (!active) continue;
         // quotient(x) = constraints(x) / Z_H(x)  (prover.rs:183); flatten + split (prover.rs:78-80):
@@ -329,24 +341,31 @@ k_check_constraints(const uint32_t* __restrict__ code, uint32_t n_instr, uint32_
         const uint32_t sel1 = ii == n - 1 ? R_MOD_P : 0u;
         const uint32_t sel2 = ii != n - 1 ? R_MOD_P : 0u;
         unsigned long long bad = ~0ull;
+        const uint4* code4 = reinterpret_cast<const uint4*>(code);
+        uint4 ins = code4[0];
+        uint32_t fwd_reg = ~0u, fwd_val = 0;  // as in k_quotient
+        auto rd = [&](uint32_t reg) { return reg == fwd_reg ? fwd_val : my[(size_t)reg * NTHREADS]; };
         for (uint32_t pc = 0; pc < n_instr; pc++) {
-            const uint32_t op = code[4 * pc], dst = code[4 * pc + 1], a = code[4 * pc + 2],
-                           b = code[4 * pc + 3];
+            const uint4 nxt = code4[pc + 1 < n_instr ? pc + 1 : pc];
+            const uint32_t op = ins.x, dst = ins.y, a = ins.z, b = ins.w;
+            ins = nxt;
             uint32_t v;
             switch (op) {
                 case D_LOAD: v = to_mont((a ? row_next : row_local)[b]); break;
                 case D_CONST: v = consts_mont[a]; break;
                 case D_SEL: v = a == 0 ? sel0 : (a == 1 ? sel1 : sel2); break;
-                case D_ADD: v = add(my[(size_t)a * NTHREADS], my[(size_t)b * NTHREADS]); break;
-                case D_SUB: v = sub(my[(size_t)a * NTHREADS], my[(size_t)b * NTHREADS]); break;
-                case D_NEG: v = neg(my[(size_t)a * NTHREADS]); break;
-                case D_MUL: v = mont_mul(my[(size_t)a * NTHREADS], my[(size_t)b * NTHREADS]); break;
+                case D_ADD: v = add(rd(a), rd(b)); break;
+                case D_SUB: v = sub(rd(a), rd(b)); break;
+                case D_NEG: v = neg(rd(a)); break;
+                case D_MUL: v = mont_mul(rd(a), rd(b)); break;
                 default: {  // D_ASSERT
-                    if (my[(size_t)a * NTHREADS] != 0 && bad == ~0ull) bad = ii * 65536ull + b;
+                    if (rd(a) != 0 && bad == ~0ull) bad = ii * 65536ull + b;
                     continue;
                 }
             }
             my[(size_t)dst * NTHREADS] = v;
+            fwd_reg = dst;
+            fwd_val = v;
         }
         if (active && bad != ~0ull) atomicMin(violation, bad);
     }

@@ -69,9 +69,8 @@ def _write_summary():
 
 
 def _compile(ctx, tape, monkeypatch, jit: bool):
-    # hiprtc serialises compilations inside one process, so a background compilation nobody waits for
-    # would hold up every later ts_air_compile: programs above the size this run waits for are left to
-    # the interpreter (TS_JIT_MAX_INSTR), like any program above the product's own budget
+    # programs above the size this run waits for are left to the interpreter (TS_JIT_MAX_INSTR), like any
+    # program above the product's own budget: a compiler child nobody waits for would only burn host cores
     with monkeypatch.context() as m:
         if not jit:
             m.setenv("TS_NO_JIT", "1")
@@ -291,7 +290,7 @@ def _thread_ranks(G, rank_fn):
 
 
 @pytest.mark.parametrize("seed", [0, 3, 6, 9, 12, 15, 18, 21, 24, 27, 1, 4])
-def test_random_airs_sharded(ctx, orc, seed):
+def test_random_airs_sharded(ctx, orc, monkeypatch, seed):
     """The same random AIRs as ONE proof over G thread-ranks (csrc/sharded.cpp): the quotient is then
     evaluated on row ranges / on each rank's own cosets with their shifts and mixed back
     (local_quotient), a different consumer of the lowered program.  Valid-trace seeds (multiples of 3)
@@ -312,14 +311,18 @@ def test_random_airs_sharded(ctx, orc, seed):
     for b, G in ((max(lqd, 1), 2), (max(lqd, 1) + 1, 4)):
         cfg = (b, 4, 3)
         want = orc.prove(orc.FriConfig(*cfg), tape, trace, pis, debug_assertions=False)
+        # rank 0 runs the specialised kernel (one compilation per configuration), the others the
+        # interpreter: both take the row ranges / coset shifts of the sharded quotient, and the ranks'
+        # slabs must still fit together into the oracle's proof
+        ctxs = [ts.Context(0) for _ in range(G)]
+        airs = [_compile(ctxs[r], tape, monkeypatch, r == 0) for r in range(G)]
         for localq in (False, True):
             group = LocalCommGroup(G)
 
             def rank(r):
-                c = ts.Context(0)
-                conf = ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(*cfg), c))
+                conf = ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(*cfg), ctxs[r]))
                 rows = np.ascontiguousarray(trace[r * n // G:(r + 1) * n // G])
-                return ts.prove_sharded(conf, ts.CompiledAir(c, tape), ts.BfChallenger(), rows, pis, group.comm(r),
+                return ts.prove_sharded(conf, airs[r], ts.BfChallenger(), rows, pis, group.comm(r),
                                         min_local_log=2, local_quotient=localq).words
 
             for r, words in enumerate(_thread_ranks(G, rank)):

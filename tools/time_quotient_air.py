@@ -38,7 +38,7 @@ for name, air, npub in AIRS:
     for path in paths:
         env = {"jit": {}, "interp-lds": {"TS_NO_JIT": "1", "TS_INTERP_LDS_MAX_REGS": "1000000"},
                "interp-global": {"TS_NO_JIT": "1", "TS_INTERP_GLOBAL_REGS": "1"}, "interp": {"TS_NO_JIT": "1"}}[path]
-        for k in ("TS_NO_JIT", "TS_INTERP_GLOBAL_REGS"):
+        for k in ("TS_NO_JIT", "TS_INTERP_GLOBAL_REGS", "TS_INTERP_LDS_MAX_REGS"):
             os.environ.pop(k, None)
         os.environ.update(env)
         t0 = time.time()

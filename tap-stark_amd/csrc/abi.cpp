@@ -105,9 +105,17 @@ struct ts_air {
         char* argv[] = {const_cast<char*>(helper.c_str()), const_cast<char*>(arch.c_str()),
                         const_cast<char*>(j->src.c_str()), const_cast<char*>(j->out.c_str()),
                         const_cast<char*>(j->log.c_str()), nullptr};
+        // the child is a plain compiler run: nothing preloaded into the host (profilers, sanitizer runtimes)
+        // belongs in it
+        std::vector<char*> envp;
+        for (char** e = environ; e && *e; e++)
+            if (strncmp(*e, "LD_PRELOAD=", 11) != 0 && strncmp(*e, "HSA_TOOLS_LIB=", 14) != 0 &&
+                strncmp(*e, "ROCP_TOOL_", 10) != 0)
+                envp.push_back(*e);
+        envp.push_back(nullptr);
         j->t0 = std::chrono::steady_clock::now();
         pid_t pid = -1;
-        if (posix_spawn(&pid, helper.c_str(), nullptr, nullptr, argv, environ) != 0) {
+        if (posix_spawn(&pid, helper.c_str(), nullptr, nullptr, argv, envp.data()) != 0) {
             jit_log = "posix_spawn of " + helper + " failed: interpreter only";
             return;
         }

@@ -132,7 +132,9 @@ ts_status ts_air_info(const ts_air* air, uint32_t* width, uint32_t* n_public,
  * 32768) by a child process (the helper `ts_jitc` beside the library; TS_JITC_PATH overrides; without it
  * such programs stay on the interpreter) while proofs already run on the interpreter -- the first use after
  * it finishes switches over, the proof words are the same either way; larger programs stay on the
- * interpreter, which has no limit on program size or live values. */
+ * interpreter, which has no limit on program size or live values.  TS_JIT_CACHE_DIR (an existing
+ * directory) keeps the code objects across processes: a later ts_air_compile of the same AIR loads
+ * instead of compiling. */
 int ts_air_is_jit(const ts_air* air);
 /* joins a background compilation; state: 0 none, 3 specialised kernel loaded, 4 compilation failed */
 ts_status ts_air_jit_wait(ts_ctx* ctx, ts_air* air, int* state, double* compile_seconds);

@@ -45,7 +45,7 @@ static std::string jitc_path() {
 
 struct JitChild {
     pid_t pid = -1;
-    std::string dir, src, out, log;
+    std::string dir, src, out, log, cache;
     std::chrono::steady_clock::time_point t0;
     void cleanup() {
         for (const std::string& f : {src, out, out + ".part", log})
@@ -75,6 +75,18 @@ struct ts_air {
     std::string arch;
     std::mutex poll_m;  // two threads proving with one ts_air: the adoption happens once
 
+    // a code object of this very source left by an earlier process (TS_JIT_CACHE_DIR): no compilation at all
+    bool adopt_cached() {
+        std::vector<char> code_obj;
+        if (!ts::jit_cache_load(ts::jit_cache_path(ts::jit_quotient_source(prog), arch.c_str()), code_obj)) return false;
+        ts::JitKernel jk;
+        std::string log;
+        if (!ts::jit_load_code(code_obj, jk, log)) return false;
+        prog.jit_module = jk.module;
+        prog.jit_fn = jk.fn;
+        jit_state = JIT_LOADED;
+        return true;
+    }
     void start_background_jit() {
         const std::string helper = jitc_path();
         if (access(helper.c_str(), X_OK) != 0) {
@@ -95,6 +107,7 @@ struct ts_air {
         j->out = j->dir + "/quotient_jit.co";
         j->log = j->dir + "/log.txt";
         const std::string src = ts::jit_quotient_source(prog);
+        j->cache = ts::jit_cache_path(src, arch.c_str());
         FILE* f = fopen(j->src.c_str(), "wb");
         if (!f || fwrite(src.data(), 1, src.size(), f) != src.size()) {
             if (f) fclose(f);
@@ -142,6 +155,7 @@ struct ts_air {
                 fclose(f);
             }
             ok = !code_obj.empty();
+            if (ok) ts::jit_cache_store(job->cache, code_obj);
         }
         if (!ok) {
             if (FILE* f = fopen(job->log.c_str(), "rb")) {
@@ -611,7 +625,7 @@ ts_status ts_air_compile(ts_ctx* ctx, const uint32_t* tape, size_t n_words, ts_a
             }
             a->jit_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         } else if (n_instr <= env_or("TS_JIT_MAX_INSTR", 32768)) {
-            a->start_background_jit();
+            if (!a->adopt_cached()) a->start_background_jit();
         } else {
             a->jit_log = "program above TS_JIT_MAX_INSTR: interpreter only";
         }

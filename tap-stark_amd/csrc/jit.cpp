@@ -10,6 +10,8 @@
 #include <dlfcn.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
 
 #include <sstream>
 
@@ -143,6 +145,56 @@ std::string jit_quotient_source(const AirProgram& air) {
     return s.str();
 }
 
+// ---- optional on-disk cache of code objects (TS_JIT_CACHE_DIR): the reference pays for `Air::eval` once, at
+// build time; a prover process that restarts should not pay hiprtc again for an AIR it has compiled before.
+// Key: 128 bits of FNV-1a over (generator version, hiprtc version, arch, source).
+static const char* kGeneratorVersion = "tapstark-jit-1";
+
+std::string jit_cache_path(const std::string& src, const char* arch) {
+    const char* dir = getenv("TS_JIT_CACHE_DIR");
+    if (!dir || !*dir) return "";
+    int major = 0, minor = 0;
+    if (void* lib = rtc().lib)
+        if (auto ver = (int (*)(int*, int*))dlsym(lib, "hiprtcVersion")) (void)ver(&major, &minor);
+    uint64_t h1 = 0xcbf29ce484222325ull, h2 = 0x84222325cbf29ce4ull;
+    auto mix = [&](const void* p, size_t n) {
+        const unsigned char* b = (const unsigned char*)p;
+        for (size_t i = 0; i < n; i++) {
+            h1 = (h1 ^ b[i]) * 0x100000001b3ull;
+            h2 = (h2 ^ (b[i] + 0x9e)) * 0x100000001b3ull;
+            h2 ^= h2 >> 29;
+        }
+    };
+    mix(kGeneratorVersion, strlen(kGeneratorVersion));
+    mix(&major, sizeof major);
+    mix(&minor, sizeof minor);
+    mix(arch, strlen(arch));
+    mix(src.data(), src.size());
+    char name[96];
+    snprintf(name, sizeof name, "/q_%016llx%016llx_%s.co", (unsigned long long)h1, (unsigned long long)h2, arch);
+    return std::string(dir) + name;
+}
+bool jit_cache_load(const std::string& path, std::vector<char>& code) {
+    if (path.empty()) return false;
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    code.clear();
+    char buf[1 << 16];
+    size_t n;
+    while ((n = fread(buf, 1, sizeof buf, f)) > 0) code.insert(code.end(), buf, buf + n);
+    fclose(f);
+    return code.size() > 64 && memcmp(code.data(), "\177ELF", 4) == 0;
+}
+void jit_cache_store(const std::string& path, const std::vector<char>& code) {
+    if (path.empty() || code.empty()) return;
+    const std::string tmp = path + ".part" + std::to_string((long)getpid());
+    FILE* f = fopen(tmp.c_str(), "wb");
+    if (!f) return;  // the directory must exist; a cache that cannot be written is simply not used
+    const bool ok = fwrite(code.data(), 1, code.size(), f) == code.size();
+    fclose(f);
+    if (!ok || rename(tmp.c_str(), path.c_str()) != 0) (void)unlink(tmp.c_str());
+}
+
 bool jit_compile_code(const AirProgram& air, const char* arch, std::vector<char>& code, std::string& log) {
     return jit_compile_source(jit_quotient_source(air), arch, code, log);
 }
@@ -158,6 +210,11 @@ bool jit_compile_source(const std::string& src, const char* arch, std::vector<ch
             fwrite(src.data(), 1, src.size(), f);
             fclose(f);
         }
+    }
+    const std::string cached = jit_cache_path(src, arch);
+    if (jit_cache_load(cached, code)) {
+        log = "code object from " + cached;
+        return true;
     }
     rtcProgram prog = nullptr;
     if (r.create(&prog, src.c_str(), "quotient_jit.hip", 0, nullptr, nullptr) != 0) {
@@ -181,6 +238,7 @@ bool jit_compile_source(const std::string& src, const char* arch, std::vector<ch
     code.resize(sz);
     r.get_code(prog, code.data());
     r.destroy(&prog);
+    jit_cache_store(cached, code);
     return true;
 }
 

@@ -94,3 +94,29 @@ def test_large_tape_lowering(orc):
     want = orc.constraint_values(tape, local, nxt, pis, sels)
     got = run_program(cair.program(), local, nxt, pis, sels, int(tape[5]))
     assert (got == want).all()
+
+
+def test_code_object_cache(orc, tmp_path, monkeypatch):
+    """TS_JIT_CACHE_DIR: the code object of a source is compiled once and then read back (no GPU needed:
+    hiprtc cross-compiles); a damaged file is not trusted."""
+    import glob
+    import time
+
+    air = RandomAir(11, 40, 60, 3)
+    cair = ts.CompiledAir(None, ts.air_tape(air, 3))
+    monkeypatch.setenv("TS_JIT_CACHE_DIR", str(tmp_path))
+    try:
+        code1, t1 = cair.jit_compile()
+    except ts._lib.TsError as e:  # no libhiprtc in this environment
+        pytest.skip(str(e))
+    files = glob.glob(str(tmp_path / "q_*_gfx950.co"))
+    assert len(files) == 1 and open(files[0], "rb").read() == code1
+    t0 = time.time()
+    code2, _ = cair.jit_compile()
+    assert code2 == code1 and time.time() - t0 < 0.5 * t1 + 0.05
+    other = ts.CompiledAir(None, ts.air_tape(RandomAir(12, 40, 60, 3), 3))
+    other.jit_compile()
+    assert len(glob.glob(str(tmp_path / "q_*_gfx950.co"))) == 2  # another source, another entry
+    open(files[0], "wb").write(b"not an ELF file")
+    code3, _ = cair.jit_compile()
+    assert code3[:4] == b"\x7fELF" and len(code3) == len(code1)

@@ -266,6 +266,35 @@ def test_jit_budget_knobs(ctx, orc, monkeypatch):
     assert ts.CompiledAir(ctx, tape).is_jit
 
 
+def test_code_object_cache_on_the_device(ctx, orc, monkeypatch, tmp_path):
+    """TS_JIT_CACHE_DIR: the first ts_air_compile leaves the code object, a later one of the same AIR --
+    inside or above the synchronous budget -- loads it without compiling, and computes the same chunks."""
+    import glob
+
+    air = RandomAir(21, 30, 50, 3)
+    tape = ts.air_tape(air, 3)
+    log_n, b = 6, 1
+    trace = splitmix64_stream(5, (1 << log_n) * 30).reshape(1 << log_n, 30)
+    pis, alpha = splitmix64_stream(6, 3), splitmix64_stream(7, 4)
+    lqd = orc.log_quotient_degree(tape)
+    b = max(lqd, 1)
+    want = orc.split_quotient(orc.quotient_values(tape, orc.commit_lde(trace, 1, b), log_n, b, pis, alpha), log_n, lqd)
+    pcs = ts.TwoAdicFriPcs(ts.FriConfig(b, 3, 2), ctx)
+    _, data = pcs.commit([((log_n, 1), trace.copy())])
+    monkeypatch.setenv("TS_JIT_CACHE_DIR", str(tmp_path))
+    first = ts.CompiledAir(ctx, tape)
+    assert first.is_jit and len(glob.glob(str(tmp_path / "q_*.co"))) == 1
+    t0 = time.time()
+    again = ts.CompiledAir(ctx, tape)
+    assert again.is_jit and time.time() - t0 < 0.2, "a cached code object is loaded, not compiled"
+    with monkeypatch.context() as m:
+        m.setenv("TS_JIT_SYNC_INSTR", "1")  # the background route: the cache answers before a child is started
+        bg = ts.CompiledAir(ctx, tape)
+        assert bg.is_jit and bg.jit_wait()[0] == 3
+    for c in (first, again, bg):
+        _check_chunks(pcs, data, c, pis, alpha, want, "cached", 21)
+
+
 # ------------------------------------------------------------------ random AIRs through the sharded prover
 def _thread_ranks(G, rank_fn):
     import threading

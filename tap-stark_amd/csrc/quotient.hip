@@ -107,14 +107,13 @@ struct QuotConsts {
 // declines (jit.cpp: instruction budget) still runs on the device.
 struct RegFilePlan {
     int nthreads;
-    int rows = 1;  // rows per lane (slab variant of the quotient interpreter)
     bool global;
     size_t lds_bytes;
     unsigned grid;
     size_t scratch_words;
 };
 
-static RegFilePlan plan_reg_file(Context& ctx, uint32_t n_regs, uint64_t rows, int rows_per_lane = 1) {
+static RegFilePlan plan_reg_file(Context& ctx, uint32_t n_regs, uint64_t rows) {
     RegFilePlan pl;
     pl.nthreads = 256;
     while (pl.nthreads > 64 && (size_t)n_regs * pl.nthreads * 4 > 48 * 1024) pl.nthreads >>= 1;
@@ -129,16 +128,15 @@ static RegFilePlan plan_reg_file(Context& ctx, uint32_t n_regs, uint64_t rows, i
     if (pl.global) {
         pl.nthreads = 64;
         pl.lds_bytes = 0;
-        pl.rows = rows_per_lane;
-        const uint64_t t64 = (rows + 64 * rows_per_lane - 1) / (64 * rows_per_lane);
+        const uint64_t t64 = (rows + 63) / 64;
         // a few waves per SIMD hide the slab's latency (16 per CU: 1.5x over 8, 32 adds nothing); the slab stays
         // below 4 GiB of the 288 (a smaller, cache-resident slab is slower: the grid is what matters)
         uint64_t grid = std::min<uint64_t>(t64, (uint64_t)ctx.num_cus * waves_per_cu);
         const uint64_t slab_mb = [] { const char* e = getenv("TS_INTERP_SLAB_MB"); return e ? (uint64_t)atoi(e) : (uint64_t)4096; }();
-        const uint64_t cap = (slab_mb << 18) / ((uint64_t)n_regs * 64 * rows_per_lane);
+        const uint64_t cap = (slab_mb << 18) / ((uint64_t)n_regs * 64);
         grid = std::max<uint64_t>(1, std::min(grid, cap));
         pl.grid = (unsigned)grid;
-        pl.scratch_words = (size_t)grid * n_regs * 64 * rows_per_lane;
+        pl.scratch_words = (size_t)grid * n_regs * 64;
     } else {
         pl.grid = (unsigned)tiles;
         pl.scratch_words = 0;
@@ -146,9 +144,7 @@ static RegFilePlan plan_reg_file(Context& ctx, uint32_t n_regs, uint64_t rows, i
     return pl;
 }
 
-// ROWS rows per lane (the slab variant): ROWS independent dependency chains per wave, so ROWS register-file
-// reads are in flight where one was, and an instruction is fetched and decoded once for ROWS rows.
-template <int NTHREADS, bool GLOBAL_REGS, int ROWS>
+template <int NTHREADS, bool GLOBAL_REGS>
 __global__ void __launch_bounds__(NTHREADS)
 k_quotient(const uint32_t* __restrict__ code, uint32_t n_instr, uint32_t n_regs,
            const uint32_t* __restrict__ lde, uint64_t col_stride, unsigned log_n, unsigned log_qd,
@@ -156,31 +152,22 @@ k_quotient(const uint32_t* __restrict__ code, uint32_t n_instr, uint32_t n_regs,
            const uint32_t* __restrict__ is_first, const uint32_t* __restrict__ is_last,
            const uint32_t* __restrict__ is_transition, QuotConsts qc, QuotOut out,
            uint32_t row_begin, uint32_t row_end, uint32_t* __restrict__ reg_slabs, uint32_t n_tiles) {
-    extern __shared__ uint32_t lds_regs[];  // [n_regs][ROWS * NTHREADS] unless GLOBAL_REGS
-    constexpr int LANES = ROWS * NTHREADS;  // rows per tile = the stride between registers
+    extern __shared__ uint32_t lds_regs[];  // [n_regs][NTHREADS] unless GLOBAL_REGS
     const unsigned L = log_n + log_qd;
     const uint32_t total = 1u << L;
-    uint32_t* my = GLOBAL_REGS ? reg_slabs + (size_t)blockIdx.x * n_regs * LANES + threadIdx.x
+    uint32_t* my = GLOBAL_REGS ? reg_slabs + (size_t)blockIdx.x * n_regs * NTHREADS + threadIdx.x
                                : lds_regs + threadIdx.x;
     for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        uint32_t r[ROWS], sel0[ROWS], sel1[ROWS], sel2[ROWS];
-        bool active[ROWS];
-        const uint32_t* row_local[ROWS];
-        const uint32_t* row_next[ROWS];
-        uint32_t acc0[ROWS], acc1[ROWS], acc2[ROWS], acc3[ROWS];
-#pragma unroll
-        for (int k = 0; k < ROWS; k++) {
-            r[k] = row_begin + tile * LANES + k * NTHREADS + threadIdx.x;
-            active[k] = r[k] < row_end;
-            const uint32_t rr = active[k] ? r[k] : row_begin;
-            const uint32_t i = bitrev32(rr, L);
-            const uint32_t i_next = (i + (1u << log_qd)) & (total - 1);  // prover.rs:139-140,165
-            const uint32_t r_next = bitrev32(i_next, L);
-            sel0[k] = is_first[rr], sel1[k] = is_last[rr], sel2[k] = is_transition[rr];
-            row_local[k] = lde + rr;
-            row_next[k] = lde + r_next;
-            acc0[k] = acc1[k] = acc2[k] = acc3[k] = 0;
-        }
+        const uint32_t r = row_begin + tile * NTHREADS + threadIdx.x;
+        const bool active = r < row_end;
+        const uint32_t rr = active ? r : row_begin;
+        const uint32_t i = bitrev32(rr, L);
+        const uint32_t i_next = (i + (1u << log_qd)) & (total - 1);  // prover.rs:139-140,165
+        const uint32_t r_next = bitrev32(i_next, L);
+        const uint32_t sel0 = is_first[rr], sel1 = is_last[rr], sel2 = is_transition[rr];
+        const uint32_t* row_local = lde + rr;
+        const uint32_t* row_next = lde + r_next;
+        uint32_t acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
 
         // Wave-uniform instruction fetch (scalar loads), one instruction ahead.  The value an instruction
         // produces stays in a VGPR for the next one (`fwd`): in a post-order evaluation the next instruction
@@ -188,84 +175,50 @@ k_quotient(const uint32_t* __restrict__ code, uint32_t n_instr, uint32_t n_regs,
         // trip (LDS or, worse, the slab) on every link of the dependency chain.
         const uint4* code4 = reinterpret_cast<const uint4*>(code);
         uint4 ins = code4[0];
-        uint32_t fwd_reg = ~0u, fwd_val[ROWS];
-#pragma unroll
-        for (int k = 0; k < ROWS; k++) fwd_val[k] = 0;
-        auto rd = [&](uint32_t reg, int k) {
-            return reg == fwd_reg ? fwd_val[k] : my[(size_t)reg * LANES + k * NTHREADS];
-        };
+        uint32_t fwd_reg = ~0u, fwd_val = 0;
+        auto rd = [&](uint32_t reg) { return reg == fwd_reg ? fwd_val : my[(size_t)reg * NTHREADS]; };
         for (uint32_t pc = 0; pc < n_instr; pc++) {
             const uint4 nxt = code4[pc + 1 < n_instr ? pc + 1 : pc];
             const uint32_t op = ins.x, dst = ins.y, a = ins.z, b = ins.w;
             ins = nxt;
-            uint32_t v[ROWS];
+            uint32_t v;
             switch (op) {
-                case D_LOAD:
-#pragma unroll
-                    for (int k = 0; k < ROWS; k++) v[k] = (a ? row_next[k] : row_local[k])[(uint64_t)b * col_stride];
-#pragma unroll
-                    for (int k = 0; k < ROWS; k++) v[k] = to_mont(v[k]);
-                    break;
-                case D_CONST: {
-                    const uint32_t cv = consts_mont[a];
-#pragma unroll
-                    for (int k = 0; k < ROWS; k++) v[k] = cv;
+                case D_LOAD: {
+                    const uint32_t* base = a ? row_next : row_local;
+                    v = to_mont(base[(uint64_t)b * col_stride]);
                     break;
                 }
-                case D_SEL:
-#pragma unroll
-                    for (int k = 0; k < ROWS; k++) v[k] = a == 0 ? sel0[k] : (a == 1 ? sel1[k] : sel2[k]);
-                    break;
-                case D_ADD:
-                case D_SUB:
-                case D_MUL: {
-                    uint32_t x[ROWS], y[ROWS];
-#pragma unroll
-                    for (int k = 0; k < ROWS; k++) x[k] = rd(a, k), y[k] = rd(b, k);  // all loads first
-#pragma unroll
-                    for (int k = 0; k < ROWS; k++)
-                        v[k] = op == D_ADD ? add(x[k], y[k]) : op == D_SUB ? sub(x[k], y[k]) : mont_mul(x[k], y[k]);
-                    break;
-                }
-                case D_NEG:
-#pragma unroll
-                    for (int k = 0; k < ROWS; k++) v[k] = neg(rd(a, k));
-                    break;
+                case D_CONST: v = consts_mont[a]; break;
+                case D_SEL: v = a == 0 ? sel0 : (a == 1 ? sel1 : sel2); break;
+                case D_ADD: v = add(rd(a), rd(b)); break;
+                case D_SUB: v = sub(rd(a), rd(b)); break;
+                case D_NEG: v = neg(rd(a)); break;
+                case D_MUL: v = mont_mul(rd(a), rd(b)); break;
                 default: {  // D_ASSERT
+                    const uint32_t c = rd(a);
                     const uint32_t* ap = alpha_pows + 4 * b;
-                    const uint32_t ap0 = ap[0], ap1 = ap[1], ap2 = ap[2], ap3 = ap[3];
-#pragma unroll
-                    for (int k = 0; k < ROWS; k++) {
-                        const uint32_t c = rd(a, k);
-                        acc0[k] = add(acc0[k], mont_mul(c, ap0));
-                        acc1[k] = add(acc1[k], mont_mul(c, ap1));
-                        acc2[k] = add(acc2[k], mont_mul(c, ap2));
-                        acc3[k] = add(acc3[k], mont_mul(c, ap3));
-                    }
+                    acc0 = add(acc0, mont_mul(c, ap[0]));
+                    acc1 = add(acc1, mont_mul(c, ap[1]));
+                    acc2 = add(acc2, mont_mul(c, ap[2]));
+                    acc3 = add(acc3, mont_mul(c, ap[3]));
                     continue;
                 }
             }
-#pragma unroll
-            for (int k = 0; k < ROWS; k++) {
-                my[(size_t)dst * LANES + k * NTHREADS] = v[k];
-                fwd_val[k] = v[k];
-            }
+            my[(size_t)dst * NTHREADS] = v;
             fwd_reg = dst;
+            fwd_val = v;
         }
+        if (!active) continue;
         // quotient(x) = constraints(x) / Z_H(x)  (prover.rs:183); flatten + split (prover.rs:78-80):
         // natural row i -> chunk i % qd, position i / qd; stored bit-reversed = r & (n-1)
-#pragma unroll
-        for (int k = 0; k < ROWS; k++) {
-            if (!active[k]) continue;
-            const uint32_t c = bitrev32(r[k] >> log_n, log_qd);
-            const uint32_t iz = qc.inv_zh_canonical[c];
-            const uint64_t n = 1ull << log_n;
-            uint32_t* o = out.chunk[c] + (r[k] & (n - 1));
-            o[0] = mont_mul(acc0[k], iz);
-            o[n] = mont_mul(acc1[k], iz);
-            o[2 * n] = mont_mul(acc2[k], iz);
-            o[3 * n] = mont_mul(acc3[k], iz);
-        }
+        const uint32_t c = bitrev32(r >> log_n, log_qd);
+        const uint32_t iz = qc.inv_zh_canonical[c];
+        const uint64_t n = 1ull << log_n;
+        uint32_t* o = out.chunk[c] + (r & (n - 1));
+        o[0] = mont_mul(acc0, iz);
+        o[n] = mont_mul(acc1, iz);
+        o[2 * n] = mont_mul(acc2, iz);
+        o[3 * n] = mont_mul(acc3, iz);
     }
 }
 
@@ -305,25 +258,21 @@ void launch_quotient(Context& ctx, const AirProgram& air, const ColMat& trace_ld
                                      256, 1, 1, 0, ctx.stream, args, nullptr));
         return;
     }
-    const int rpl = [] { const char* e = getenv("TS_INTERP_ROWS"); const int v = e ? atoi(e) : 2; return v == 1 || v == 4 ? v : 2; }();
-    const RegFilePlan pl = plan_reg_file(ctx, air.n_regs, total, rpl);
+    const RegFilePlan pl = plan_reg_file(ctx, air.n_regs, total);
     DevBuf<uint32_t> slabs;
     if (pl.global) slabs = DevBuf<uint32_t>(&ctx, pl.scratch_words);
-    const uint64_t per_tile = (uint64_t)pl.nthreads * pl.rows;
-    const uint32_t n_tiles = (uint32_t)((total + per_tile - 1) / per_tile);
-#define TS_LAUNCH_Q(NTH, GLOB, ROWS)                                                                    \
+    const uint32_t n_tiles = (uint32_t)((total + pl.nthreads - 1) / pl.nthreads);
+#define TS_LAUNCH_Q(NTH, GLOB)                                                                          \
     do {                                                                                                \
-        allow_lds(k_quotient<NTH, GLOB, ROWS>, pl.lds_bytes);                                           \
-        TS_LAUNCH(ctx, (k_quotient<NTH, GLOB, ROWS>), dim3(pl.grid), dim3(NTH), pl.lds_bytes, air.d_code, n_instr, \
+        allow_lds(k_quotient<NTH, GLOB>, pl.lds_bytes);                                                 \
+        TS_LAUNCH(ctx, (k_quotient<NTH, GLOB>), dim3(pl.grid), dim3(NTH), pl.lds_bytes, air.d_code, n_instr, \
                   air.n_regs, trace_lde.d, trace_lde.col_stride, log_n, log_qd, d_consts_mont,          \
                   d_alpha_pows_mont, is_first, is_last, is_transition, qc, out, rb, re, slabs.p, n_tiles); \
     } while (0)
-    if (pl.global && pl.rows == 4) TS_LAUNCH_Q(64, true, 4);
-    else if (pl.global && pl.rows == 2) TS_LAUNCH_Q(64, true, 2);
-    else if (pl.global) TS_LAUNCH_Q(64, true, 1);
-    else if (pl.nthreads == 256) TS_LAUNCH_Q(256, false, 1);
-    else if (pl.nthreads == 128) TS_LAUNCH_Q(128, false, 1);
-    else TS_LAUNCH_Q(64, false, 1);
+    if (pl.global) TS_LAUNCH_Q(64, true);
+    else if (pl.nthreads == 256) TS_LAUNCH_Q(256, false);
+    else if (pl.nthreads == 128) TS_LAUNCH_Q(128, false);
+    else TS_LAUNCH_Q(64, false);
 #undef TS_LAUNCH_Q
     TS_HIP(hipGetLastError());
 }

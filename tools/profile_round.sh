@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collects a round's evidence on the GPU box (run from the repo root through gpurun):
-#     bash tools/profile_round.sh r05
+#     bash tools/profile_round.sh r06 [a|b]
 # Everything lands under gpurun_out/<tag>/final/ and is then copied into profiles/<tag>_* by
 # tools/profile_collect.py: bench lines (driver protocol for config 3; configs 2, 4, 5; the 2-rank
 # shared-GPU rehearsal of --gpus 2 with both sharded blocks), rocprofv3 kernel-trace stats for configs
@@ -9,11 +9,13 @@
 # reference's fold benchmark.
 set -e
 set -o pipefail
-TAG=${1:-r05}
+TAG=${1:-r06}
+PART=${2:-all}   # all | a (bench lines, shard stages, latency, launch sequences) | b (power, counters, kernel traces)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG/final
 mkdir -p $O
 cd $R
+if [ $PART != b ]; then
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_config3_k20.json 2> $O/bench.err
 python3 bench.py --workload config2 --streams 8 --steps 48 --warmup 8 --no-cpu-baseline > $O/bench_config2.json 2>> $O/bench.err
 python3 bench.py --workload config4 --streams 1 --steps 6 --warmup 2 --windows 1 --no-cpu-baseline > $O/bench_config4.json 2>> $O/bench.err
@@ -33,6 +35,8 @@ bash tools/trace_proof.sh final_c3 config3 > /dev/null && cp gpurun_out/r5/trace
 bash tools/trace_proof.sh final_c2 config2 > /dev/null && cp gpurun_out/r5/trace_final_c2.txt $O/config2_launch_sequence.txt
 cd $R
 echo "latency done"
+fi
+if [ $PART = a ]; then exit 0; fi
 python3 tools/power_vs_working_set.py > $O/power_vs_working_set.json 2>> $O/bench.err
 python3 tools/power_per_stage.py > $O/power_per_stage.json 2>> $O/bench.err
 echo "power done"

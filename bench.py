@@ -878,12 +878,14 @@ def main():
         # Sustained priming (setup, untimed, on the record as `priming`): before the W warm-up steps the
         # lanes prove freshly generated traces in probes of K steps -- the timed window's own shape: same
         # lanes, same start gate, a device sync on both sides -- until two consecutive probes agree within
-        # 1.5 %, for at most TS_BENCH_PRIME_S (default 2 s) in all.  A fresh box needs a fraction of a
+        # 1.5 % and at least TS_BENCH_PRIME_MIN_S (0.5 s) of this load have run, for at most TS_BENCH_PRIME_S
+        # (default 2 s) in all.  A fresh box needs a fraction of a
         # second of this load before clocks and power management settle (cold first windows of 3.18 ms per
         # step against 2.8 in every later one were seen, and the driver's r05 run: 2.908 against 2.690
         # sustained in the same process).  The metric is sustained proofs per second; TS_BENCH_PRIME_S=0
         # turns the priming off.
         prime_cap = float(os.environ.get("TS_BENCH_PRIME_S", "2.0"))
+        prime_min = min(prime_cap, float(os.environ.get("TS_BENCH_PRIME_MIN_S", "0.5")))  # never less than this much load
         probes = []
         t_prime0 = time.perf_counter()
         while prime_cap > 0 and time.perf_counter() - t_prime0 < prime_cap:
@@ -904,7 +906,8 @@ def main():
             for c, _, _ in lanes:
                 c.synchronize()
             probes.append(round(1e3 * (time.perf_counter() - tp) / args.steps, 4))
-            if len(probes) >= 2 and abs(probes[-1] - probes[-2]) <= 0.015 * min(probes[-1], probes[-2]):
+            if (len(probes) >= 2 and abs(probes[-1] - probes[-2]) <= 0.015 * min(probes[-1], probes[-2])
+                    and time.perf_counter() - t_prime0 >= prime_min):
                 break
         primed["s"] = round(time.perf_counter() - t_prime0, 3)
         primed["probes_ms_per_step"] = probes

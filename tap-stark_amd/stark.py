@@ -748,7 +748,7 @@ def prove(config: StarkConfig, air, challenger: BfChallenger, trace, public_valu
 
 def prove_sharded(config: StarkConfig, air, challenger: BfChallenger, trace_rows, public_values,
                   comm, min_local_log: int = 0, trace_replicated: bool = False,
-                  local_quotient: bool = False) -> Proof:
+                  local_quotient: bool = False, _options_struct_size: int | None = None) -> Proof:
     """One proof over ``comm.world`` GPUs (``ts_prove_sharded``).
 
     Every rank calls this with its own context, a challenger in the same state and its row slice
@@ -778,8 +778,9 @@ def prove_sharded(config: StarkConfig, air, challenger: BfChallenger, trace_rows
     n_words = C.c_size_t()
     cfg = pcs.fri._c()
     pis_p = _p(pis) if len(pis) else None
-    opts = _lib.ShardOptionsC(C.sizeof(_lib.ShardOptionsC), min_local_log, int(trace_replicated),
-                              int(local_quotient))
+    # (_options_struct_size: test hook -- a caller built against another layout of ts_shard_options)
+    opts = _lib.ShardOptionsC(C.sizeof(_lib.ShardOptionsC) if _options_struct_size is None else _options_struct_size,
+                              min_local_log, int(trace_replicated), int(local_quotient))
     rc = ctx._l.ts_prove_sharded(ctx.h, C.byref(cfg), C.byref(comm.c), air.h, challenger.h,
                                  trace_rows.h, pis_p, len(pis), C.byref(opts), _p(out), cap,
                                  C.byref(n_words))

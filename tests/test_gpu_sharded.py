@@ -637,3 +637,20 @@ def test_local_quotient_on_an_invalid_trace_is_still_the_single_gpu_proof(ctx, o
             assert len(words) == len(single) and (words == single).all()
             assert fallbacks == (1 if localq else 0)
             assert (np.asarray(state) == np.asarray(ch1.state())).all()  # the transcript ends where ts_prove's does
+
+
+def test_shard_options_of_another_layout_are_refused(ctx):
+    """ABI 5: ts_shard_options starts with struct_size.  A caller built against ABI 4 (whose first field
+    was min_local_log, and which had a field that did nothing) is refused instead of having its fields
+    read as something else."""
+    from tapstark_amd._lib import TsError
+    from tapstark_amd.airs import SynthMulAir, generate_synth_mul_trace
+    from tapstark_amd.comm import LocalCommGroup
+
+    config = ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(2, 4, 4), ctx))
+    group = LocalCommGroup(1)
+    for bad in (0, 12, 20):
+        with pytest.raises(TsError, match="struct_size"):
+            ts.prove_sharded(config, SynthMulAir(7), ts.BfChallenger(), generate_synth_mul_trace(16, 7), [],
+                             group.comm(0), _options_struct_size=bad)
+    ts.prove_sharded(config, SynthMulAir(7), ts.BfChallenger(), generate_synth_mul_trace(16, 7), [], group.comm(0))

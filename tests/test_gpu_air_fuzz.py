@@ -318,7 +318,11 @@ def _thread_ranks(G, rank_fn):
     return out
 
 
-@pytest.mark.parametrize("seed", [0, 3, 6, 9, 12, 15, 18, 21, 24, 27, 1, 4])
+SHARDED_SEEDS = ([0, 3, 6, 9, 12, 15, 18, 21, 24, 27, 1, 4] if "TS_AIR_FUZZ_SHARDED" not in os.environ
+                 else list(range(int(os.environ["TS_AIR_FUZZ_SHARDED"]))))
+
+
+@pytest.mark.parametrize("seed", SHARDED_SEEDS)
 def test_random_airs_sharded(ctx, orc, monkeypatch, seed):
     """The same random AIRs as ONE proof over G thread-ranks (csrc/sharded.cpp): the quotient is then
     evaluated on row ranges / on each rank's own cosets with their shifts and mixed back
@@ -357,3 +361,4 @@ def test_random_airs_sharded(ctx, orc, monkeypatch, seed):
             for r, words in enumerate(_thread_ranks(G, rank)):
                 assert len(words) == len(want) and (words == want).all(), \
                     f"seed {seed} G={G} b={b} localq={localq} rank {r}: proof differs from the oracle's"
+            SUMMARY["sharded_proofs_compared"] = SUMMARY.get("sharded_proofs_compared", 0) + G

@@ -66,6 +66,13 @@ ts_status ts_ctx_set_timing(ts_ctx* ctx, int enabled);
 /* writes "name=ms;name=ms;..." of the stages recorded since the last call */
 ts_status ts_ctx_take_timings(ts_ctx* ctx, char* buf, size_t cap);
 
+/* MEASUREMENT AID: the ceiling of a "zero-host-sync" proof.  mode 1: the next ts_prove records the bytes the
+ * host reads at each of its mid-proof synchronisations (two commitment roots, the opened-value sums, the FRI
+ * block); mode 2: a ts_prove of the SAME trace, AIR and configuration skips those synchronisations and is
+ * handed the recorded bytes at once -- as if the challenges cost nothing -- and must return the same proof;
+ * mode 0: off.  Call it before EVERY proof it should apply to (it rewinds the log).  Not for production: with a
+ * different trace a mode-2 proof is garbage. */
+ts_status ts_ctx_set_replay(ts_ctx* ctx, int mode);
 /* per-kernel timers: HIP events recorded on the context's stream around EVERY kernel launch
  * (resolved lazily, no sync per kernel); take writes "kernel=launches:total_ms;..." */
 ts_status ts_ctx_set_kernel_timing(ts_ctx* ctx, int enabled);

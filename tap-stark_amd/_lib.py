@@ -18,7 +18,7 @@ voidpp = C.POINTER(C.c_void_p)
 # every symbol include/tapstark.h declares (tests check the built library exports all of them)
 ABI_SYMBOLS = [
     "ts_abi_version", "ts_device_count", "ts_ctx_create", "ts_ctx_destroy", "ts_last_error", "ts_ctx_synchronize",
-    "ts_ctx_stream", "ts_ctx_set_timing", "ts_ctx_take_timings", "ts_ctx_set_kernel_timing",
+    "ts_ctx_stream", "ts_ctx_set_timing", "ts_ctx_take_timings", "ts_ctx_set_replay", "ts_ctx_set_kernel_timing",
     "ts_ctx_take_kernel_timings", "ts_ctx_graph_stats", "ts_ctx_stat", "ts_matrix_upload",
     "ts_matrix_from_device", "ts_trace_fibonacci", "ts_trace_synth_mul", "ts_trace_synth_ext", "ts_matrix_dims", "ts_matrix_download", "ts_matrix_free",
     "ts_air_compile", "ts_air_info", "ts_air_is_jit", "ts_air_jit_wait", "ts_air_free", "ts_air_program", "ts_air_jit_source", "ts_air_jit_compile", "ts_pcs_commit", "ts_mmcs_commit", "ts_pcs_data_lde",
@@ -127,6 +127,7 @@ def lib() -> C.CDLL:
         l.ts_ctx_set_timing.argtypes = [C.c_void_p, C.c_int]
         l.ts_ctx_take_timings.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
         l.ts_ctx_set_kernel_timing.argtypes = [C.c_void_p, C.c_int]
+        l.ts_ctx_set_replay.argtypes = [C.c_void_p, C.c_int]
         l.ts_ctx_take_kernel_timings.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
         l.ts_matrix_upload.argtypes = [C.c_void_p, u32p, C.c_uint64, C.c_uint32, voidpp]
         l.ts_matrix_from_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, voidpp]

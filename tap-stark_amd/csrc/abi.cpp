@@ -363,6 +363,15 @@ ts_status ts_ctx_take_timings(ts_ctx* ctx, char* buf, size_t cap) {
     return TS_OK;
 }
 
+ts_status ts_ctx_set_replay(ts_ctx* ctx, int mode) {
+    if (!ctx || mode < 0 || mode > 2) return TS_ERR_INVALID;
+    return guard(ctx, [&] {
+        ctx->ctx.sync();
+        if (mode == 1) ctx->ctx.replay_log.clear();
+        ctx->ctx.replay_pos = 0;
+        ctx->ctx.replay_mode = mode;
+    });
+}
 ts_status ts_ctx_set_kernel_timing(ts_ctx* ctx, int enabled) {
     if (!ctx) return TS_ERR_INVALID;
     return guard(ctx, [&] {

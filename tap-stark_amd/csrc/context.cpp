@@ -183,6 +183,24 @@ const void* Context::stage(const void* src, size_t bytes) {
     return p;
 }
 
+void Context::sync_point(void* host, size_t bytes) {
+    if (replay_mode == 2 && replay_pos < replay_log.size() && replay_log[replay_pos].size() == bytes) {
+        memcpy(host, replay_log[replay_pos++].data(), bytes);
+        return;
+    }
+    sync();
+    if (replay_mode == 1) replay_log.emplace_back((const char*)host, (const char*)host + bytes);
+}
+void Context::d2h_point(void* host_dst, const void* dev_src, size_t bytes) {
+    if (replay_mode == 2 && replay_pos < replay_log.size() && replay_log[replay_pos].size() == bytes) {
+        memcpy(host_dst, replay_log[replay_pos++].data(), bytes);  // no copy enqueued: host_dst may die before it ran
+        return;
+    }
+    if (bytes) TS_HIP(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, stream));
+    sync();
+    if (replay_mode == 1) replay_log.emplace_back((const char*)host_dst, (const char*)host_dst + bytes);
+}
+
 uint32_t* Context::mailbox(size_t words) {
     constexpr size_t WORDS = 16384;  // 64 KiB
     if (words > WORDS / 4) {

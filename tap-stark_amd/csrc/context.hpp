@@ -173,6 +173,17 @@ struct Context {
     T* alloc_n(size_t n) { return static_cast<T*>(alloc(n * sizeof(T))); }
     void release_cache();
 
+    // MEASUREMENT AID (ts_ctx_set_replay, tools/latency_replay.py): what would a proof cost if the host never
+    // had to wait for the device -- the ceiling of a "zero-host-sync" design?  Mode 1 records, at every point
+    // where prove() synchronises to read a small device result (two commitment roots, the opened-value sums,
+    // the FRI block), the bytes it read; mode 2 proves the SAME trace again without those synchronisations,
+    // handing the host the recorded bytes at once (the device still computes and writes the same values).
+    // The proof must come out identical; only the final gather still synchronises.
+    int replay_mode = 0;
+    size_t replay_pos = 0;
+    std::vector<std::vector<char>> replay_log;
+    void sync_point(void* host, size_t bytes);                        // host memory a kernel wrote (mailbox)
+    void d2h_point(void* host_dst, const void* dev_src, size_t bytes);  // an async copy + sync
     void* pinned(size_t bytes);
     void ensure_twiddles(unsigned log_size);
     void sync() { TS_HIP(hipStreamSynchronize(stream)); }

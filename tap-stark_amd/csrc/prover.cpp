@@ -149,7 +149,7 @@ void mmcs_commit(Context& ctx, PcsData& data) {
             }
         }
         if (mail) {
-            ctx.sync();
+            ctx.sync_point(mail, 32);
             memcpy(data.root, mail, 32);
         } else {
             d2h_sync(ctx, data.root, data.tree.p + 8 * (merkle_total_digests(log_H) - 1), 32);
@@ -412,7 +412,7 @@ DevBuf<Ef> TwoAdicFriPcs::open_reduce_slab(const PcsData& trace_data, const PcsD
                 launch_bary_dots(ctx_, quotient_data.ldes[c], log_n, weights.p, 1, sums.p + 2 * w + 4 * c, &pend);
         }
         launch_bary_finish(ctx_, pend);
-        ctx_.sync();
+        ctx_.sync_point(sums.p, raw.size() * sizeof(Ef));
         memcpy(raw.data(), sums.p, raw.size() * sizeof(Ef));
     }
     // p(z) = ((z/s)^n - 1)/n * sum_i p_i x_i/(z - x_i) on the coset s*H_n (s = 31 unless sharded)
@@ -640,7 +640,7 @@ Ef fri_commit_finish(Context& ctx, const FriConfig& fri, BfChallenger& challenge
     std::vector<uint32_t> roots(std::max<size_t>(8 * (size_t)R_total, 8));
     DevChallenger hc;
     std::vector<uint32_t> block(st.d_block.n);
-    d2h_sync(ctx, block.data(), st.d_block.p, block.size() * 4);
+    ctx.d2h_point(block.data(), st.d_block.p, block.size() * 4);
     memcpy(&hc, block.data(), sizeof hc);
     st.pow_hint = block[FRI_POW_WORD];
     memcpy(roots.data(), block.data() + 64, roots.size() * 4);

@@ -81,6 +81,10 @@ class Context:
                 out.append((k, float(v)))
         return out
 
+    def set_replay(self, mode: int):
+        """``ts_ctx_set_replay`` (measurement aid: 1 record, 2 replay without the mid-proof syncs, 0 off)."""
+        self.check(self._l.ts_ctx_set_replay(self.h, int(mode)))
+
     def set_kernel_timing(self, enabled: bool):
         self.check(self._l.ts_ctx_set_kernel_timing(self.h, int(enabled)))
 

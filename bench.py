@@ -854,6 +854,22 @@ def main():
         if env.dist is not None and env.device is not None:
             torch.cuda.synchronize()
 
+    # The interpreter's cyclic garbage collector is switched off for the priming and the timed windows (and what
+    # exists is frozen out of its reach): a generation-2 collection in a process that has imported torch takes
+    # milliseconds WITH the interpreter lock held, and every lane returning from ts_prove would wait for it.  It is
+    # one possible source of the sporadic slow window, and a cheap one to exclude -- but not THE source: about
+    # one window (or priming probe) in forty still takes 2.9-3.2 ms/step instead of 2.73-2.78 with it off, with and
+    # without the amdsmi sampler (profiles/r06_window_hunt.txt).  `proof_latencies_ms_by_lane` of such a window shows
+    # proofs of ALL lanes 2-4 ms late at the same moment: a stall of the whole GPU (or host) of a few ms, about once
+    # per second of proving, outside this process's control.  `value` (window 1) draws such a window with that
+    # probability; the 160-step sustained leg and the other windows are on the record beside it.
+    import gc
+    keep_gc = os.environ.get("TS_BENCH_KEEP_GC") == "1"  # A/B knob
+    if not keep_gc:
+        gc.collect()
+        gc.freeze()
+        gc.disable()
+
     # Stagger: explicit, or auto = a quarter of the step time a single lane sustains (measured here
     # on one untimed proof per lane, which also primes every lane's tables / pools / code objects)
     single_ms = None
@@ -928,6 +944,7 @@ def main():
                     extra_windows=n_windows - 1)
     if sampler is not None:
         sampler.stop()
+    gc.enable()
     phase_done("replicas: warm-up + timed windows")
     # per window: ms/step, the clock and power the chip held, and what the host side did on each lane
     # (the longest pause between one ts_prove returning and the next being called, and how much of the
@@ -937,11 +954,12 @@ def main():
         row = {"window": k + 1, "ms_per_step": round(res["windows_ms_per_step"][k], 4)}
         if sampler is not None:
             row.update(sampler.window(w0, w1) if not sampler.error or sampler.samples else {"sampler_error": sampler.error})
-        gaps, gate, first_call, last_ret, lat = [], 0.0, [], [], []
-        for lg in lane_log:
+        gaps, gate, first_call, last_ret, lat, per_lane = [], 0.0, [], [], [], []
+        for li, lg in enumerate(lane_log):
             evs = [e for e in lg if w0 <= e[0] <= w1]
             if not evs:
                 continue
+            per_lane.append([round(1e3 * (e[1] - e[0]), 2) for e in evs])
             first_call.append(evs[0][0] - w0)
             last_ret.append(w1 - evs[-1][1])
             gate += sum(e[2] for e in evs)
@@ -953,7 +971,10 @@ def main():
                         "first_call_after_window_start_ms": [round(1e3 * x, 3) for x in first_call],
                         "window_end_after_last_return_ms": [round(1e3 * x, 3) for x in last_ret],
                         "proof_latency_in_window_ms_median": round(1e3 * sorted(lat)[len(lat) // 2], 3),
-                        "proof_latency_in_window_ms_max": round(1e3 * max(lat), 3)})
+                        "proof_latency_in_window_ms_max": round(1e3 * max(lat), 3),
+                        # every proof's wall time, lane by lane in call order: a stall of the GPU shows in
+                        # all lanes at once, a stall of one host thread / stream in one
+                        "proof_latencies_ms_by_lane": per_lane})
         per_window.append(row)
     shard_stages = None
     if sharded:
@@ -996,6 +1017,7 @@ def main():
                 "socket_power_w_median": [r_.get("socket_power_w_median") for r_ in per_window],
                 "longest_host_gap_ms": [r_.get("longest_host_gap_ms") for r_ in per_window],
                 "priming_probes_ms_per_step": primed.get("probes_ms_per_step"), "priming_s": primed.get("s"),
+                "python_gc": "on (TS_BENCH_KEEP_GC=1)" if keep_gc else "disabled and frozen over priming + timed windows",
                 "note": "every timed window of K steps (value = the first); clock / power from an amdsmi child "
                         "process during the window; host gap = longest pause between a ts_prove returning and "
                         "the next call on one lane; the sustained 160-step leg is clocks.prover_sustained"},
@@ -1265,9 +1287,17 @@ def rank0_legs(ts, args, env, ctx, config, cair, lanes, S, pool, local_sync, mak
 
     import numpy as np
 
-    # ---- roofline leg: per-kernel HIP-event timings over 3 extra (untimed) proofs
+    # ---- roofline leg: per-kernel HIP-event timings over 3 extra (untimed) proofs.  The GPU has been idle for a
+    # few hundred ms by now (sampler child joined, window statistics, the verifier on the host) and starts from
+    # its idle clock: timed cold, EVERY kernel of the leg read 5-9 % long (k_leaf_tree 0.371 ms here against
+    # 0.348 by rocprofv3 on the same box).  So the lane first proves for ~0.25 s, untimed, as rocprofv3's
+    # ten-proof trace does before the launches it averages.
+    t_warm = time.perf_counter() + 0.25
+    while time.perf_counter() < t_warm:
+        ts.prove(config, cair, ts.BfChallenger(), make_trace(ctx), pis)
     reps = 3
     extra = [make_trace(ctx) for _ in range(reps)]
+    ctx.synchronize()
     ctx.set_kernel_timing(True)
     for m in extra:
         ts.prove(config, cair, ts.BfChallenger(), m, pis)

@@ -1287,7 +1287,7 @@ def rank0_legs(ts, args, env, ctx, config, cair, lanes, S, pool, local_sync, mak
 
     import numpy as np
 
-    # ---- roofline leg: per-kernel HIP-event timings over 3 extra (untimed) proofs.  The GPU has been idle for a
+    # ---- roofline leg: per-kernel HIP-event timings over 10 extra (untimed) proofs.  The GPU has been idle for a
     # few hundred ms by now (sampler child joined, window statistics, the verifier on the host) and starts from
     # its idle clock: timed cold, EVERY kernel of the leg read 5-9 % long (k_leaf_tree 0.371 ms here against
     # 0.348 by rocprofv3 on the same box).  So the lane first proves for ~0.25 s, untimed, as rocprofv3's
@@ -1295,7 +1295,7 @@ def rank0_legs(ts, args, env, ctx, config, cair, lanes, S, pool, local_sync, mak
     t_warm = time.perf_counter() + 0.25
     while time.perf_counter() < t_warm:
         ts.prove(config, cair, ts.BfChallenger(), make_trace(ctx), pis)
-    reps = 3
+    reps = 10  # as many proofs as the committed rocprofv3 trace averages over (tools/prof_prove.py 10)
     extra = [make_trace(ctx) for _ in range(reps)]
     ctx.synchronize()
     ctx.set_kernel_timing(True)

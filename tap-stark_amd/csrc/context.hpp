@@ -186,7 +186,24 @@ struct Context {
     void d2h_point(void* host_dst, const void* dev_src, size_t bytes);  // an async copy + sync
     void* pinned(size_t bytes);
     void ensure_twiddles(unsigned log_size);
-    void sync() { TS_HIP(hipStreamSynchronize(stream)); }
+    // The host's wait for the stream: hipStreamSynchronize puts the thread to sleep on an interrupt after a
+    // short spin, and the wake-up is the OS scheduler's business -- tens of microseconds normally, milliseconds
+    // now and then.  TS_SYNC_SPIN=1 polls hipStreamQuery instead (the thread has nothing else to do during
+    // the 0.1-0.5 ms it waits for; one core per context is busy while a proof runs).
+    void sync() {
+        static const int spin = [] { const char* e = getenv("TS_SYNC_SPIN"); return e ? atoi(e) : 0; }();
+        if (!spin) {
+            TS_HIP(hipStreamSynchronize(stream));
+            return;
+        }
+        hipError_t e;
+        while ((e = hipStreamQuery(stream)) == hipErrorNotReady) {
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
+        TS_HIP(e);
+    }
 };
 
 // RAII device buffer from the context's pool

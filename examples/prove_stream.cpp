@@ -20,6 +20,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <mutex>
@@ -120,6 +121,9 @@ int main(int argc, char** argv) {
     std::atomic<int> failed{0};
     Gate gate;
     std::vector<double> solo_ms(lanes, 0.0), lane_done_ms(lanes, 0.0);
+    // TS_STREAM_LATENCIES=1: every timed proof's (start, wall time), to look for stalls without any Python in the process
+    const bool want_lat = getenv("TS_STREAM_LATENCIES") != nullptr;
+    std::vector<std::vector<std::pair<double, double>>> lat(lanes);
     double t_begin = 0, t_end = 0;
     std::mutex mu;
     int primed = 0;
@@ -182,8 +186,11 @@ int main(int argc, char** argv) {
                 primed++;
             }
             while (!go.load()) std::this_thread::yield();
-            for (int i = l, k = 0; i < n_proofs; i += lanes, k++)
+            for (int i = l, k = 0; i < n_proofs; i += lanes, k++) {
+                const double t0 = now_ms();
                 if (!prove_one(pinned ? make_trace() : mats[k], &proofs[i])) return fail("ts_prove");
+                if (want_lat) lat[l].push_back({t0, now_ms() - t0});
+            }
             lane_done_ms[l] = now_ms();  // before the teardown: ts_ctx_destroy gives a ~3.5 GB pool back (tens of ms)
             ts_air_free(ctx, air);
             ts_ctx_destroy(ctx);
@@ -234,5 +241,22 @@ int main(int argc, char** argv) {
            "one proof alone %.3f ms, start gate %.2f ms; all proofs identical (%zu words), verify -> %d\n",
            log_n, w, n_proofs, lanes, pinned ? "from pinned host memory (ts_matrix_upload_async)" : "generated on the device",
            ms, 1e3 / ms, (double)n * w * 1e3 / ms, solo_ms[0], gate.gap_ms, proofs[0].size(), verdict);
+    if (want_lat) {
+        std::vector<double> all;
+        for (auto& v : lat)
+            for (auto& e : v) all.push_back(e.second);
+        std::sort(all.begin(), all.end());
+        const double med = all[all.size() / 2];
+        printf("  proof wall times: median %.2f ms, p99 %.2f, max %.2f; proofs above 1.4 x median (lane: start since the clock started, ms -> wall time):\n",
+               med, all[(size_t)(0.99 * all.size())], all.back());
+        int n_slow = 0;
+        for (int l = 0; l < lanes; l++)
+            for (auto& e : lat[l])
+                if (e.second > 1.4 * med) {
+                    printf("    lane %d: %9.1f -> %.2f\n", l, e.first - t_begin, e.second);
+                    n_slow++;
+                }
+        printf("  %d of %zu proofs\n", n_slow, all.size());
+    }
     return verdict == 0 ? 0 : 1;
 }

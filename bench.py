@@ -833,9 +833,34 @@ def main():
                 time.sleep(min(wait, 2e-4))
             gate_last[0] = time.perf_counter()
 
+    # How the S lanes are driven.  Default: ONE library call per window (ts_prove_stream): the lane threads, the
+    # start gate and the per-proof clock are C++ inside the library, as a compiled host (Rust, C++:
+    # examples/prove_stream.cpp) would have them.  A lane loop in Python threads -- TS_BENCH_PY_LANES=1, what
+    # rounds 3-5 timed -- pays the interpreter lock once per proof and showed, in about one window of thirty,
+    # one to four proofs of 15-50 ms among 11-ms ones (profiles/r06_window_hunt.txt); the C++ loop showed none in
+    # 3600 proofs on the same boxes and runs ~2 % faster.  The timed region is the same either way: EXACTLY K
+    # complete proofs between two barrier + device-sync pairs.
+    py_lanes = os.environ.get("TS_BENCH_PY_LANES") == "1" or sharded or args.host_traces
+    stream_ok = (not py_lanes) and S > 1 and hasattr(ts, "prove_stream")
+    pool = None
+    stream_lanes = [(conf, ca) for _, conf, ca in lanes]
     if S == 1:
         step = prove_one
         run_steps = None
+    elif stream_ok and pregen:
+        step = prove_one
+
+        def run_steps(first, count):
+            idx = list(range(first, first + count))
+            t_call = time.perf_counter()
+            proof, st, wl = ts.prove_stream(stream_lanes, [mats[i] for i in idx], [i % S for i in idx], pis,
+                                            gate_ms=stagger["ms"])
+            last["proof"] = proof
+            for k, i in enumerate(idx):  # the library's per-proof clock, on this process's time axis
+                lane_log[i % S].append((t_call + 1e-3 * st[k], t_call + 1e-3 * (st[k] + wl[k]), 0.0))
+                mats[i] = None
+            for lg in lane_log:
+                lg.sort()
     else:
         from concurrent.futures import ThreadPoolExecutor
         pool = ThreadPoolExecutor(max_workers=S)
@@ -847,6 +872,9 @@ def main():
                 for i in range(first + l, first + count, S):
                     prove_one(i)
             list(pool.map(lane_job, range(S)))
+    if S > 1 and pool is None:
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=S)  # per-lane priming and the h2d leg still use Python lanes
 
     def local_sync():
         for c, _, _ in lanes:
@@ -915,7 +943,10 @@ def main():
                     start_gate()
                     ts.prove(conf, ca, ts.BfChallenger(), pm[i], pis)
             tp = time.perf_counter()
-            if S > 1:
+            if stream_ok:
+                ts.prove_stream(stream_lanes, pm, [i % S for i in range(args.steps)], pis, gate_ms=stagger["ms"],
+                                want_times=False)
+            elif S > 1:
                 list(pool.map(probe_job, range(S)))
             else:
                 probe_job(0)
@@ -1037,6 +1068,9 @@ def main():
                                         f"collectives over {comm.backend}, quotient {'local' if localq else 'broadcast'}" if sharded else
                                        ("1 rank per GPU (replicas)" if env.world > 1 else "1 GPU")
                                        + f", {S} proofs in flight per GPU, starts spaced >= {stagger['ms']:.2f} ms"),
+                       "lane_driver": ("ts_prove_stream (lane threads, gate and per-proof clock inside the library)"
+                                       if (not sharded and S > 1 and stream_ok and pregen) else
+                                       "python threads (one ts_prove call per proof per lane)" if S > 1 else "one lane"),
                        "quotient_kernel": "hiprtc-specialised" if cair.is_jit else "interpreter",
                        "proof_words": int(len(proof.words))},
             "proofs_per_sec": res["steps_per_sec"],
@@ -1058,7 +1092,8 @@ def main():
         }
     if env.rank == 0 and not args.headline_only:
         out.update(rank0_legs(ts, args, env, ctx, config, cair, lanes, S, pool if S > 1 else None, local_sync,
-                              make_trace, pis, cfg, n, w, qd, res, sharded, start_gate, proof))
+                              make_trace, pis, cfg, n, w, qd, res, sharded, start_gate, proof,
+                              gate_ms=stagger["ms"], stream_ok=(not sharded and S > 1 and stream_ok)))
         cb = out.get("cpu_baseline") or {}
         # the two fields VERDICT r3 asked for, at the top level of the line
         out["proof_blake3"] = cb.get("gpu_proof_blake3")
@@ -1281,7 +1316,7 @@ def latest_profile(pattern: str):
 
 
 def rank0_legs(ts, args, env, ctx, config, cair, lanes, S, pool, local_sync, make_trace, pis, cfg, n, w, qd,
-               res, sharded, start_gate=lambda: None, timed_proof=None) -> dict:
+               res, sharded, start_gate=lambda: None, timed_proof=None, gate_ms=0.0, stream_ok=False) -> dict:
     """Everything on the record beside the headline: measured on rank 0 after the timed region."""
     import hashlib
 
@@ -1611,7 +1646,11 @@ def rank0_legs(ts, args, env, ctx, config, cair, lanes, S, pool, local_sync, mak
                 local_sync()
                 with smp:
                     t0 = time.perf_counter()
-                    list(pool.map(clk_job, range(len(lanes))))
+                    if stream_ok:  # the same driver as the timed windows
+                        ts.prove_stream([(conf, ca) for _, conf, ca in lanes], mats3,
+                                        [i % len(lanes) for i in range(k3)], pis, gate_ms=gate_ms, want_times=False)
+                    else:
+                        list(pool.map(clk_job, range(len(lanes))))
                     local_sync()
                     dt_c = time.perf_counter() - t0
                 load = smp.summary()

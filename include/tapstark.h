@@ -331,6 +331,21 @@ void ts_comm_local_group_destroy(ts_comm_group* group);
 ts_status ts_comm_local_group_reset(ts_comm_group* group);
 ts_status ts_comm_local_group_set_timeout(ts_comm_group* group, int seconds);
 
+/* Throughput mode in one call: n_proofs independent proofs (uni-stark/src/prover.rs:25-35, one trace each, a
+ * fresh BfChallenger each) of one AIR on n_lanes contexts of ONE device, one host thread per lane inside
+ * the call; proof i runs on lane lane_of[i] (< n_lanes) with traces[i] (consumed; it must have been created
+ * on that lane's context) and airs[lane_of[i]] (compiled on that context).  No two proofs start within
+ * gate_ms of each other (0 = no gate; a quarter of one proof's solo time keeps the lanes in complementary
+ * phases).  last_proof_out receives the proof of the highest index; start_ms_out / wall_ms_out (n_proofs each,
+ * may be NULL): when each ts_prove-equivalent started, relative to the call's start, and how long it took.
+ * What a host with cheap threads does itself (examples/prove_stream.cpp); a host behind an interpreter
+ * lock gets the loop without paying its lock per proof. */
+ts_status ts_prove_stream(ts_ctx* const* ctxs, const ts_air* const* airs, uint32_t n_lanes,
+                          const ts_fri_config* cfg, ts_matrix* const* traces, const uint32_t* lane_of,
+                          uint32_t n_proofs, const uint32_t* public_values, uint32_t n_public, double gate_ms,
+                          uint32_t* last_proof_out, size_t cap_words, size_t* n_words_out,
+                          double* start_ms_out, double* wall_ms_out);
+
 /* prove() with the work of ONE proof split over comm->world ranks, one GPU each: rank g owns the
  * bit-reversed LDE rows [g N/G, (g+1) N/G) -- whole cosets, so world must be a power of two
  * <= 2^log_blowup (TS_ERR_UNSUPPORTED otherwise) -- with their Merkle sub-trees, FRI slabs and

@@ -5,4 +5,4 @@ from .air import (BaseAir, SymbolicAirBuilder, air_tape, get_log_quotient_degree
                   get_max_constraint_degree, get_symbolic_constraints)
 from .stark import (BfChallenger, Blake3Mmcs, CompiledAir, Context, DeviceMatrix, FriConfig, PcsData, PinnedHostMatrix,  # noqa: F401
                     Proof, StarkConfig, TwoAdicFriPcs, VerificationError, check_constraints,
-                    default_context, prove, prove_sharded, verify)
+                    default_context, prove, prove_sharded, prove_stream, verify)

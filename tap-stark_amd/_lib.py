@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "ts_pcs_data_info", "ts_pcs_data_matrix_info", "ts_pcs_data_digests", "ts_pcs_open_batch", "ts_pcs_data_free",
     "ts_quotient_chunks", "ts_pcs_open_reduce", "ts_pcs_open", "ts_pcs_verify", "ts_fri_prove", "ts_fri_verify", "ts_fri_fold", "ts_fri_fold_device", "ts_chal_new", "ts_chal_clone",
     "ts_chal_free", "ts_chal_observe", "ts_chal_observe_commitment", "ts_chal_sample",
-    "ts_chal_sample_bits", "ts_chal_check_witness", "ts_chal_grind", "ts_chal_state", "ts_prove", "ts_prove_sharded", "ts_verify", "ts_check_constraints",
+    "ts_chal_sample_bits", "ts_chal_check_witness", "ts_chal_grind", "ts_chal_state", "ts_prove", "ts_prove_stream", "ts_prove_sharded", "ts_verify", "ts_check_constraints",
     "ts_proof_to_postcard", "ts_proof_from_postcard", "ts_proof_from_postcard_v",
     "ts_rccl_available", "ts_rccl_unique_id", "ts_comm_rccl_create", "ts_comm_rccl_destroy",
     "ts_comm_rccl_info",
@@ -169,6 +169,10 @@ def lib() -> C.CDLL:
         l.ts_fri_fold_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, u32p, C.c_void_p]
         l.ts_prove.argtypes = [C.c_void_p, C.POINTER(FriConfigC), C.c_void_p, C.c_void_p, C.c_void_p,
                                u32p, C.c_uint32, u32p, C.c_size_t, C.POINTER(C.c_size_t)]
+        l.ts_prove_stream.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(FriConfigC),
+                                      C.POINTER(C.c_void_p), u32p, C.c_uint32, u32p, C.c_uint32, C.c_double,
+                                      u32p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_double),
+                                      C.POINTER(C.c_double)]
         l.ts_prove_sharded.argtypes = [C.c_void_p, C.POINTER(FriConfigC), C.POINTER(CommC), C.c_void_p,
                                        C.c_void_p, C.c_void_p, u32p, C.c_uint32,
                                        C.POINTER(ShardOptionsC), u32p, C.c_size_t,

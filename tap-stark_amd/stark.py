@@ -756,6 +756,40 @@ def prove(config: StarkConfig, air, challenger: BfChallenger, trace, public_valu
     return Proof(out[: n_words.value].copy())
 
 
+def prove_stream(lanes, traces, lane_of, public_values, gate_ms: float = 0.0, want_times: bool = True):
+    """``ts_prove_stream``: ``len(traces)`` independent proofs on the contexts of ``lanes`` = [(StarkConfig,
+    CompiledAir), ...] (one context each, same device, same FriConfig), one host thread per lane INSIDE the
+    library; proof i runs on lane ``lane_of[i]`` with ``traces[i]`` (a DeviceMatrix made on that lane's context;
+    consumed) and a fresh challenger.  Returns (Proof of the highest index, start_ms array, wall_ms array)."""
+    n_l, n = len(lanes), len(traces)
+    l = _lib.lib()
+    ctxs = (C.c_void_p * n_l)(*[conf.pcs.ctx.h for conf, _ in lanes])
+    airs = (C.c_void_p * n_l)(*[a.h for _, a in lanes])
+    mats = (C.c_void_p * max(n, 1))(*[t.h for t in traces])
+    lo = _u32(lane_of)
+    pis = _u32(public_values)
+    pcs = lanes[0][0].pcs
+    cfg = pcs.fri._c()
+    ctx0 = pcs.ctx
+    out = getattr(ctx0, "_proof_buf", None)
+    if out is None or len(out) < (1 << 20):
+        out = ctx0._proof_buf = np.zeros(1 << 20, dtype=np.uint32)
+    n_words = C.c_size_t()
+    st = np.zeros(max(n, 1), dtype=np.float64)
+    wl = np.zeros(max(n, 1), dtype=np.float64)
+    dp = C.POINTER(C.c_double)
+    rc = l.ts_prove_stream(ctxs, airs, n_l, C.byref(cfg), mats, _p(lo), n, _p(pis) if len(pis) else None, len(pis),
+                           float(gate_ms), _p(out), len(out), C.byref(n_words),
+                           st.ctypes.data_as(dp) if want_times else None, wl.ctypes.data_as(dp) if want_times else None)
+    if rc:
+        for conf, _ in lanes:  # the failing lane's context holds the message
+            msg = (l.ts_last_error(conf.pcs.ctx.h) or b"").decode()
+            if msg:
+                raise _lib.TsError(rc, msg)
+        raise _lib.TsError(rc, "ts_prove_stream")
+    return Proof(out[: n_words.value].copy()), st[:n], wl[:n]
+
+
 def prove_sharded(config: StarkConfig, air, challenger: BfChallenger, trace_rows, public_values,
                   comm, min_local_log: int = 0, trace_replicated: bool = False,
                   local_quotient: bool = False, _options_struct_size: int | None = None) -> Proof:

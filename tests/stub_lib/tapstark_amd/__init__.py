@@ -172,6 +172,29 @@ def prove(config, air_, challenger, trace, public_values):
     return _fake_proof(config.pcs.ctx)
 
 
+def prove_stream(lanes, traces, lane_of, public_values, gate_ms=0.0, want_times=True):
+    """Stand-in for ts_prove_stream: one thread per lane, each 'proof' a sleep."""
+    import threading
+
+    n = len(traces)
+    start, wall = np.zeros(n), np.zeros(n)
+    t_begin = time.perf_counter()
+
+    def lane(l):
+        for i in range(n):
+            if lane_of[i] == l:
+                t0 = time.perf_counter()
+                _fake_proof(lanes[l][0].pcs.ctx)
+                start[i], wall[i] = 1e3 * (t0 - t_begin), 1e3 * (time.perf_counter() - t0)
+
+    th = [threading.Thread(target=lane, args=(l,)) for l in range(len(lanes))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    return Proof(np.arange(64, dtype=np.uint32) if n else np.zeros(0, dtype=np.uint32)), start, wall
+
+
 def prove_sharded(config, air_, challenger, trace_rows, public_values, comm, min_local_log=0,
                   trace_replicated=False, local_quotient=False):
     ctx = config.pcs.ctx

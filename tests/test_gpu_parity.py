@@ -784,3 +784,35 @@ def test_out_of_memory_in_the_middle_of_a_proof():
     proof = ts.prove(config, FibonacciAir(), ts.BfChallenger(), trace, pis)
     ts.verify(config, FibonacciAir(), ts.BfChallenger(), proof, pis)
     del proof, m, c  # the context (and its 128 GB block cache) goes away here
+
+
+# ------------------------------------------------------------------ several proofs in flight, one call
+def test_prove_stream_is_prove_on_several_lanes(ctx, orc):
+    """ts_prove_stream: independent proofs on several contexts, the lane threads inside the library.  Every
+    proof is prove()'s (checked as the returned last proof over runs that end on each lane, and through the
+    start / wall time arrays that every proof ran), a consumed trace is an error of that call, and the gate
+    spaces the starts."""
+    air = SynthMulAir(7)
+    tape = ts.air_tape(air, 0)
+    cfg = (2, 5, 4)
+    ctxs = [ctx, ts.Context(0), ts.Context(0)]
+    lanes = [(ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(*cfg), c)), ts.CompiledAir(c, tape)) for c in ctxs]
+    ocfg = orc.FriConfig(*cfg)
+
+    def trace(i):
+        return generate_synth_mul_trace(1 << 7, 7, seed=1000 + i)
+
+    for n in (1, 3, 7, 8):
+        lane_of = [(i * 2 + 1) % 3 for i in range(n)]
+        mats = [ts.DeviceMatrix.upload(ctxs[lane_of[i]], trace(i)) for i in range(n)]
+        proof, start, wall = ts.prove_stream(lanes, mats, lane_of, [], gate_ms=0.3)
+        want = orc.prove(ocfg, tape, trace(n - 1), [])
+        assert len(proof.words) == len(want) and (proof.words == want).all(), f"n = {n}"
+        assert len(start) == n and (wall > 0).all()
+        s = np.sort(start)
+        assert (np.diff(s) >= 0.3 - 1e-3).all(), "two proofs started within the gate"
+        with pytest.raises(ts._lib.TsError):  # the matrices are spent
+            ts.prove_stream(lanes, mats[:1], lane_of[:1], [])
+    # nothing to do is not an error
+    proof, start, wall = ts.prove_stream(lanes, [], [], [])
+    assert len(proof.words) == 0 and len(start) == 0

@@ -681,9 +681,17 @@ def main():
         return
 
     import numpy as np
-    import torch
+    # Experiment knob (N = 1 only): TS_BENCH_NO_TORCH=1 keeps torch -- and with it the libamdhip64 its wheel bundles
+    # (ROCm 7.0), which the library would otherwise be bound to -- out of the process: the library then runs on the
+    # system's HIP runtime (ROCm 7.2), as a compiled host's process does.
+    no_torch = os.environ.get("TS_BENCH_NO_TORCH") == "1" and env.world == 1 and not sharded and not STUB_LIB
+    if no_torch:
+        os.environ["TS_PRELOAD_TORCH"] = "0"
+        torch = None
+    else:
+        import torch
 
-    if not share_gpu and not STUB_LIB:
+    if not share_gpu and not STUB_LIB and not no_torch:
         local_world = int(os.environ.get("LOCAL_WORLD_SIZE", env.world))
         have = torch.cuda.device_count()
         if have < local_world or env.local_rank >= have:
@@ -1068,6 +1076,7 @@ def main():
                                         f"collectives over {comm.backend}, quotient {'local' if localq else 'broadcast'}" if sharded else
                                        ("1 rank per GPU (replicas)" if env.world > 1 else "1 GPU")
                                        + f", {S} proofs in flight per GPU, starts spaced >= {stagger['ms']:.2f} ms"),
+                       "hip_runtime": "system (torch not imported: TS_BENCH_NO_TORCH=1)" if no_torch else "the one torch's wheel bundles",
                        "lane_driver": ("ts_prove_stream (lane threads, gate and per-proof clock inside the library)"
                                        if (not sharded and S > 1 and stream_ok and pregen) else
                                        "python threads (one ts_prove call per proof per lane)" if S > 1 else "one lane"),

@@ -13,6 +13,12 @@ import threading
 import time
 
 flags = set(sys.argv[2:])
+if "nothp" in flags:  # no transparent huge pages for this process (khugepaged collapsing the interpreter's heap?)
+    import ctypes
+    ctypes.CDLL("libc.so.6").prctl(41, 1, 0, 0, 0)  # PR_SET_THP_DISABLE
+if "noblas" in flags:
+    os.environ["OPENBLAS_NUM_THREADS"] = "1"
+    os.environ["OMP_NUM_THREADS"] = "1"
 if "mallopt" in flags:  # keep glibc from mmap'ing / munmap'ing every buffer above 128 KiB (numpy's proof buffers)
     import ctypes
     libc = ctypes.CDLL("libc.so.6")

@@ -843,11 +843,11 @@ def main():
 
     # How the S lanes are driven.  Default: ONE library call per window (ts_prove_stream): the lane threads, the
     # start gate and the per-proof clock are C++ inside the library, as a compiled host (Rust, C++:
-    # examples/prove_stream.cpp) would have them.  A lane loop in Python threads -- TS_BENCH_PY_LANES=1, what
-    # rounds 3-5 timed -- pays the interpreter lock once per proof and showed, in about one window of thirty,
-    # one to four proofs of 15-50 ms among 11-ms ones (profiles/r06_window_hunt.txt); the C++ loop showed none in
-    # 3600 proofs on the same boxes and runs ~2 % faster.  The timed region is the same either way: EXACTLY K
-    # complete proofs between two barrier + device-sync pairs.
+    # examples/prove_stream.cpp) would have them, and the timed region holds no Python.  TS_BENCH_PY_LANES=1 keeps
+    # the lane loop of rounds 3-5 (Python threads, one ts_prove call per proof).  Same-box A/B: the same ms/step
+    # (2.74-2.78) and the same sporadic slow window either way (profiles/r06_window_hunt.txt) -- the interpreter
+    # lock is not what causes those.  The timed region is the same: EXACTLY K complete proofs between two
+    # barrier + device-sync pairs.
     py_lanes = os.environ.get("TS_BENCH_PY_LANES") == "1" or sharded or args.host_traces
     stream_ok = (not py_lanes) and S > 1 and hasattr(ts, "prove_stream")
     pool = None
@@ -892,13 +892,15 @@ def main():
 
     # The interpreter's cyclic garbage collector is switched off for the priming and the timed windows (and what
     # exists is frozen out of its reach): a generation-2 collection in a process that has imported torch takes
-    # milliseconds WITH the interpreter lock held, and every lane returning from ts_prove would wait for it.  It is
-    # one possible source of the sporadic slow window, and a cheap one to exclude -- but not THE source: about
-    # one window (or priming probe) in forty still takes 2.9-3.2 ms/step instead of 2.73-2.78 with it off, with and
-    # without the amdsmi sampler (profiles/r06_window_hunt.txt).  `proof_latencies_ms_by_lane` of such a window shows
-    # proofs of ALL lanes 2-4 ms late at the same moment: a stall of the whole GPU (or host) of a few ms, about once
-    # per second of proving, outside this process's control.  `value` (window 1) draws such a window with that
-    # probability; the 160-step sustained leg and the other windows are on the record beside it.
+    # milliseconds with the interpreter lock held.  A cheap source of jitter to exclude -- but not the source of the
+    # sporadic slow window: about one window (or priming probe) in thirty reads 2.9-3.3 ms/step instead of 2.73-2.78
+    # because one to four of its proofs take 15-50 ms instead of 11, often on all lanes at once.  Same-box A/Bs
+    # (profiles/r06_window_hunt.txt) found it unchanged by: this switch, the amdsmi sampler child, sleeping or
+    # polling stream waits (TS_SYNC_SPIN), the lane loop in Python threads or inside the library, per-proof or kept
+    # output buffers, torch's bundled HIP runtime or the system's (TS_BENCH_NO_TORCH), transparent huge pages, BLAS
+    # threads; the device pool makes no hipMalloc in a window (TS_POOL_DEBUG).  A process WITHOUT an interpreter
+    # (examples/prove_stream.cpp) showed none in 3600 proofs on the same boxes.  Unexplained; `value` (window 1)
+    # draws such a window with that probability, and the line says when it did (`windows`, `headline_windows`).
     import gc
     keep_gc = os.environ.get("TS_BENCH_KEEP_GC") == "1"  # A/B knob
     if not keep_gc:

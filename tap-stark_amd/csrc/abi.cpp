@@ -1025,8 +1025,7 @@ ts_status ts_prove(ts_ctx* ctx, const ts_fri_config* cfg, const ts_air* air, ts_
 // objects (uni-stark/src/prover.rs:25-35 takes one trace), so several are kept in flight: one proof's kernels
 // fill the gaps the serial transcript of another leaves.  A host whose own threads are cheap (Rust, C++)
 // does this itself; a host behind an interpreter lock (the Python binding: bench.py) gets the same loop
-// without taking its lock once per proof -- the sporadic 15-50 ms proofs of a Python-driven lane loop
-// (profiles/r06_window_hunt.txt) do not occur here (0 in 3600 proofs from the C++ example on the same boxes).
+// without taking its lock once per proof.
 ts_status ts_prove_stream(ts_ctx* const* ctxs, const ts_air* const* airs, uint32_t n_lanes,
                           const ts_fri_config* cfg, ts_matrix* const* traces, const uint32_t* lane_of,
                           uint32_t n_proofs, const uint32_t* public_values, uint32_t n_public, double gate_ms,

@@ -741,10 +741,8 @@ def prove(config: StarkConfig, air, challenger: BfChallenger, trace, public_valu
     Q = pcs.fri.num_queries
     cap = (64 + 8 * w + 16 * qd + 8 * R
            + Q * (16 + w + 5 * qd + 2 * 8 * log_N + R * (9 + 8 * log_N)))
-    # One output buffer per context, kept for its lifetime (a context is driven by one thread).  A fresh
-    # half-megabyte numpy array per proof meant an mmap and a munmap per proof; in a process with several
-    # proving threads that churn stalled ALL of them for 10-20 ms about once per second of proving
-    # (tools/py_stream_stalls.py: none with a kept buffer, none from a C++ host, profiles/r06_window_hunt.txt).
+    # One output buffer per context, kept for its lifetime (a context is driven by one thread): no
+    # half-megabyte allocation, zero-fill and release per proof.
     out = getattr(ctx, "_proof_buf", None)
     if out is None or len(out) < cap:
         out = ctx._proof_buf = np.zeros(cap, dtype=np.uint32)

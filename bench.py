@@ -884,6 +884,31 @@ def main():
         from concurrent.futures import ThreadPoolExecutor
         pool = ThreadPoolExecutor(max_workers=S)  # per-lane priming and the h2d leg still use Python lanes
 
+    # cgroup CPU-bandwidth throttling (cpu.max of the container: e.g. 16 CPUs' worth per 100 ms on a 256-core
+    # host): when the container's processes together exceed the quota inside a period, EVERY thread in it is frozen
+    # until the period ends -- tens of ms during which all lanes stand still.  Read before and after every call of
+    # run_steps (one call = one timed window or warm-up block), so that a window can say whether it was throttled.
+    throttle_log = []
+
+    def read_throttle():
+        try:
+            with open("/sys/fs/cgroup/cpu.stat") as f:
+                kv = dict(line.split() for line in f)
+            return int(kv.get("nr_throttled", 0)), int(kv.get("throttled_usec", 0))
+        except (OSError, ValueError):
+            return None
+
+    if run_steps is not None:
+        _inner_run_steps = run_steps
+
+        def run_steps(first, count):  # noqa: F811
+            a = read_throttle()
+            t_a = time.perf_counter()
+            _inner_run_steps(first, count)
+            b = read_throttle()
+            if a is not None and b is not None:
+                throttle_log.append((t_a, time.perf_counter(), b[0] - a[0], b[1] - a[1]))
+
     def local_sync():
         for c, _, _ in lanes:
             c.synchronize()
@@ -940,7 +965,7 @@ def main():
         # turns the priming off.
         prime_cap = float(os.environ.get("TS_BENCH_PRIME_S", "2.0"))
         prime_min = min(prime_cap, float(os.environ.get("TS_BENCH_PRIME_MIN_S", "0.5")))  # never less than this much load
-        probes = []
+        probes, probes_thr = [], []
         t_prime0 = time.perf_counter()
         while prime_cap > 0 and time.perf_counter() - t_prime0 < prime_cap:
             pm = [make_trace(lanes[i % S][0]) for i in range(args.steps)]
@@ -952,6 +977,7 @@ def main():
                 for i in range(l, args.steps, S):
                     start_gate()
                     ts.prove(conf, ca, ts.BfChallenger(), pm[i], pis)
+            thr_a = read_throttle()
             tp = time.perf_counter()
             if stream_ok:
                 ts.prove_stream(stream_lanes, pm, [i % S for i in range(args.steps)], pis, gate_ms=stagger["ms"],
@@ -963,11 +989,14 @@ def main():
             for c, _, _ in lanes:
                 c.synchronize()
             probes.append(round(1e3 * (time.perf_counter() - tp) / args.steps, 4))
+            thr_b = read_throttle()
+            probes_thr.append(None if thr_a is None or thr_b is None else thr_b[0] - thr_a[0])
             if (len(probes) >= 2 and abs(probes[-1] - probes[-2]) <= 0.015 * min(probes[-1], probes[-2])
                     and time.perf_counter() - t_prime0 >= prime_min):
                 break
         primed["s"] = round(time.perf_counter() - t_prime0, 3)
         primed["probes_ms_per_step"] = probes
+        primed["probes_cgroup_cpu_throttled_times"] = probes_thr
         primed["settled"] = bool(len(probes) >= 2 and abs(probes[-1] - probes[-2]) <= 0.015 * min(probes[-1], probes[-2]))
 
     phase_done("start-up (imports, rendezvous, context, AIR compile)")
@@ -995,6 +1024,9 @@ def main():
         row = {"window": k + 1, "ms_per_step": round(res["windows_ms_per_step"][k], 4)}
         if sampler is not None:
             row.update(sampler.window(w0, w1) if not sampler.error or sampler.samples else {"sampler_error": sampler.error})
+        thr = [e for e in throttle_log if w0 <= e[0] <= w1]
+        if thr:
+            row["cgroup_cpu_throttled"] = {"times": sum(e[2] for e in thr), "thread_usec": sum(e[3] for e in thr)}
         gaps, gate, first_call, last_ret, lat, per_lane = [], 0.0, [], [], [], []
         for li, lg in enumerate(lane_log):
             evs = [e for e in lg if w0 <= e[0] <= w1]
@@ -1057,6 +1089,7 @@ def main():
                 "gfxclk_mhz_median": [r_.get("gfxclk_mhz_median") for r_ in per_window],
                 "socket_power_w_median": [r_.get("socket_power_w_median") for r_ in per_window],
                 "longest_host_gap_ms": [r_.get("longest_host_gap_ms") for r_ in per_window],
+                "cgroup_cpu_throttled_times": [(r_.get("cgroup_cpu_throttled") or {}).get("times") for r_ in per_window],
                 "priming_probes_ms_per_step": primed.get("probes_ms_per_step"), "priming_s": primed.get("s"),
                 "python_gc": "on (TS_BENCH_KEEP_GC=1)" if keep_gc else "disabled and frozen over priming + timed windows",
                 "note": "every timed window of K steps (value = the first); clock / power from an amdsmi child "

@@ -923,7 +923,8 @@ def main():
     # (profiles/r06_window_hunt.txt) found it unchanged by: this switch, the amdsmi sampler child, sleeping or
     # polling stream waits (TS_SYNC_SPIN), the lane loop in Python threads or inside the library, per-proof or kept
     # output buffers, torch's bundled HIP runtime or the system's (TS_BENCH_NO_TORCH), transparent huge pages, BLAS
-    # threads; the device pool makes no hipMalloc in a window (TS_POOL_DEBUG).  A process WITHOUT an interpreter
+    # threads; the device pool makes no hipMalloc in a window (TS_POOL_DEBUG) and the container's CPU quota does not
+    # throttle during one (cpu.stat, read around every window: `cgroup_cpu_throttled`).  A process WITHOUT an interpreter
     # (examples/prove_stream.cpp) showed none in 3600 proofs on the same boxes.  Unexplained; `value` (window 1)
     # draws such a window with that probability, and the line says when it did (`windows`, `headline_windows`).
     import gc

@@ -39,6 +39,52 @@ from tapstark_amd.airs import SynthMulAir  # noqa: E402
 n_proofs = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 S, n, w, cfg = 4, 1 << 20, 64, (2, 28, 8)
 pis = np.zeros(0, dtype=np.uint32)
+if "perthread" in flags:
+    # as examples/prove_stream.cpp: every lane thread makes its OWN context, AIR and traces, primes, then waits at a
+    # barrier; nothing of a lane is ever touched by another thread
+    tape = ts.air_tape(SynthMulAir(64), 0)
+    bar = threading.Barrier(S + 1)
+    lat = [[] for _ in range(S)]
+    t_begin_box = [0.0]
+
+    def lane_main(l):
+        import ctypes as C
+        from tapstark_amd import _lib
+        c = ts.Context(0)
+        conf = ts.StarkConfig(ts.TwoAdicFriPcs(ts.FriConfig(*cfg), c))
+        ca = ts.CompiledAir(c, tape)
+        my = [ts.DeviceMatrix.synth_mul(c, n, w) for _ in range(l, n_proofs, S)]
+        ts.prove(conf, ca, ts.BfChallenger(), ts.DeviceMatrix.synth_mul(c, n, w), pis)
+        c.synchronize()
+        L = _lib.lib()
+        out = np.zeros(1 << 20, dtype=np.uint32)
+        outp = out.ctypes.data_as(_lib.u32p)
+        cfgc = conf.pcs.fri._c()
+        nw = C.c_size_t()
+        bar.wait()
+        for m in my:
+            ch = ts.BfChallenger()
+            t = time.perf_counter()
+            rc = L.ts_prove(c.h, C.byref(cfgc), ca.h, ch.h, m.h, None, 0, outp, len(out), C.byref(nw))
+            lat[l].append((t, time.perf_counter() - t))
+            assert rc == 0
+        c.synchronize()
+
+    th = [threading.Thread(target=lane_main, args=(l,)) for l in range(S)]
+    for t in th:
+        t.start()
+    bar.wait()
+    t_begin = time.perf_counter()
+    for t in th:
+        t.join()
+    dt = time.perf_counter() - t_begin
+    allv = sorted(e[1] for v in lat for e in v)
+    med = allv[len(allv) // 2]
+    slow = [(l, 1e3 * (e[0] - t_begin), 1e3 * e[1]) for l, v in enumerate(lat) for e in v if e[1] > 1.4 * med]
+    print(f"flags {sorted(flags)}: {n_proofs} proofs, {1e3 * dt / n_proofs:.3f} ms/proof (no gate); proof wall time median {1e3 * med:.2f} p99 "
+          f"{1e3 * allv[int(0.99 * len(allv))]:.2f} max {1e3 * allv[-1]:.2f} ms; above 1.4 x median: {len(slow)} "
+          + " ".join(f"[lane {l} @{t:.0f} ms: {d:.1f}]" for l, t, d in slow[:12]), flush=True)
+    sys.exit(0)
 lanes = []
 for _ in range(S):
     c = ts.Context(0)
